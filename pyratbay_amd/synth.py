@@ -1,0 +1,179 @@
+"""Deterministic synthetic workloads of the shapes named in BASELINE.json.
+
+Host-side NumPy only.  The spectral-grid and Voigt-grid set-up mirror what the
+reference's callers do before they reach the native kernels, so that the arrays
+handed to the hot path have the same structure as in a real `pyrat.run()`:
+
+* spectral grid + fine grid + divisors : pyratbay/pyrat/spectrum.py:203-228,
+  pyratbay/tools/tools.py:314-323
+* Voigt width grids and half-sizes      : pyratbay/pyrat/voigt.py:27-130,
+  pyratbay/opacity/broadening/broadening.py:367-498
+* number densities                      : pyratbay/atmosphere/atmosphere.py:629-664
+* line-list ordering (isotope, then wn) : pyratbay/pyrat/line_by_line.py:298-482
+
+Inputs are synthetic: uniform-random line positions,
+Elow ~ U(0, 8000) cm-1, log10 gf ~ U(-12, -6), Z(T) = 1 + T**1.5/10.
+"""
+import numpy as np
+
+# CGS constants used only to *generate inputs* (CODATA-2018 like the reference's
+# Python layer, pyratbay/constants/astrophysical_constants.py:67-109)
+K_B = 1.380649e-16
+AMU = 1.66053906660e-24
+C_LIGHT = 2.99792458e10
+G_GRAV = 6.67430e-8
+BAR = 1e6
+ANGSTROM = 1e-8
+RJUP = 7.1492e9
+RSUN = 6.957e10
+MJUP = 1.8982e30
+
+# name: (mass amu, collision radius Angstrom)
+SPECIES = {
+    'H2': (2.01588, 1.445), 'He': (4.002602, 1.40), 'H2O': (18.01528, 1.60),
+    'CO': (28.0101, 1.69), 'CO2': (44.0095, 1.90), 'CH4': (16.0425, 2.00),
+}
+HCN = np.array([
+    1, 2, 4, 6, 12, 24, 36, 48, 60, 120, 180, 240, 360, 720, 840,
+    1260, 1680, 2160, 2520, 5040, 7560, 10080, 15120, 20160, 25200,
+    27720, 45360, 50400, 55440, 83160, 110880, 221760, 277200])
+
+
+def divisors(number):
+    """All integer divisors of number, ascending (tools.py:314-323)."""
+    number = int(number)
+    divs = [i for i in range(1, number // 2 + 1) if number % i == 0]
+    divs.append(number)
+    return np.asarray(divs, np.int32)
+
+
+def spectral_grid(wnlow, wnhigh, wnstep, wnosamp=None):
+    """Constant-step output grid wn and fine grid own (spectrum.py:182-228)."""
+    if wnosamp is None:
+        wnosamp = int(HCN[wnstep / HCN <= 0.0004][0])
+    nwave = int((wnhigh - wnlow) / wnstep) + 1
+    wn = wnlow + np.arange(nwave) * wnstep
+    ownstep = wnstep / wnosamp
+    onwave = int(np.ceil((wn[-1] - wnlow) / ownstep)) + 1
+    own = wnlow + np.arange(onwave) * ownstep
+    return dict(wn=wn, own=own, wnstep=wnstep, ownstep=ownstep, nwave=nwave,
+                onwave=onwave, wnosamp=int(wnosamp), divisors=divisors(wnosamp))
+
+
+def voigt_widths(wn, press_bar, masses, radii_cm, nlor, ndop, tmin=100.0, tmax=3000.0):
+    """log-spaced Lorentz/Doppler HWHM samples (voigt.py:27-105 with the
+    H2-dominated estimates of broadening.py:411-497)."""
+    h2_rad, h2_mass = 1.445e-8, 2.01588
+    min_mass, max_mass = np.amin(masses), np.amax(masses)
+    min_rad, max_rad = np.amin(radii_cm), np.amax(radii_cm)
+    dmin = np.sqrt(2 * np.log(2) * K_B * tmin / (max_mass * AMU)) * np.amin(wn) / C_LIGHT
+    dmax = np.sqrt(2 * np.log(2) * K_B * tmax / (min_mass * AMU)) * np.amax(wn) / C_LIGHT
+    lmin = (np.sqrt(2 / (np.pi * K_B * tmax * AMU)) * np.amin(press_bar) * BAR
+            * (h2_rad + min_rad)**2 / C_LIGHT * np.sqrt(1 / max_mass + 1 / h2_mass))
+    lmax = (np.sqrt(2 / (np.pi * K_B * tmin * AMU)) * np.amax(press_bar) * BAR
+            * (h2_rad + max_rad)**2 / C_LIGHT * np.sqrt(1 / min_mass + 1 / h2_mass))
+    doppler = np.logspace(np.log10(dmin), np.log10(dmax), ndop)
+    lorentz = np.logspace(np.log10(lmin), np.log10(lmax), nlor)
+    return lorentz, doppler
+
+
+def voigt_sizes(lorentz, doppler, extent, cutoff, ownstep, onwave, dlratio=0.1):
+    """Profile half-sizes in fine-grid samples; 0 marks a cell that is not computed
+    and will alias the previous Doppler column (voigt.py:109-130)."""
+    size = np.zeros((len(lorentz), len(doppler)), np.int64)
+    for i, lor in enumerate(lorentz):
+        pwidth = extent * (0.5346 * lor + np.sqrt(0.2166 * lor**2 + doppler**2))
+        if cutoff > 0:
+            pwidth = np.minimum(pwidth, cutoff)
+        psize = 1 + 2 * np.asarray(pwidth / ownstep + 0.5, int)
+        psize = np.clip(psize, 3, 1 + 2 * onwave)
+        skip = doppler / lor < dlratio
+        skip[0] = False
+        psize[skip] = 0
+        size[i] = psize // 2
+    return size
+
+
+def synthetic_lines(nlines, wnlow, wnhigh, niso=1, seed=42,
+                    ratios=(0.997, 2e-3, 4e-4, 3e-4)):
+    """Line list sorted by isotope then wavenumber, as the TLI reader returns it."""
+    rng = np.random.default_rng(seed)
+    frac = np.asarray(ratios[:niso], float)
+    frac = frac / frac.sum()
+    # most lines belong to the main isotopologue, but give the minor ones enough
+    counts = np.maximum((nlines * np.maximum(frac, 0.05 if niso > 1 else 1.0)
+                         / np.sum(np.maximum(frac, 0.05 if niso > 1 else 1.0))).astype(int), 1)
+    counts[0] += nlines - counts.sum()
+    lwn, lid = [], []
+    for i, c in enumerate(counts):
+        lwn.append(np.sort(rng.uniform(wnlow, wnhigh, c)))
+        lid.append(np.full(c, i, np.int32))
+    lwn = np.concatenate(lwn)
+    lid = np.concatenate(lid)
+    elow = rng.uniform(0.0, 8000.0, nlines)
+    gf = 10.0**rng.uniform(-12.0, -6.0, nlines)
+    return dict(lwn=lwn, elow=elow, gf=gf, lid=lid)
+
+
+def partition_function(temp):
+    return 1.0 + np.asarray(temp, float)**1.5 / 10.0
+
+
+def synthetic_atmosphere(nlayers, species=('H2', 'He', 'H2O'), vmr=(0.85, 0.149, 4e-4),
+                         ptop=1e-6, pbottom=1e2, t_top=1000.0, t_bottom=1700.0,
+                         mplanet=0.6 * MJUP, rplanet=1.0 * RJUP, refpressure=0.1,
+                         rstar=1.27 * RSUN):
+    """Layers from top (low p) to bottom, smooth T(p), uniform VMRs, ideal-gas number
+    densities and a hydrostatic radius profile (g = GM/r**2)."""
+    press = np.logspace(np.log10(ptop), np.log10(pbottom), nlayers)     # bar
+    x = (np.log10(press) - np.log10(ptop)) / (np.log10(pbottom) - np.log10(ptop))
+    temp = t_top + (t_bottom - t_top) * 0.5 * (1 - np.cos(np.pi * x))
+    vmr = np.tile(np.asarray(vmr, float), (nlayers, 1))
+    dens = vmr * np.expand_dims(press / temp, 1) * BAR / K_B             # cm-3
+    mol_mass = np.array([SPECIES[s][0] for s in species])
+    mol_radius = np.array([SPECIES[s][1] for s in species]) * ANGSTROM   # cm
+    mu = np.sum(vmr * mol_mass, axis=1)
+    # hydrostatic: d(1/r) = k T/(mu amu G M) dln p, anchored at refpressure
+    lnp = np.log(press)
+    integrand = K_B * temp / (mu * AMU * G_GRAV * mplanet)
+    cum = np.concatenate([[0.0], np.cumsum(0.5 * (integrand[1:] + integrand[:-1])
+                                           * np.diff(lnp))])
+    cum_ref = np.interp(np.log(refpressure), lnp, cum)
+    radius = 1.0 / (1.0 / rplanet + (cum - cum_ref))
+    return dict(press=press, temp=temp, vmr=vmr, dens=dens, radius=radius,
+                mol_mass=mol_mass, mol_radius=mol_radius, species=list(species),
+                rstar=rstar, nlayers=nlayers)
+
+
+def lbl_case(nwave_target, nlayers, nlines, *, wnlow=4000.0, wnstep=0.05, wnosamp=None,
+             niso=1, nlor=100, ndop=50, extent=300.0, cutoff=25.0, dlratio=0.1,
+             seed=42, species=('H2', 'He', 'H2O'), vmr=(0.85, 0.149, 4e-4),
+             line_species_index=2, iso_masses=None, ptop=1e-6, pbottom=1e2):
+    """Everything the LBL hot path needs for one synthetic spectrum.
+
+    The line-carrying species is species[line_species_index]; its `niso` isotopes
+    have masses m, m+1, ... and the HITEMP-style ratios of SURVEY.md section 8d."""
+    wnhigh = wnlow + (nwave_target - 1) * wnstep
+    grid = spectral_grid(wnlow, wnhigh + 0.5 * wnstep, wnstep, wnosamp)
+    atm = synthetic_atmosphere(nlayers, species, vmr, ptop=ptop, pbottom=pbottom)
+    lines = synthetic_lines(nlines, grid['wn'][0], grid['wn'][-1], niso, seed)
+    m0 = atm['mol_mass'][line_species_index]
+    if iso_masses is None:
+        iso_masses = m0 + np.arange(niso)
+    ratios = np.array((0.997, 2e-3, 4e-4, 3e-4)[:niso]) if niso > 1 else np.array([1.0])
+    iso = dict(
+        isoimol=np.full(niso, line_species_index, np.int32),
+        isomass=np.asarray(iso_masses, float),
+        isoratio=ratios,
+        isoiext=np.zeros(niso, np.int32),
+        isoz=partition_function(atm['temp'])[None, :].repeat(niso, 0),  # [niso, L]
+    )
+    lorentz, doppler = voigt_widths(
+        grid['wn'], atm['press'], np.array([m0]),
+        np.array([atm['mol_radius'][line_species_index]]), nlor, ndop)
+    size = voigt_sizes(lorentz, doppler, extent, cutoff, grid['ownstep'],
+                       grid['onwave'], dlratio)
+    voigt = dict(lorentz=lorentz, doppler=doppler, size=size, extent=extent,
+                 cutoff=cutoff, dlratio=dlratio)
+    return dict(grid=grid, atm=atm, lines=lines, iso=iso, voigt=voigt,
+                ethresh=1e-30, maxdepth=10.0)
