@@ -1,0 +1,195 @@
+/* pbhip.h -- C ABI of libpbhip.so: MI355X (gfx950) kernels for the Pyrat Bay
+ * line-by-line opacity + radiative-transfer hot path.
+ *
+ * Every entry point replaces one native function of the reference (pyratbay v2.0.1,
+ * CPython extension modules under src_c/, file:line cited per function) or one
+ * per-layer / per-impact-parameter Python loop around it.  The reference has no
+ * C-level API of its own (each function parses a PyObject* tuple); this header is
+ * the interface a binding (ctypes stub in INTEGRATION.md) attaches to.
+ *
+ * Conventions
+ *   - `_d` pointers are DEVICE memory (hipMalloc / torch.cuda), `_h` pointers are
+ *     HOST memory.  All arrays are C-contiguous; doubles are binary64; integer
+ *     arrays are int32 (the reference reads/writes C `int` through the NumPy stride,
+ *     src_c/include/ind.h:31-37).
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream).  Calls are
+ *     asynchronous with respect to the host unless stated otherwise.
+ *   - Return value: PB_OK (0) or a negative PB_ERR_* code; pb_last_error() returns a
+ *     thread-local message.  The library never calls exit() and has no CPU fallback:
+ *     without a usable GPU every compute entry fails with PB_ERR_HIP.
+ */
+#ifndef PBHIP_H
+#define PBHIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PB_OK 0
+#define PB_ERR_ARG (-1)         /* invalid argument / shape                      */
+#define PB_ERR_HIP (-2)         /* HIP runtime error (message has the detail)    */
+#define PB_ERR_UNSUPPORTED (-3) /* valid in the reference, not supported here    */
+#define PB_ERR_NOMEM (-4)
+
+const char *pb_last_error(void);
+int pb_version(void);
+int pb_device_count(int *count);
+int pb_set_device(int device);
+
+/* =========================================================================
+ * Voigt profile table  (vprofile.grid, src_c/vprofile.c:42-114;
+ *                       voigtn/voigtxy, src_c/include/voigt.h:147-359)
+ * ========================================================================= */
+typedef struct pb_voigt pb_voigt;
+
+/* Build the table on the device from the width grids and the requested half-sizes
+ * (psize_h[nlor*ndop]; 0 = alias the previous Doppler column, vprofile.c:100-104).
+ * `dwn` is the fine-grid step (spec.ownstep), `osamp` the oversampling factor
+ * (spec.wnosamp) that fixes the phase-major device layout used by the extinction
+ * kernel.  Synchronous. */
+int pb_voigt_create(pb_voigt **out, const double *lorentz_h, int nlor,
+                    const double *doppler_h, int ndop, const int32_t *psize_h,
+                    double dwn, int osamp, int keep_flat, void *stream);
+/* Wrap an existing reference-layout table (what vprofile.grid returned) held on the
+ * host: uploads it and derives the phase-major layout.  psize_h/pindex_h are the
+ * arrays as left by vprofile.grid. */
+int pb_voigt_from_flat(pb_voigt **out, const double *profile_h, int64_t nprofile,
+                       const double *lorentz_h, int nlor, const double *doppler_h,
+                       int ndop, const int32_t *psize_h, const int32_t *pindex_h,
+                       int osamp, int keep_flat, void *stream);
+/* Outputs of vprofile.grid: final half-sizes, start indices, number of samples. */
+int pb_voigt_meta(const pb_voigt *v, int32_t *psize_h, int32_t *pindex_h,
+                  int64_t *nprofile);
+/* Reference-layout table (concatenated profiles) copied to host memory. */
+int pb_voigt_flat_to_host(pb_voigt *v, double *profile_h, int64_t nprofile);
+int64_t pb_voigt_device_bytes(const pb_voigt *v);
+void pb_voigt_destroy(pb_voigt *v);
+
+/* =========================================================================
+ * Line list  (arrays read by _extcoeff.extinction, src_c/_extcoeff.c:87-123;
+ *             TLI reader pyratbay/pyrat/line_by_line.py:298-482)
+ * ========================================================================= */
+typedef struct pb_lines pb_lines;
+
+/* Upload a line list and pre-compute what depends only on (lwn, lID, own): the
+ * in-range mask, the nearest fine-grid index of each line (_extcoeff.c:243-245) and
+ * the greedy co-add groups (_extcoeff.c:248-262).  own_h may be NULL, in which case
+ * own[i] = own0 + i*ownstep is generated exactly as NumPy does
+ * (pyratbay/pyrat/spectrum.py:222). */
+int pb_lines_create(pb_lines **out, const double *lwn_h, const double *elow_h,
+                    const double *gf_h, const int32_t *lid_h, int64_t nlines, int niso,
+                    const double *own_h, int64_t onwn, double own0, double ownstep);
+/* stats[0]=lines in range, [1]=groups, [2]=co-added lines (nadd of _extcoeff.c:256) */
+int pb_lines_stats(const pb_lines *l, int64_t stats[3]);
+void pb_lines_destroy(pb_lines *l);
+
+/* =========================================================================
+ * Line-by-line extinction for ALL layers in one call
+ * (replaces the per-layer loop pyratbay/pyrat/extinction.py:170-213 around
+ *  _extcoeff.extinction, src_c/_extcoeff.c:87-345)
+ * ========================================================================= */
+typedef struct pb_lbl pb_lbl;
+
+int pb_lbl_create(pb_lbl **out, pb_voigt *voigt, pb_lines *lines,
+                  const double *wn_h, int nwave,
+                  const int32_t *divisors_h, int ndivs,
+                  const double *molrad_h, const double *molmass_h, int nmol,
+                  const int32_t *isoimol_h, const double *isomass_h,
+                  const double *isoratio_h, const int32_t *isoiext_h, int niso,
+                  double cutoff, double ethresh, int resolution, int max_layers);
+/* Change the species-selection flags (isoiext < 0 = neglect; extinction.py:164-167) */
+int pb_lbl_set_isoiext(pb_lbl *p, const int32_t *isoiext_h);
+int pb_lbl_set_ethresh(pb_lbl *p, double ethresh);
+/* ext_d[nlayers, nrows, wcount] with nrows = 1 if add else (max isoiext)+1, for the
+ * output samples [wbegin, wbegin+wcount) of the global grid (wavenumber shard).
+ * temp_d[nlayers]; dens_d[nlayers, nmol]; isoz_d element (i,l) at
+ * isoz_d[i*z_iso_stride + l*z_layer_stride].  Resample mode assigns, resolution
+ * (linterp) mode accumulates into ext_d, like the reference. */
+int pb_lbl_extinction(pb_lbl *p, double *ext_d, int64_t wbegin, int64_t wcount,
+                      const double *temp_d, const double *dens_d, const double *isoz_d,
+                      int64_t z_iso_stride, int64_t z_layer_stride, int nlayers, int add,
+                      void *stream);
+/* Diagnostics of the last call, copied to host (synchronises the stream):
+ * ofactor_h[nlayers] (dynamic-sampling factor, _extcoeff.c:195) and
+ * kmax_h[nlayers*nrows] (per-species maximum line strength, :225). */
+int pb_lbl_last_state(pb_lbl *p, int32_t *ofactor_h, double *kmax_h, int nlayers,
+                      int nrows, void *stream);
+void pb_lbl_destroy(pb_lbl *p);
+
+/* =========================================================================
+ * Cross-section table interpolation (_extcoeff.interp_ec / interp_ec_per_mol,
+ * src_c/_extcoeff.c:367-472).  etable_d[nmol,ntemp,nlayers,nwave]; ttable_d[ntemp];
+ * temperatures_d[nlayers];
+ * density_d[nlayers,nmol]; accumulates into extinction_d[nlayers,nwave]
+ * (per_mol: [nmol,nlayers,nwave]) for layers lay1 <= k < min(lay2,nlayers).
+ * ========================================================================= */
+int pb_interp_ec(double *extinction_d, const double *etable_d, const double *ttable_d,
+                 const double *temperatures_d, const double *density_d, int nmol,
+                 int ntemp, int nlayers, int nwave, int lay1, int lay2, int per_mol,
+                 void *stream);
+
+/* =========================================================================
+ * Optical depth
+ * ========================================================================= */
+/* One impact parameter: _trapezoid.optdepth (src_c/_trapezoid.c:238-276).
+ * data_d[(nint+1), nwave] rows row_stride elements apart. */
+int pb_optdepth(double *tau_d, const double *data_d, int64_t row_stride,
+                const double *intervals_d, int nint, double taumax, int32_t *ideep_d,
+                int ilay, int nwave, void *stream);
+/* All impact parameters in one launch: the loop of
+ * pyratbay/opacity/optic_depth.py:103-112 including the final
+ * `ideep[ideep<0] = r`.  raypath_d is the packed lower triangle of
+ * atmosphere.transit_path(radius, itop): row r (itop<=r<nlayers) has r-itop
+ * entries starting at ((r-itop)*(r-itop-1))/2.  depth_d[nlayers,nwave] is fully
+ * written (rows outside [itop,ibottom) and below ideep are zero). */
+int pb_optical_depth_transit(double *depth_d, int32_t *ideep_d, const double *ec_d,
+                             const double *raypath_d, int itop, int ibottom,
+                             double maxdepth, int nlayers, int nwave, void *stream);
+/* _trapezoid.plane_parallel_optical_depth (src_c/_trapezoid.c:175-213); rows below
+ * the stopping layer are left as passed in, like the reference. */
+int pb_plane_parallel_optical_depth(double *depth_d, int32_t *ideep_d,
+                                    const double *ec_d, const double *intervals_d,
+                                    double maxdepth, int itop, int ibottom, int nlayers,
+                                    int nwave, void *stream);
+
+/* =========================================================================
+ * Spectrum integrals
+ * ========================================================================= */
+/* _trapezoid.trapezoid2D (src_c/_trapezoid.c:70-90): data_d[nrows,nwave] */
+int pb_trapezoid2D(double *out_d, const double *data_d, const double *intervals_d,
+                   const int32_t *nint_d, int nrows, int nwave, void *stream);
+/* Fused transmission spectrum = radiative_transfer.transmission without cloud deck
+ * (pyratbay/spectrum/radiative_transfer.py:57-71): exp(-depth)*r, trapezoid2D over
+ * ideep-itop intervals, (r_top^2 + 2*integral)/rstar^2. */
+int pb_transmission(double *spectrum_d, const double *depth_d, const int32_t *ideep_d,
+                    const double *radius_d, int itop, double rstar, int nlayers,
+                    int nwave, void *stream);
+/* _blackbody.blackbody_wn_2D / blackbody_wn (src_c/_blackbody.c:35-130);
+ * last_d may be NULL. */
+int pb_blackbody_wn_2D(double *B_d, const double *wn_d, int nwave, const double *temp_d,
+                       int nlayers, const int32_t *last_d, void *stream);
+int pb_blackbody_wn(double *B_d, const double *wn_d, int nwave, double temp, void *stream);
+/* _trapezoid.intensity (src_c/_trapezoid.c:304-341): out_d[nmu,nwave] */
+int pb_intensity(double *out_d, const double *tau_d, const int32_t *ideep_d,
+                 const double *bbody_d, const double *mu_d, int nmu, int rtop,
+                 int nlayers, int nwave, void *stream);
+/* Fused emission: Planck evaluated in registers (never stored), intensity per mu and
+ * flux = sum_k I_k * w_k (pyratbay/pyrat/spectrum.py:366-377).  intensity_d may be
+ * NULL. */
+int pb_emission_flux(double *flux_d, double *intensity_d, const double *tau_d,
+                     const int32_t *ideep_d, const double *wn_d, const double *temp_d,
+                     const double *mu_d, const double *weights_d, int nmu, int rtop,
+                     int nlayers, int nwave, void *stream);
+/* _simpson.simps2D (src_c/_simpson.c:167-203): y_d[ny,nwave] */
+int pb_simps2D(double *out_d, const double *y_d, int ny, int nwave, const double *h_d,
+               const int32_t *nint_d, const double *hsum_d, const double *hratio_d,
+               const double *hfactor_d, void *stream);
+/* cutils.ediff (src_c/cutils.c:27-42) */
+int pb_ediff(double *out_d, const double *arr_d, int n, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PBHIP_H */

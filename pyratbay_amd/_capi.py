@@ -1,0 +1,109 @@
+"""ctypes binding of libpbhip.so (include/pbhip.h).
+
+There is no CPU fallback: if the shared library is missing or a call fails, an
+exception is raised.  torch is used only as plumbing for device memory and streams.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIBPATH = os.path.join(_HERE, 'libpbhip.so')
+
+PB_OK = 0
+
+
+class PbError(RuntimeError):
+    pass
+
+
+_lib = None
+
+vp = C.c_void_p
+i32, i64, f64 = C.c_int, C.c_int64, C.c_double
+
+# name: argtypes (all functions return int unless listed in _RESTYPES)
+_PROTOS = {
+    'pb_version': [],
+    'pb_device_count': [C.POINTER(C.c_int)],
+    'pb_set_device': [i32],
+    'pb_voigt_create': [C.POINTER(vp), vp, i32, vp, i32, vp, f64, i32, i32, vp],
+    'pb_voigt_from_flat': [C.POINTER(vp), vp, i64, vp, i32, vp, i32, vp, vp, i32, i32, vp],
+    'pb_voigt_meta': [vp, vp, vp, C.POINTER(i64)],
+    'pb_voigt_flat_to_host': [vp, vp, i64],
+    'pb_voigt_device_bytes': [vp],
+    'pb_voigt_destroy': [vp],
+    'pb_lines_create': [C.POINTER(vp), vp, vp, vp, vp, i64, i32, vp, i64, f64, f64],
+    'pb_lines_stats': [vp, C.POINTER(i64 * 3)],
+    'pb_lines_destroy': [vp],
+    'pb_lbl_create': [C.POINTER(vp), vp, vp, vp, i32, vp, i32, vp, vp, i32, vp, vp, vp, vp,
+                      i32, f64, f64, i32, i32],
+    'pb_lbl_set_isoiext': [vp, vp],
+    'pb_lbl_set_ethresh': [vp, f64],
+    'pb_lbl_extinction': [vp, vp, i64, i64, vp, vp, vp, i64, i64, i32, i32, vp],
+    'pb_lbl_last_state': [vp, vp, vp, i32, i32, vp],
+    'pb_lbl_destroy': [vp],
+    'pb_interp_ec': [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp],
+    'pb_optdepth': [vp, vp, i64, vp, i32, f64, vp, i32, i32, vp],
+    'pb_optical_depth_transit': [vp, vp, vp, vp, i32, i32, f64, i32, i32, vp],
+    'pb_plane_parallel_optical_depth': [vp, vp, vp, vp, f64, i32, i32, i32, i32, vp],
+    'pb_trapezoid2D': [vp, vp, vp, vp, i32, i32, vp],
+    'pb_transmission': [vp, vp, vp, vp, i32, f64, i32, i32, vp],
+    'pb_blackbody_wn_2D': [vp, vp, i32, vp, i32, vp, vp],
+    'pb_blackbody_wn': [vp, vp, i32, f64, vp],
+    'pb_intensity': [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp],
+    'pb_emission_flux': [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp],
+    'pb_simps2D': [vp, vp, i32, i32, vp, vp, vp, vp, vp, vp],
+    'pb_ediff': [vp, vp, i32, vp],
+}
+_RESTYPES = {'pb_voigt_destroy': None, 'pb_lines_destroy': None, 'pb_lbl_destroy': None,
+             'pb_voigt_device_bytes': i64}
+_NO_CHECK = set(_RESTYPES) | {'pb_version'}
+
+
+def exported_names():
+    return sorted(list(_PROTOS) + ['pb_last_error'])
+
+
+def lib():
+    """Load libpbhip.so or fail loudly."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIBPATH):
+            raise PbError(
+                f'{LIBPATH} is missing: build it with `make -C pyratbay_amd/csrc` '
+                '(or __graft_entry__.build()); there is no CPU fallback')
+        handle = C.CDLL(LIBPATH)
+        handle.pb_last_error.restype = C.c_char_p
+        handle.pb_last_error.argtypes = []
+        for name, args in _PROTOS.items():
+            fn = getattr(handle, name)
+            fn.argtypes = args
+            fn.restype = _RESTYPES.get(name, C.c_int)
+        _lib = handle
+    return _lib
+
+
+def call(name, *args):
+    fn = getattr(lib(), name)
+    rc = fn(*args)
+    if name not in _NO_CHECK and rc != PB_OK:
+        raise PbError(f'{name} failed ({rc}): {lib().pb_last_error().decode()}')
+    return rc
+
+
+def hptr(a):
+    """Host pointer of a C-contiguous NumPy array (or None)."""
+    if a is None:
+        return None
+    assert a.flags.c_contiguous
+    return a.ctypes.data_as(vp)
+
+
+def f64h(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def i32h(a):
+    return np.ascontiguousarray(a, dtype=np.int32)

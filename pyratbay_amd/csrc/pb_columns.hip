@@ -1,0 +1,562 @@
+// Column (per-wavenumber) kernels: optical depth, transmission / emission integrals,
+// Planck function, Simpson.  All are HBM-streaming: the [layer][wavenumber] arrays are
+// row-major so that the 64 lanes of a wavefront read 512 contiguous bytes of one layer
+// and walk down the layers; per-layer scalars (ray paths, radii, temperatures, mu) are
+// wave-uniform and come through the scalar cache or LDS.
+//
+// Reference functions restated (pyratbay v2.0.1): src_c/_trapezoid.c:70-341,
+// src_c/_blackbody.c:35-130, src_c/_simpson.c:167-203, src_c/cutils.c:27-42 and the
+// Python loops pyratbay/opacity/optic_depth.py:103-112,
+// pyratbay/spectrum/radiative_transfer.py:57-71, pyratbay/pyrat/spectrum.py:366-377.
+#include "pb_common.h"
+
+namespace {
+
+constexpr int kBlock = 256;
+constexpr int kMaxMu = 16;
+
+// ---------------------------------------------------------------------------
+// cutils.ediff
+// ---------------------------------------------------------------------------
+__global__ void k_ediff(double *out, const double *arr, int n)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i + 1 < n)
+        out[i] = arr[i + 1] - arr[i];
+}
+
+// ---------------------------------------------------------------------------
+// _trapezoid.optdepth: one impact parameter (src_c/_trapezoid.c:238-276)
+// ---------------------------------------------------------------------------
+__global__ void k_optdepth(double *tau, const double *data, int64_t row_stride,
+                           const double *h, int nint, double taumax, int32_t *ideep,
+                           int ilay, int nwave)
+{
+    int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= nwave)
+        return;
+    double acc = 0.0;
+    if (ideep[j] < 0) {
+        double prev = nint > 0 ? data[j] : 0.0;
+        for (int i = 0; i < nint; i++) {
+            double next = data[(int64_t)(i + 1) * row_stride + j];
+            acc += h[i] * (next + prev);
+            prev = next;
+        }
+        if (acc > taumax)
+            ideep[j] = ilay;
+    }
+    tau[j] = acc;
+}
+
+// ---------------------------------------------------------------------------
+// Transit optical depth for all impact parameters (optic_depth.py:103-112).
+// One workgroup = 64 columns x 4 waves.  The ec tile [nlayers][64] and the packed
+// ray-path triangle are staged in LDS; wave q computes rows itop+q, itop+q+4, ...
+// (row r costs r-itop FMAs, so the interleave balances the waves).  The per-column
+// first crossing of maxdepth is an LDS min; rows below it are then zeroed, which
+// reproduces the sequential early exit of the reference.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_transit_depth(
+    double *depth, int32_t *ideep, const double *ec, const double *raypath, int itop,
+    int ibottom, double maxdepth, int nlayers, int nwave)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int nrow = nlayers - itop;            // rows held in LDS (layers itop..L-1)
+    double *s_ec = reinterpret_cast<double *>(smem);            // [nrow][64]
+    double *s_path = s_ec + (size_t)nrow * 64;                  // packed triangle
+    int *s_first = reinterpret_cast<int *>(s_path + (size_t)nrow * (nrow - 1) / 2);  // [64]
+
+    const int lane = threadIdx.x & 63;
+    const int q = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int col = blockIdx.x * 64 + lane;
+    const bool live = col < nwave;
+    const int ntri = nrow * (nrow - 1) / 2;
+
+    for (int r = q; r < nrow; r += 4)
+        s_ec[r * 64 + lane] = live ? ec[(int64_t)(itop + r) * nwave + col] : 0.0;
+    for (int i = threadIdx.x; i < ntri; i += kBlock)
+        s_path[i] = raypath[i];
+    if (threadIdx.x < 64)
+        s_first[threadIdx.x] = 0x7fffffff;
+    __syncthreads();
+
+    const int nimpact = ibottom - itop;         // rows itop..ibottom-1 are evaluated
+    // pass 1: tau for every evaluated row, remember the first crossing
+    int first = 0x7fffffff;
+    for (int r = q; r < nrow; r += 4) {
+        double acc = 0.0;
+        if (r < nimpact) {
+            const double *path = s_path + (r * (r - 1)) / 2;
+            double prev = s_ec[lane];
+            for (int i = 0; i < r; i++) {
+                double next = s_ec[(i + 1) * 64 + lane];
+                acc += path[i] * (next + prev);
+                prev = next;
+            }
+            if (acc > maxdepth && r < first)
+                first = r;
+        }
+        if (live)
+            depth[(int64_t)(itop + r) * nwave + col] = acc;
+    }
+    if (first != 0x7fffffff)
+        atomicMin(&s_first[lane], first);
+    // rows above itop are never touched by the reference loop (depth starts at zero)
+    for (int r = q; r < itop; r += 4)
+        if (live)
+            depth[(int64_t)r * nwave + col] = 0.0;
+    __syncthreads();
+
+    // pass 2: rows below the first crossing stay zero in the reference
+    const int stop = s_first[lane];
+    if (stop != 0x7fffffff) {
+        for (int r = q; r < nimpact; r += 4)
+            if (r > stop && live)
+                depth[(int64_t)(itop + r) * nwave + col] = 0.0;
+    }
+    if (q == 0 && live) {
+        // ideep[ideep<0] = r with r the last loop value (itop if the loop is empty)
+        int last = nimpact > 0 ? ibottom - 1 : itop;
+        ideep[col] = stop != 0x7fffffff ? itop + stop : last;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// _trapezoid.plane_parallel_optical_depth (src_c/_trapezoid.c:175-213)
+// ---------------------------------------------------------------------------
+__global__ void k_plane_depth(double *depth, int32_t *ideep, const double *ec,
+                              const double *h, double maxdepth, int itop, int ibottom,
+                              int nlayers, int nwave)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nwave)
+        return;
+    double acc = 0.0;
+    double prev = 0.0;
+    int k;
+    for (k = 0; k < nlayers; k++) {
+        if (k <= itop) {
+            depth[(int64_t)k * nwave + i] = 0.0;
+            if (k == itop)
+                prev = ec[(int64_t)k * nwave + i];
+            continue;
+        }
+        double cur = ec[(int64_t)k * nwave + i];
+        acc += 0.5 * h[k - 1] * (cur + prev);
+        prev = cur;
+        depth[(int64_t)k * nwave + i] = acc;
+        if (acc >= maxdepth || k == ibottom || k == nlayers - 1)
+            break;
+    }
+    ideep[i] = k;
+}
+
+// ---------------------------------------------------------------------------
+// _trapezoid.trapezoid2D (src_c/_trapezoid.c:70-90)
+// ---------------------------------------------------------------------------
+__global__ void k_trapezoid2d(double *out, const double *data, const double *h,
+                              const int32_t *nint, int nrows, int nwave)
+{
+    int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= nwave)
+        return;
+    int n = nint[j];
+    if (n > nrows - 1)
+        n = nrows - 1;      // the reference would read past the array
+    double acc = 0.0;
+    if (n > 0) {
+        double prev = data[j];
+        for (int i = 0; i < n; i++) {
+            double next = data[(int64_t)(i + 1) * nwave + j];
+            acc += h[i] * (prev + next);
+            prev = next;
+        }
+    }
+    out[j] = acc * 0.5;
+}
+
+// ---------------------------------------------------------------------------
+// Fused transmission spectrum (radiative_transfer.py:57-71, no cloud deck)
+// ---------------------------------------------------------------------------
+__global__ void k_transmission(double *spectrum, const double *depth,
+                               const int32_t *ideep, const double *radius, int itop,
+                               double rstar, int nlayers, int nwave)
+{
+    int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= nwave)
+        return;
+    int n = ideep[j] - itop;                 // number of intervals
+    if (n > nlayers - 1 - itop)
+        n = nlayers - 1 - itop;
+    double acc = 0.0;
+    if (n > 0) {
+        double rprev = radius[itop];
+        double prev = exp(-depth[(int64_t)itop * nwave + j]) * rprev;
+        for (int i = 0; i < n; i++) {
+            double rnext = radius[itop + i + 1];
+            double next = exp(-depth[(int64_t)(itop + i + 1) * nwave + j]) * rnext;
+            acc += (rnext - rprev) * (prev + next);
+            prev = next;
+            rprev = rnext;
+        }
+    }
+    acc *= 0.5;
+    double rtop = radius[itop];
+    spectrum[j] = (rtop * rtop + 2 * acc) / (rstar * rstar);
+}
+
+// ---------------------------------------------------------------------------
+// Planck function (src_c/_blackbody.c:35-130)
+// ---------------------------------------------------------------------------
+__device__ inline double planck_factor(double wn)
+{
+    return 2 * pb::kH * pb::kLS * pb::kLS * pow(wn, 3.0);
+}
+__device__ inline double planck(double factor, double wn, double temp)
+{
+    return factor / (exp(pb::kH * pb::kLS * wn / (pb::kKB * temp)) - 1.0);
+}
+
+__global__ void k_blackbody2d(double *B, const double *wn, int nwave, const double *temp,
+                              int nlayers, const int32_t *last)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    int j = blockIdx.y;
+    if (i >= nwave)
+        return;
+    int ilast = last ? last[i] : nlayers - 1;
+    if (j > ilast)
+        return;
+    double w = wn[i];
+    B[(int64_t)j * nwave + i] = planck(planck_factor(w), w, temp[j]);
+}
+
+__global__ void k_blackbody1d(double *B, const double *wn, int nwave, double temp)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nwave)
+        return;
+    double w = wn[i];
+    B[i] = planck(planck_factor(w), w, temp);
+}
+
+// ---------------------------------------------------------------------------
+// _trapezoid.intensity (src_c/_trapezoid.c:304-341; tdiff/itrapezoid utils.h:6-41)
+// one thread per (column, mu)
+// ---------------------------------------------------------------------------
+__global__ void k_intensity(double *out, const double *tau, const int32_t *ideep,
+                            const double *bbody, const double *mu, int nmu, int rtop,
+                            int nlayers, int nwave)
+{
+    int j = blockIdx.x * blockDim.x + threadIdx.x;
+    int k = blockIdx.y;
+    if (j >= nwave)
+        return;
+    int last = ideep[j];
+    if (last > nlayers - 1)
+        last = nlayers - 1;
+    const double m = mu[k];
+    double blast = bbody[(int64_t)last * nwave + j];
+    double result;
+    if (last - rtop == 1) {
+        result = blast;
+    } else {
+        double acc = 0.0;
+        if (last > rtop) {
+            double eprev = exp(-tau[(int64_t)rtop * nwave + j] / m);
+            double bprev = bbody[(int64_t)rtop * nwave + j];
+            for (int i = rtop; i < last; i++) {
+                double enext = exp(-tau[(int64_t)(i + 1) * nwave + j] / m);
+                double bnext = bbody[(int64_t)(i + 1) * nwave + j];
+                acc += (enext - eprev) * (bnext + bprev);
+                eprev = enext;
+                bprev = bnext;
+            }
+        }
+        result = blast * exp(-tau[(int64_t)last * nwave + j] / m) - 0.5 * acc;
+    }
+    out[(int64_t)k * nwave + j] = result;
+}
+
+// ---------------------------------------------------------------------------
+// Fused emission: Planck in registers + intensity for every mu + quadrature sum
+// (pyrat/spectrum.py:366-377).  One thread per column, layers outermost so that
+// tau is read once; the nmu running sums live in registers.
+// ---------------------------------------------------------------------------
+__global__ void k_emission_flux(double *flux, double *intensity, const double *tau,
+                                const int32_t *ideep, const double *wn,
+                                const double *temp, const double *mu,
+                                const double *weights, int nmu, int rtop, int nlayers,
+                                int nwave)
+{
+    int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= nwave)
+        return;
+    int last = ideep[j];
+    if (last > nlayers - 1)
+        last = nlayers - 1;
+    const double w = wn[j];
+    const double factor = planck_factor(w);
+    double acc[kMaxMu], eprev[kMaxMu];
+    double t0 = tau[(int64_t)rtop * nwave + j];
+#pragma unroll
+    for (int k = 0; k < kMaxMu; k++) {
+        acc[k] = 0.0;
+        eprev[k] = k < nmu ? exp(-t0 / mu[k]) : 0.0;
+    }
+    double bprev = planck(factor, w, temp[rtop]);
+    double tlast = t0;
+    for (int i = rtop; i < last; i++) {
+        double t = tau[(int64_t)(i + 1) * nwave + j];
+        double bnext = planck(factor, w, temp[i + 1]);
+        double bsum = bnext + bprev;
+#pragma unroll
+        for (int k = 0; k < kMaxMu; k++) {
+            if (k < nmu) {
+                double enext = exp(-t / mu[k]);
+                acc[k] += (enext - eprev[k]) * bsum;
+                eprev[k] = enext;
+            }
+        }
+        bprev = bnext;
+        tlast = t;
+    }
+    double blast = (last > rtop) ? bprev : planck(factor, w, temp[last]);
+    if (last <= rtop)
+        tlast = tau[(int64_t)last * nwave + j];
+    double total = 0.0;
+#pragma unroll
+    for (int k = 0; k < kMaxMu; k++) {
+        if (k < nmu) {
+            double val;
+            if (last - rtop == 1)
+                val = blast;
+            else
+                val = blast * exp(-tlast / mu[k]) - 0.5 * acc[k];
+            if (intensity)
+                intensity[(int64_t)k * nwave + j] = val;
+            total += val * weights[k];
+        }
+    }
+    flux[j] = total;
+}
+
+// ---------------------------------------------------------------------------
+// _simpson.simps2D (src_c/_simpson.c:167-203, include/simpson.h:29-47)
+// ---------------------------------------------------------------------------
+__global__ void k_simps2d(double *out, const double *y, int ny, int nwave,
+                          const double *h, const int32_t *nint, const double *hsum,
+                          const double *hratio, const double *hfactor)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nwave)
+        return;
+    int n = nint[i];
+    if (n > ny)
+        n = ny;
+    double res;
+    if (n < 2) {
+        res = 0.0;
+    } else if (n == 2) {
+        res = h[0] * 0.5 * (y[i] + y[(int64_t)nwave + i]);
+    } else {
+        double acc = 0.0;
+        for (int p = 0; p < (n - 1) / 2; p++) {
+            int j = 2 * p;
+            acc += (y[(int64_t)j * nwave + i] * (2.0 - 1.0 / hratio[p]) +
+                    y[(int64_t)(j + 1) * nwave + i] * hfactor[p] +
+                    y[(int64_t)(j + 2) * nwave + i] * (2.0 - hratio[p])) * hsum[p];
+        }
+        res = acc / 6.0;
+        if (n % 2 == 0)
+            res += h[n - 2] * 0.5 *
+                   (y[(int64_t)(n - 2) * nwave + i] + y[(int64_t)(n - 1) * nwave + i]);
+    }
+    out[i] = res;
+}
+
+}  // namespace
+
+// ===========================================================================
+// C ABI
+// ===========================================================================
+extern "C" {
+
+int pb_ediff(double *out_d, const double *arr_d, int n, void *stream)
+{
+    PB_REQUIRE(n >= 0, "pb_ediff: n < 0");
+    if (n < 2)
+        return PB_OK;
+    PB_REQUIRE(out_d && arr_d, "pb_ediff: null pointer");
+    k_ediff<<<pb::div_up(n - 1, kBlock), kBlock, 0, pb::as_stream(stream)>>>(out_d, arr_d, n);
+    PB_LAUNCH_CHECK();
+    return PB_OK;
+}
+
+int pb_optdepth(double *tau_d, const double *data_d, int64_t row_stride,
+                const double *intervals_d, int nint, double taumax, int32_t *ideep_d,
+                int ilay, int nwave, void *stream)
+{
+    PB_REQUIRE(nwave >= 0 && nint >= 0, "pb_optdepth: negative size");
+    if (nwave == 0)
+        return PB_OK;
+    PB_REQUIRE(tau_d && data_d && ideep_d && (nint == 0 || intervals_d),
+               "pb_optdepth: null pointer");
+    PB_REQUIRE(row_stride >= nwave, "pb_optdepth: row_stride < nwave");
+    k_optdepth<<<pb::div_up(nwave, kBlock), kBlock, 0, pb::as_stream(stream)>>>(
+        tau_d, data_d, row_stride, intervals_d, nint, taumax, ideep_d, ilay, nwave);
+    PB_LAUNCH_CHECK();
+    return PB_OK;
+}
+
+int pb_optical_depth_transit(double *depth_d, int32_t *ideep_d, const double *ec_d,
+                             const double *raypath_d, int itop, int ibottom,
+                             double maxdepth, int nlayers, int nwave, void *stream)
+{
+    PB_REQUIRE(nlayers > 0 && nwave >= 0, "pb_optical_depth_transit: bad shape");
+    PB_REQUIRE(itop >= 0 && itop < nlayers, "pb_optical_depth_transit: itop out of range");
+    PB_REQUIRE(ibottom <= nlayers, "pb_optical_depth_transit: ibottom > nlayers");
+    if (nwave == 0)
+        return PB_OK;
+    PB_REQUIRE(depth_d && ideep_d && ec_d, "pb_optical_depth_transit: null pointer");
+    const int nrow = nlayers - itop;
+    PB_REQUIRE(nrow == 1 || raypath_d, "pb_optical_depth_transit: null raypath");
+    size_t lds = (size_t)nrow * 64 * 8 + (size_t)nrow * (nrow - 1) / 2 * 8 + 64 * 4;
+    if (lds > 160 * 1024) {
+        pb::set_error("pb_optical_depth_transit: %d layers need %zu B of LDS (>160 KiB)",
+                      nrow, lds);
+        return PB_ERR_UNSUPPORTED;
+    }
+    PB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_transit_depth),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    k_transit_depth<<<pb::div_up(nwave, 64), kBlock, lds, pb::as_stream(stream)>>>(
+        depth_d, ideep_d, ec_d, raypath_d, itop, ibottom, maxdepth, nlayers, nwave);
+    PB_LAUNCH_CHECK();
+    return PB_OK;
+}
+
+int pb_plane_parallel_optical_depth(double *depth_d, int32_t *ideep_d,
+                                    const double *ec_d, const double *intervals_d,
+                                    double maxdepth, int itop, int ibottom, int nlayers,
+                                    int nwave, void *stream)
+{
+    PB_REQUIRE(nlayers > 0 && nwave >= 0, "pb_plane_parallel_optical_depth: bad shape");
+    PB_REQUIRE(itop >= 0, "pb_plane_parallel_optical_depth: itop < 0");
+    if (nwave == 0)
+        return PB_OK;
+    PB_REQUIRE(depth_d && ideep_d && ec_d && (nlayers == 1 || intervals_d),
+               "pb_plane_parallel_optical_depth: null pointer");
+    k_plane_depth<<<pb::div_up(nwave, kBlock), kBlock, 0, pb::as_stream(stream)>>>(
+        depth_d, ideep_d, ec_d, intervals_d, maxdepth, itop, ibottom, nlayers, nwave);
+    PB_LAUNCH_CHECK();
+    return PB_OK;
+}
+
+int pb_trapezoid2D(double *out_d, const double *data_d, const double *intervals_d,
+                   const int32_t *nint_d, int nrows, int nwave, void *stream)
+{
+    PB_REQUIRE(nrows >= 1 && nwave >= 0, "pb_trapezoid2D: bad shape");
+    if (nwave == 0)
+        return PB_OK;
+    PB_REQUIRE(out_d && data_d && nint_d && (nrows == 1 || intervals_d),
+               "pb_trapezoid2D: null pointer");
+    k_trapezoid2d<<<pb::div_up(nwave, kBlock), kBlock, 0, pb::as_stream(stream)>>>(
+        out_d, data_d, intervals_d, nint_d, nrows, nwave);
+    PB_LAUNCH_CHECK();
+    return PB_OK;
+}
+
+int pb_transmission(double *spectrum_d, const double *depth_d, const int32_t *ideep_d,
+                    const double *radius_d, int itop, double rstar, int nlayers,
+                    int nwave, void *stream)
+{
+    PB_REQUIRE(nlayers > 0 && nwave >= 0, "pb_transmission: bad shape");
+    PB_REQUIRE(itop >= 0 && itop < nlayers, "pb_transmission: itop out of range");
+    if (nwave == 0)
+        return PB_OK;
+    PB_REQUIRE(spectrum_d && depth_d && ideep_d && radius_d, "pb_transmission: null pointer");
+    k_transmission<<<pb::div_up(nwave, kBlock), kBlock, 0, pb::as_stream(stream)>>>(
+        spectrum_d, depth_d, ideep_d, radius_d, itop, rstar, nlayers, nwave);
+    PB_LAUNCH_CHECK();
+    return PB_OK;
+}
+
+int pb_blackbody_wn_2D(double *B_d, const double *wn_d, int nwave, const double *temp_d,
+                       int nlayers, const int32_t *last_d, void *stream)
+{
+    PB_REQUIRE(nwave >= 0 && nlayers >= 0, "pb_blackbody_wn_2D: bad shape");
+    if (nwave == 0 || nlayers == 0)
+        return PB_OK;
+    PB_REQUIRE(B_d && wn_d && temp_d, "pb_blackbody_wn_2D: null pointer");
+    PB_REQUIRE(nlayers <= 65535, "pb_blackbody_wn_2D: too many layers");
+    dim3 grid(pb::div_up(nwave, kBlock), nlayers);
+    k_blackbody2d<<<grid, kBlock, 0, pb::as_stream(stream)>>>(B_d, wn_d, nwave, temp_d,
+                                                            nlayers, last_d);
+    PB_LAUNCH_CHECK();
+    return PB_OK;
+}
+
+int pb_blackbody_wn(double *B_d, const double *wn_d, int nwave, double temp, void *stream)
+{
+    PB_REQUIRE(nwave >= 0, "pb_blackbody_wn: bad shape");
+    if (nwave == 0)
+        return PB_OK;
+    PB_REQUIRE(B_d && wn_d, "pb_blackbody_wn: null pointer");
+    k_blackbody1d<<<pb::div_up(nwave, kBlock), kBlock, 0, pb::as_stream(stream)>>>(
+        B_d, wn_d, nwave, temp);
+    PB_LAUNCH_CHECK();
+    return PB_OK;
+}
+
+int pb_intensity(double *out_d, const double *tau_d, const int32_t *ideep_d,
+                 const double *bbody_d, const double *mu_d, int nmu, int rtop,
+                 int nlayers, int nwave, void *stream)
+{
+    PB_REQUIRE(nlayers > 0 && nwave >= 0 && nmu >= 0, "pb_intensity: bad shape");
+    PB_REQUIRE(rtop >= 0 && rtop < nlayers, "pb_intensity: rtop out of range");
+    if (nwave == 0 || nmu == 0)
+        return PB_OK;
+    PB_REQUIRE(out_d && tau_d && ideep_d && bbody_d && mu_d, "pb_intensity: null pointer");
+    dim3 grid(pb::div_up(nwave, kBlock), nmu);
+    k_intensity<<<grid, kBlock, 0, pb::as_stream(stream)>>>(out_d, tau_d, ideep_d, bbody_d,
+                                                          mu_d, nmu, rtop, nlayers, nwave);
+    PB_LAUNCH_CHECK();
+    return PB_OK;
+}
+
+int pb_emission_flux(double *flux_d, double *intensity_d, const double *tau_d,
+                     const int32_t *ideep_d, const double *wn_d, const double *temp_d,
+                     const double *mu_d, const double *weights_d, int nmu, int rtop,
+                     int nlayers, int nwave, void *stream)
+{
+    PB_REQUIRE(nlayers > 0 && nwave >= 0, "pb_emission_flux: bad shape");
+    PB_REQUIRE(nmu >= 1 && nmu <= kMaxMu, "pb_emission_flux: nmu must be in [1,%d]", kMaxMu);
+    PB_REQUIRE(rtop >= 0 && rtop < nlayers, "pb_emission_flux: rtop out of range");
+    if (nwave == 0)
+        return PB_OK;
+    PB_REQUIRE(flux_d && tau_d && ideep_d && wn_d && temp_d && mu_d && weights_d,
+               "pb_emission_flux: null pointer");
+    k_emission_flux<<<pb::div_up(nwave, kBlock), kBlock, 0, pb::as_stream(stream)>>>(
+        flux_d, intensity_d, tau_d, ideep_d, wn_d, temp_d, mu_d, weights_d, nmu, rtop,
+        nlayers, nwave);
+    PB_LAUNCH_CHECK();
+    return PB_OK;
+}
+
+int pb_simps2D(double *out_d, const double *y_d, int ny, int nwave, const double *h_d,
+               const int32_t *nint_d, const double *hsum_d, const double *hratio_d,
+               const double *hfactor_d, void *stream)
+{
+    PB_REQUIRE(ny >= 0 && nwave >= 0, "pb_simps2D: bad shape");
+    if (nwave == 0)
+        return PB_OK;
+    PB_REQUIRE(out_d && nint_d && (ny == 0 || y_d), "pb_simps2D: null pointer");
+    PB_REQUIRE(ny < 3 || (h_d && hsum_d && hratio_d && hfactor_d), "pb_simps2D: null h");
+    k_simps2d<<<pb::div_up(nwave, kBlock), kBlock, 0, pb::as_stream(stream)>>>(
+        out_d, y_d, ny, nwave, h_d, nint_d, hsum_d, hratio_d, hfactor_d);
+    PB_LAUNCH_CHECK();
+    return PB_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,1013 @@
+// Line-by-line extinction for all layers of an atmosphere in one launch sequence.
+//
+// Restates _extcoeff.extinction (src_c/_extcoeff.c:87-345) as a GATHER:
+//
+//   reference : per layer, per line group: scatter k*profile[...] over a "dynamic"
+//               fine grid (ktmp, up to W*osamp doubles), then keep every
+//               (osamp/ofactor)-th sample (resample, utils.h:119-135).
+//   here      : the kept samples are computed directly,
+//                 ext[jo] = sum_groups k * profile_c[half + osamp*jo - iown],
+//               restricted to the reference's window [minj,maxj) of that group
+//               (_extcoeff.c:281-299), so ktmp never exists.  The result is the same
+//               sum, term for term.
+//
+// Launch sequence per call (one stream, no host synchronisation):
+//   1. k_layer_state : per layer/isotope Lorentz+Doppler widths, width-grid indices,
+//                      dynamic-sampling factor (_extcoeff.c:138-200)
+//   2. k_kmax        : per layer/species maximum line strength (_extcoeff.c:203-226)
+//   3. k_ext_resample / k_ext_linterp : the gather.
+//
+// Gather kernel design (MI355X): a workgroup owns (layer, row, tile of 1024 output
+// samples); a wavefront owns 4 consecutive 64-sample chunks and keeps their sums in
+// registers, so every output is written exactly once, coalesced, without atomics and
+// in a fixed order (bitwise reproducible).  Candidate groups of the tile are found by
+// binary search in the (isotope, fine-index)-sorted group list; 256 of them at a time
+// are turned -- one per lane -- into {strength, window, table offset} records in LDS
+// (2 exp per group instead of per sample), then each wavefront walks the records that
+// intersect its range (wave-level ballot culling).  The Voigt table is read through
+// the phase-major layout of pb_voigt.hip: 64 lanes x 8 B contiguous per line chunk.
+// Workgroups are numbered so that the 8 XCDs take different layers (the part of the
+// table a layer touches -- one Lorentz row, a few Doppler columns -- then stays in
+// that XCD's 4 MiB L2), heaviest (deepest) layers first.
+#include <algorithm>
+#include <cmath>
+#include <new>
+#include <vector>
+
+#include "pb_common.h"
+#include "pb_internal.h"
+
+namespace {
+
+constexpr int kBlock = 256;
+constexpr int kChunks = 4;                       // 64-sample chunks per wavefront
+constexpr int kTile = kBlock * kChunks;          // output samples per workgroup
+
+struct LblArgs {
+    // Voigt table
+    const double *pm;
+    const double *flat;
+    const int64_t *pm_base;
+    const int32_t *pm_stride;
+    const int32_t *psize;
+    const int32_t *pindex;
+    const double *doppler;
+    const double *lorentz;
+    int ndop, nlor, osamp;
+    // lines and groups
+    const double *lwn, *elow, *gf;
+    const int32_t *lid;
+    const int32_t *gfirst, *gcount, *giown;
+    const int64_t *iso_gstart;
+    int64_t nlines;
+    // static species data
+    const double *molrad, *molmass;
+    const int32_t *isoimol, *isoiext;
+    const double *isomass, *isoratio;
+    const int32_t *divisors;
+    int nmol, niso, ndivs;
+    // per-call inputs
+    const double *temp, *dens, *isoz;
+    int64_t z_iso_stride, z_layer_stride;
+    // layer state (workspace)
+    int32_t *ls_ofactor, *ls_scale;
+    int64_t *ls_dnwn;
+    double *ls_dwnstep;
+    double *li_alphad, *li_dens, *li_z;
+    int32_t *li_ilor, *li_hmax;
+    unsigned long long *kmax_bits;
+    // grid
+    const double *wn;
+    double own0, own_last, ownstep, wnstep, wn0;
+    int64_t onwn;
+    double cutoff, ethresh;
+    int add, nrows, nlayers, nwave;
+    int64_t wbegin, wcount;
+    int ntiles;
+    double *ext;
+};
+
+// Line strength divided by the abundance (_extcoeff.c:219-224), same operation order.
+__device__ inline double line_strength(double ratio, double gf, double elow, double wavn,
+                                       double temp, double z)
+{
+    return pb::kSigCte * ratio * gf * exp(-pb::kExpCte * elow / temp) *
+           (1 - exp(-pb::kExpCte * wavn / temp)) / z;
+}
+
+// ---------------------------------------------------------------------------
+// 1. per-layer state: one workgroup (64 lanes) per layer, lanes over isotopes
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_layer_state(LblArgs a)
+{
+    __shared__ unsigned long long s_minwidth;
+    const int layer = blockIdx.x;
+    const double temp = a.temp[layer];
+    const double fdop = sqrt(2 * pb::kKB * temp / pb::kAMU) * pb::kSqrtLn2 / pb::kLS;
+    const double flor = sqrt(2 * pb::kKB * temp / pb::kPi / pb::kAMU) / pb::kLS;
+    if (threadIdx.x == 0)
+        s_minwidth = __double_as_longlong(1e5);
+    for (int r = threadIdx.x; r < a.nrows; r += 64)
+        a.kmax_bits[(int64_t)layer * a.nrows + r] = 0ull;
+    __syncthreads();
+    const double *dens = a.dens + (int64_t)layer * a.nmol;
+    for (int i = threadIdx.x; i < a.niso; i += 64) {
+        const int imol = a.isoimol[i];
+        double acc = 0.0;
+        for (int j = 0; j < a.nmol; j++) {
+            double dia = a.molrad[imol] + a.molrad[j];
+            acc += dens[j] * dia * dia * sqrt(1 / a.isomass[i] + 1 / a.molmass[j]);
+        }
+        const double alphal = acc * flor;
+        const double alphad = fdop / sqrt(a.isomass[i]);
+        const double dw = alphad * a.own0;
+        const double vw = 0.5346 * alphal + sqrt(alphal * alphal * 0.2166 + dw * dw);
+        atomicMin(&s_minwidth, (unsigned long long)__double_as_longlong(vw));
+        const int ilor = pb::nearest_index(a.lorentz, alphal, 0, a.nlor - 1);
+        int hmax = 0;
+        for (int d = 0; d < a.ndop; d++)
+            hmax = max(hmax, a.psize[ilor * a.ndop + d]);
+        const int64_t k = (int64_t)layer * a.niso + i;
+        a.li_alphad[k] = alphad;
+        a.li_ilor[k] = ilor;
+        a.li_hmax[k] = hmax;
+        a.li_dens[k] = dens[imol];
+        a.li_z[k] = a.isoz[i * a.z_iso_stride + layer * a.z_layer_stride];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const double minwidth = __longlong_as_double((long long)s_minwidth);
+        int d;
+        for (d = 1; d < a.ndivs; d++)
+            if (a.divisors[d] * a.ownstep >= 0.5 * minwidth)
+                break;
+        const int ofactor = a.divisors[d - 1];
+        a.ls_ofactor[layer] = ofactor;
+        a.ls_dwnstep[layer] = a.ownstep * ofactor;
+        a.ls_dnwn[layer] = 1 + (a.onwn - 1) / ofactor;
+        a.ls_scale[layer] = (int)round(a.wnstep / a.ownstep / ofactor);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// 2. per layer / output row maximum line strength over all in-range lines
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_kmax(LblArgs a, int lines_per_block)
+{
+    extern __shared__ unsigned long long s_max[];
+    const int layer = blockIdx.y;
+    for (int r = threadIdx.x; r < a.nrows; r += kBlock)
+        s_max[r] = 0ull;
+    __syncthreads();
+    const double temp = a.temp[layer];
+    const int64_t begin = (int64_t)blockIdx.x * lines_per_block;
+    const int64_t end = min(begin + lines_per_block, a.nlines);
+    int cur_row = -1;
+    double cur_max = 0.0;
+    for (int64_t ln = begin + threadIdx.x; ln < end; ln += kBlock) {
+        const int i = a.lid[ln];
+        int row = a.isoiext[i];
+        if (row < 0)
+            continue;
+        if (a.add)
+            row = 0;
+        const double v = a.lwn[ln];
+        if (v < a.own0 || v > a.own_last)
+            continue;
+        const int64_t li = (int64_t)layer * a.niso + i;
+        const double k = line_strength(a.isoratio[i], a.gf[ln], a.elow[ln], v, temp,
+                                       a.li_z[li]);
+        if (row != cur_row) {
+            if (cur_row >= 0)
+                atomicMax(&s_max[cur_row], (unsigned long long)__double_as_longlong(cur_max));
+            cur_row = row;
+            cur_max = 0.0;
+        }
+        cur_max = fmax(cur_max, k);
+    }
+    if (cur_row >= 0)
+        atomicMax(&s_max[cur_row], (unsigned long long)__double_as_longlong(cur_max));
+    __syncthreads();
+    for (int r = threadIdx.x; r < a.nrows; r += kBlock)
+        if (s_max[r] != 0ull)
+            atomicMax(&a.kmax_bits[(int64_t)layer * a.nrows + r], s_max[r]);
+}
+
+// ---------------------------------------------------------------------------
+// helpers for the gather kernels
+// ---------------------------------------------------------------------------
+__device__ inline int64_t lower_bound_i32(const int32_t *a, int64_t lo, int64_t hi, int64_t v)
+{
+    // first index in [lo,hi) with a[idx] >= v
+    while (lo < hi) {
+        int64_t mid = (lo + hi) >> 1;
+        if (a[mid] < v)
+            lo = mid + 1;
+        else
+            hi = mid;
+    }
+    return lo;
+}
+
+__device__ inline double bcast(double v, int lane)
+{
+    int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+    int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+    return __hiloint2double(hi, lo);
+}
+__device__ inline int64_t bcast(int64_t v, int lane)
+{
+    unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(v & 0xffffffff), lane);
+    int hi = __builtin_amdgcn_readlane((int)(v >> 32), lane);
+    return ((int64_t)hi << 32) | lo;
+}
+
+// Window of one group on the dynamic grid, exactly as _extcoeff.c:274-299.
+struct Window {
+    long minj, maxj;
+    int half, cell;
+};
+
+__device__ inline Window group_window(const LblArgs &a, double wavn, int iown, int ilor,
+                                      double alphad, int ofactor, double dwnstep,
+                                      int64_t dnwn)
+{
+    Window w;
+    const int idwn = (int)((wavn - a.own0) / dwnstep);
+    const int idop = pb::nearest_index(a.doppler, alphad * wavn, 0, a.ndop - 1);
+    w.cell = ilor * a.ndop + idop;
+    w.half = a.psize[w.cell];
+    const int subw = iown - idwn * ofactor;
+    w.minj = idwn - (w.half - subw) / ofactor;
+    w.maxj = idwn + (w.half + subw) / ofactor;
+    if (w.minj < 0)
+        w.minj = 0;
+    if (w.maxj > dnwn)
+        w.maxj = dnwn;
+    if (a.cutoff > 0.0) {
+        const int mincut = (int)(idwn - a.cutoff / dwnstep);
+        const int maxcut = (int)(idwn + a.cutoff / dwnstep);
+        if (mincut > w.minj)
+            w.minj = mincut;
+        if (maxcut < w.maxj)
+            w.maxj = maxcut;
+    }
+    return w;
+}
+
+// Co-added strength of a group (left-to-right sum of its members, _extcoeff.c:248-262)
+__device__ inline double group_strength(const LblArgs &a, int first, int count, double ratio,
+                                        double temp, double z)
+{
+    double k = line_strength(ratio, a.gf[first], a.elow[first], a.lwn[first], temp, z);
+    for (int m = 1; m < count; m++)
+        k += line_strength(ratio, a.gf[first + m], a.elow[first + m], a.lwn[first + m],
+                           temp, z);
+    return k;
+}
+
+__device__ inline void decode_block(const LblArgs &a, int &tile, int &layer)
+{
+    // blocks b and b+8 share an XCD: give each XCD its own layers, deepest first
+    const int id = blockIdx.x;
+    const int xcd = id & 7;
+    const int k = id >> 3;
+    tile = k % a.ntiles;
+    const int rank = (k / a.ntiles) * 8 + xcd;
+    layer = a.nlayers - 1 - rank;      // < 0 for the padding blocks
+}
+
+// ---------------------------------------------------------------------------
+// 3a. gather, constant-step output grid (resample mode)
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_ext_resample(LblArgs a)
+{
+    __shared__ double s_k[kBlock];
+    __shared__ int64_t s_off[kBlock];
+    __shared__ int s_lo[kBlock], s_hi[kBlock];
+
+    int tile, layer;
+    decode_block(a, tile, layer);
+    if (layer < 0)
+        return;
+    const int row = blockIdx.y;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+
+    const int64_t t0 = a.wbegin + (int64_t)tile * kTile;           // global sample index
+    const int64_t tend = min(t0 + kTile, a.wbegin + a.wcount);
+    const int64_t wlo = t0 + (int64_t)wave * (64 * kChunks);
+    const int64_t whi = min(wlo + 64 * kChunks, tend);
+
+    const int ofactor = a.ls_ofactor[layer];
+    const int scale = a.ls_scale[layer];
+    const int64_t dnwn = a.ls_dnwn[layer];
+    const double dwnstep = a.ls_dwnstep[layer];
+    const double temp = a.temp[layer];
+    const double kthresh =
+        a.ethresh * __longlong_as_double((long long)a.kmax_bits[(int64_t)layer * a.nrows + row]);
+    const int osamp = a.osamp;
+
+    double acc[kChunks];
+#pragma unroll
+    for (int s = 0; s < kChunks; s++)
+        acc[s] = 0.0;
+
+    for (int iso = 0; iso < a.niso; iso++) {
+        const int iext = a.isoiext[iso];
+        if (iext < 0 || (a.add ? 0 : iext) != row)
+            continue;
+        const int64_t li = (int64_t)layer * a.niso + iso;
+        const int ilor = a.li_ilor[li];
+        const double alphad = a.li_alphad[li];
+        const double ratio = a.isoratio[iso];
+        const double z = a.li_z[li];
+        const double dens = a.li_dens[li];
+        int64_t reach = a.li_hmax[li];
+        if (a.cutoff > 0.0)
+            reach = min(reach, (int64_t)(a.cutoff / a.ownstep) + 2 * (int64_t)ofactor + 2);
+        reach += osamp + ofactor;
+        // groups whose window can touch [t0, tend)
+        const int64_t seg0 = a.iso_gstart[iso], seg1 = a.iso_gstart[iso + 1];
+        const int64_t g0 = lower_bound_i32(a.giown, seg0, seg1, t0 * osamp - reach);
+        const int64_t g1 = lower_bound_i32(a.giown, seg0, seg1, (tend - 1) * osamp + reach + 1);
+
+        for (int64_t gb = g0; gb < g1; gb += kBlock) {
+            __syncthreads();
+            // ---- one record per lane ----
+            {
+                const int64_t g = gb + threadIdx.x;
+                double k = 0.0;
+                int64_t off = 0;
+                int jlo = 0, jhi = 0;
+                if (g < g1) {
+                    const int first = a.gfirst[g];
+                    const int iown = a.giown[g];
+                    k = group_strength(a, first, a.gcount[g], ratio, temp, z);
+                    if (!(k < kthresh)) {
+                        if (a.add)
+                            k *= dens;
+                        const Window w = group_window(a, a.lwn[first], iown, ilor, alphad,
+                                                      ofactor, dwnstep, dnwn);
+                        // kept samples: minj <= scale*jo < maxj, inside the profile
+                        int64_t lo = (w.minj + scale - 1) / scale;
+                        int64_t hi = (w.maxj + scale - 1) / scale;
+                        lo = max(lo, pb::ceil_div((int64_t)iown - w.half, osamp));
+                        hi = min(hi, pb::floor_div((int64_t)iown + w.half, osamp) + 1);
+                        lo = max(lo, t0);
+                        hi = min(hi, tend);
+                        if (lo < hi) {
+                            jlo = (int)(lo - t0);
+                            jhi = (int)(hi - t0);
+                            const int64_t f0 = (int64_t)w.half - iown;
+                            const int64_t q = pb::floor_div(f0, osamp);
+                            const int64_t phi = f0 - q * osamp;
+                            // sample jo reads pm[off + (jo - t0)]
+                            off = a.pm_base[w.cell] + phi * a.pm_stride[w.cell] + q + t0;
+                        }
+                    }
+                }
+                s_k[threadIdx.x] = k;
+                s_off[threadIdx.x] = off;
+                s_lo[threadIdx.x] = jlo;
+                s_hi[threadIdx.x] = jhi;
+            }
+            __syncthreads();
+            // ---- every wavefront walks the records that reach its 256 samples ----
+            const int nrec = (int)min((int64_t)kBlock, g1 - gb);
+            const int rlo = (int)(wlo - t0), rhi = (int)(whi - t0);
+            for (int base = 0; base < nrec; base += 64) {
+                const int e = base + lane;
+                const bool hit = e < nrec && s_lo[e] < rhi && s_hi[e] > rlo;
+                unsigned long long mask = __ballot(hit);
+                const double my_k = s_k[e & (kBlock - 1)];
+                const int64_t my_off = s_off[e & (kBlock - 1)];
+                const int my_lo = s_lo[e & (kBlock - 1)];
+                const int my_hi = s_hi[e & (kBlock - 1)];
+                while (mask) {
+                    const int src = __builtin_amdgcn_readfirstlane(__builtin_ctzll(mask));
+                    mask &= mask - 1;
+                    const double k = bcast(my_k, src);
+                    const int64_t off = bcast(my_off, src);
+                    const int lo = __builtin_amdgcn_readlane(my_lo, src);
+                    const int hi = __builtin_amdgcn_readlane(my_hi, src);
+                    const double *tab = a.pm + off;
+#pragma unroll
+                    for (int s = 0; s < kChunks; s++) {
+                        const int c0 = rlo + s * 64;
+                        if (lo < c0 + 64 && hi > c0) {
+                            const int j = c0 + lane;
+                            if (j >= lo && j < hi)
+                                acc[s] = fma(k, tab[j], acc[s]);
+                        }
+                    }
+                }
+            }
+        }
+    }
+
+    double *dst = a.ext + ((int64_t)layer * a.nrows + row) * a.wcount + (wlo - a.wbegin);
+#pragma unroll
+    for (int s = 0; s < kChunks; s++) {
+        const int64_t jo = wlo + s * 64 + lane;
+        if (jo < whi)
+            dst[s * 64 + lane] = acc[s];
+    }
+}
+
+// ---------------------------------------------------------------------------
+// 3b. gather, arbitrary output grid (resolution / wlstep mode): every output needs the
+// two dynamic-grid samples that bracket it (linterp, utils.h:139-163).  Uses the
+// reference-layout table (the stride between consecutive outputs is not constant).
+// One output sample per lane, 256 per workgroup.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_ext_linterp(LblArgs a)
+{
+    __shared__ double s_k[kBlock];
+    __shared__ int64_t s_start[kBlock];                 // start of the profile in flat[]
+    __shared__ int s_inoff[kBlock];                     // half - iown
+    __shared__ int s_min[kBlock], s_max[kBlock], s_half2[kBlock];
+
+    int tile, layer;
+    decode_block(a, tile, layer);
+    if (layer < 0)
+        return;
+    const int row = blockIdx.y;
+
+    const int64_t t0 = a.wbegin + (int64_t)tile * kBlock;
+    const int64_t tend = min(t0 + kBlock, a.wbegin + a.wcount);
+    const int64_t jo = t0 + threadIdx.x;
+    const bool live = jo < tend;
+
+    const int ofactor = a.ls_ofactor[layer];
+    const int64_t dnwn = a.ls_dnwn[layer];
+    const double dwnstep = a.ls_dwnstep[layer];
+    const double temp = a.temp[layer];
+    const double kthresh =
+        a.ethresh * __longlong_as_double((long long)a.kmax_bits[(int64_t)layer * a.nrows + row]);
+
+    // bracketing dynamic-grid sample of this output and of the tile's ends
+    const double wn_i = live ? a.wn[jo] : a.wn[tend - 1];
+    const int ilo = (int)((wn_i - a.wn0) / dwnstep);
+    const int tile_jmin = (int)((a.wn[t0] - a.wn0) / dwnstep);
+    const int tile_jmax = (int)((a.wn[tend - 1] - a.wn0) / dwnstep) + 1;
+
+    double acc0 = 0.0, acc1 = 0.0;
+    for (int iso = 0; iso < a.niso; iso++) {
+        const int iext = a.isoiext[iso];
+        if (iext < 0 || (a.add ? 0 : iext) != row)
+            continue;
+        const int64_t li = (int64_t)layer * a.niso + iso;
+        const int ilor = a.li_ilor[li];
+        const double alphad = a.li_alphad[li];
+        const double ratio = a.isoratio[iso];
+        const double z = a.li_z[li];
+        const double dens = a.li_dens[li];
+        int64_t reach = a.li_hmax[li];
+        if (a.cutoff > 0.0)
+            reach = min(reach, (int64_t)(a.cutoff / a.ownstep) + 2 * (int64_t)ofactor + 2);
+        reach += 2 * (int64_t)ofactor;
+        const int64_t seg0 = a.iso_gstart[iso], seg1 = a.iso_gstart[iso + 1];
+        const int64_t g0 =
+            lower_bound_i32(a.giown, seg0, seg1, (int64_t)tile_jmin * ofactor - reach);
+        const int64_t g1 =
+            lower_bound_i32(a.giown, seg0, seg1, (int64_t)tile_jmax * ofactor + reach + 1);
+        for (int64_t gb = g0; gb < g1; gb += kBlock) {
+            __syncthreads();
+            {
+                const int64_t g = gb + threadIdx.x;
+                double k = 0.0;
+                int64_t start = 0;
+                int mn = 0, mx = 0, half2 = 0, inoff = 0;
+                if (g < g1) {
+                    const int first = a.gfirst[g];
+                    const int iown = a.giown[g];
+                    k = group_strength(a, first, a.gcount[g], ratio, temp, z);
+                    if (!(k < kthresh)) {
+                        if (a.add)
+                            k *= dens;
+                        const Window w = group_window(a, a.lwn[first], iown, ilor, alphad,
+                                                      ofactor, dwnstep, dnwn);
+                        // dynamic sample j reads flat[pindex + half + ofactor*j - iown]
+                        mn = (int)w.minj;
+                        mx = (int)w.maxj;
+                        half2 = 2 * w.half;
+                        inoff = w.half - iown;
+                        start = a.pindex[w.cell];
+                    }
+                }
+                s_k[threadIdx.x] = k;
+                s_start[threadIdx.x] = start;
+                s_inoff[threadIdx.x] = inoff;
+                s_min[threadIdx.x] = mn;
+                s_max[threadIdx.x] = mx;
+                s_half2[threadIdx.x] = half2;
+            }
+            __syncthreads();
+            const int nrec = (int)min((int64_t)kBlock, g1 - gb);
+            for (int e = 0; e < nrec; e++) {
+                const int mn = s_min[e], mx = s_max[e];
+                if (mn >= mx || mx <= tile_jmin || mn > tile_jmax)
+                    continue;
+                if (!live)
+                    continue;
+                const double k = s_k[e];
+                const double *tab = a.flat + s_start[e];
+                const int64_t inoff = s_inoff[e];
+                const int half2 = s_half2[e];
+                if (ilo >= mn && ilo < mx) {
+                    const int64_t f = inoff + (int64_t)ofactor * ilo;
+                    if (f >= 0 && f <= half2)
+                        acc0 = fma(k, tab[f], acc0);
+                }
+                if (ilo + 1 >= mn && ilo + 1 < mx) {
+                    const int64_t f = inoff + (int64_t)ofactor * (ilo + 1);
+                    if (f >= 0 && f <= half2)
+                        acc1 = fma(k, tab[f], acc1);
+                }
+            }
+        }
+    }
+    if (live) {
+        const double wnlo = a.wn0 + dwnstep * ilo;
+        a.ext[((int64_t)layer * a.nrows + row) * a.wcount + (jo - a.wbegin)] +=
+            (acc0 * (wnlo + dwnstep - wn_i) + acc1 * (wn_i - wnlo)) / dwnstep;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// _extcoeff.interp_ec / interp_ec_per_mol (src_c/_extcoeff.c:367-472)
+// grid (wavenumber blocks, layers, per_mol ? nmol : 1)
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_interp_ec(
+    double *ext, const double *etable, const double *ttable, const double *temps,
+    const double *density, int nmol, int ntemp, int nlayers, int nwave, int lay1,
+    int per_mol)
+{
+    const int k = lay1 + blockIdx.y;
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= nwave)
+        return;
+    const double t = temps[k];
+    int tlo = pb::nearest_index(ttable, t, 0, ntemp - 1);
+    if (t < ttable[tlo] || tlo == ntemp - 1)
+        tlo--;
+    const int thi = tlo + 1;
+    const double span = ttable[thi] - ttable[tlo];
+    const double w_lo = (ttable[thi] - t) / span;
+    const double w_hi = (t - ttable[tlo]) / span;
+    if (per_mol) {
+        const int j = blockIdx.z;
+        const double d = density[(int64_t)k * nmol + j];
+        const double lo = etable[(((int64_t)j * ntemp + tlo) * nlayers + k) * nwave + i];
+        const double hi = etable[(((int64_t)j * ntemp + thi) * nlayers + k) * nwave + i];
+        ext[((int64_t)j * nlayers + k) * nwave + i] += lo * (w_lo * d) + hi * (w_hi * d);
+    } else {
+        double acc = ext[(int64_t)k * nwave + i];
+        for (int j = 0; j < nmol; j++) {
+            const double d = density[(int64_t)k * nmol + j];
+            const double lo = etable[(((int64_t)j * ntemp + tlo) * nlayers + k) * nwave + i];
+            const double hi = etable[(((int64_t)j * ntemp + thi) * nlayers + k) * nwave + i];
+            acc += lo * (w_lo * d) + hi * (w_hi * d);
+        }
+        ext[(int64_t)k * nwave + i] = acc;
+    }
+}
+
+template <typename T>
+int upload(T **dst, const T *src, size_t n)
+{
+    PB_HIP(hipMalloc(dst, std::max<size_t>(n, 1) * sizeof(T)));
+    if (n)
+        PB_HIP(hipMemcpy(*dst, src, n * sizeof(T), hipMemcpyHostToDevice));
+    return PB_OK;
+}
+
+}  // namespace
+
+// ===========================================================================
+// handles
+// ===========================================================================
+struct pb_lbl {
+    pb_voigt *voigt = nullptr;
+    pb_lines *lines = nullptr;
+    int nwave = 0, nmol = 0, niso = 0, ndivs = 0, max_layers = 0, resolution = 0;
+    int nrows_sep = 1;       // rows when add == 0
+    double cutoff = 0, ethresh = 0, wnstep = 0, wn0 = 0;
+    std::vector<int32_t> isoiext;
+    double *d_wn = nullptr, *d_molrad = nullptr, *d_molmass = nullptr, *d_isomass = nullptr,
+           *d_isoratio = nullptr;
+    int32_t *d_divisors = nullptr, *d_isoimol = nullptr, *d_isoiext = nullptr;
+    // workspace
+    int32_t *ls_ofactor = nullptr, *ls_scale = nullptr, *li_ilor = nullptr, *li_hmax = nullptr;
+    int64_t *ls_dnwn = nullptr;
+    double *ls_dwnstep = nullptr, *li_alphad = nullptr, *li_dens = nullptr, *li_z = nullptr;
+    unsigned long long *kmax_bits = nullptr;
+    int kmax_rows = 0;
+};
+
+extern "C" {
+
+// ---------------------------------------------------------------------------
+// line list
+// ---------------------------------------------------------------------------
+int pb_lines_create(pb_lines **out, const double *lwn_h, const double *elow_h,
+                    const double *gf_h, const int32_t *lid_h, int64_t nlines, int niso,
+                    const double *own_h, int64_t onwn, double own0, double ownstep)
+{
+    PB_REQUIRE(out, "pb_lines_create: null out");
+    *out = nullptr;
+    PB_REQUIRE(nlines >= 0 && niso > 0 && onwn >= 2, "pb_lines_create: bad sizes");
+    PB_REQUIRE(nlines == 0 || (lwn_h && elow_h && gf_h && lid_h),
+               "pb_lines_create: null line arrays");
+    PB_REQUIRE(nlines < 2147483647LL && onwn < 2147483647LL,
+               "pb_lines_create: sizes exceed the reference's 32-bit indices");
+    // own[] generated exactly like NumPy (wnlow + arange*ownstep: multiply, then add)
+    auto own_at = [&](int64_t i) -> double {
+        if (own_h)
+            return own_h[i];
+        volatile double prod = (double)i * ownstep;
+        return own0 + prod;
+    };
+    pb_lines *l = new (std::nothrow) pb_lines();
+    if (!l)
+        return PB_ERR_NOMEM;
+    l->nlines = nlines;
+    l->niso = niso;
+    l->onwn = onwn;
+    l->own0 = own_at(0);
+    l->own_last = own_at(onwn - 1);
+    l->ownstep = own_at(1) - own_at(0);
+    const double lo = l->own0, hi = l->own_last, step = l->ownstep;
+
+    struct Group {
+        int32_t first, count, iown, iso;
+    };
+    std::vector<Group> groups;
+    groups.reserve((size_t)nlines);
+    for (int64_t ln = 0; ln < nlines; ln++) {
+        const int i = lid_h[ln];
+        if (i < 0 || i >= niso) {
+            pb::set_error("pb_lines_create: line %lld has isotope id %d outside [0,%d)",
+                          (long long)ln, i, niso);
+            delete l;
+            return PB_ERR_ARG;
+        }
+        const double v = lwn_h[ln];
+        if (v < lo || v > hi)
+            continue;
+        l->ninrange++;
+        // nearest fine-grid index (_extcoeff.c:243-245)
+        int64_t iown = (int64_t)((v - lo) / step);
+        if (iown + 1 < onwn && fabs(v - own_at(iown + 1)) < fabs(v - own_at(iown)))
+            iown++;
+        Group g{(int32_t)ln, 1, (int32_t)iown, i};
+        const double centre = own_at(iown);
+        // greedy co-adding of the following lines of the same isotope (:248-262)
+        while (ln + 1 != nlines && lid_h[ln + 1] == i && lwn_h[ln + 1] <= hi) {
+            if (fabs(lwn_h[ln + 1] - centre) < step) {
+                ln++;
+                g.count++;
+                l->nadd++;
+                l->ninrange++;
+            } else
+                break;
+        }
+        groups.push_back(g);
+    }
+    // (isotope, fine index) order; stable, so a sorted TLI keeps its file order
+    std::stable_sort(groups.begin(), groups.end(), [](const Group &x, const Group &y) {
+        return x.iso != y.iso ? x.iso < y.iso : x.iown < y.iown;
+    });
+    l->ngroups = (int64_t)groups.size();
+    l->iso_gstart.assign((size_t)niso + 1, 0);
+    for (const Group &g : groups)
+        l->iso_gstart[(size_t)g.iso + 1]++;
+    for (int i = 0; i < niso; i++)
+        l->iso_gstart[(size_t)i + 1] += l->iso_gstart[(size_t)i];
+    std::vector<int32_t> gfirst(groups.size()), gcount(groups.size()), giown(groups.size());
+    for (size_t k = 0; k < groups.size(); k++) {
+        gfirst[k] = groups[k].first;
+        gcount[k] = groups[k].count;
+        giown[k] = groups[k].iown;
+    }
+    int rc = PB_OK;
+    if (rc == PB_OK) rc = upload(&l->d_lwn, lwn_h, (size_t)nlines);
+    if (rc == PB_OK) rc = upload(&l->d_elow, elow_h, (size_t)nlines);
+    if (rc == PB_OK) rc = upload(&l->d_gf, gf_h, (size_t)nlines);
+    if (rc == PB_OK) rc = upload(&l->d_lid, lid_h, (size_t)nlines);
+    if (rc == PB_OK) rc = upload(&l->d_gfirst, gfirst.data(), gfirst.size());
+    if (rc == PB_OK) rc = upload(&l->d_gcount, gcount.data(), gcount.size());
+    if (rc == PB_OK) rc = upload(&l->d_giown, giown.data(), giown.size());
+    if (rc == PB_OK) rc = upload(&l->d_iso_gstart, l->iso_gstart.data(), l->iso_gstart.size());
+    if (rc != PB_OK) {
+        pb_lines_destroy(l);
+        return rc;
+    }
+    *out = l;
+    return PB_OK;
+}
+
+int pb_lines_stats(const pb_lines *l, int64_t stats[3])
+{
+    PB_REQUIRE(l && stats, "pb_lines_stats: null pointer");
+    stats[0] = l->ninrange;
+    stats[1] = l->ngroups;
+    stats[2] = l->nadd;
+    return PB_OK;
+}
+
+void pb_lines_destroy(pb_lines *l)
+{
+    if (!l)
+        return;
+    (void)hipFree(l->d_lwn);
+    (void)hipFree(l->d_elow);
+    (void)hipFree(l->d_gf);
+    (void)hipFree(l->d_lid);
+    (void)hipFree(l->d_gfirst);
+    (void)hipFree(l->d_gcount);
+    (void)hipFree(l->d_giown);
+    (void)hipFree(l->d_iso_gstart);
+    delete l;
+}
+
+// ---------------------------------------------------------------------------
+// LBL plan
+// ---------------------------------------------------------------------------
+int pb_lbl_create(pb_lbl **out, pb_voigt *voigt, pb_lines *lines, const double *wn_h,
+                  int nwave, const int32_t *divisors_h, int ndivs, const double *molrad_h,
+                  const double *molmass_h, int nmol, const int32_t *isoimol_h,
+                  const double *isomass_h, const double *isoratio_h,
+                  const int32_t *isoiext_h, int niso, double cutoff, double ethresh,
+                  int resolution, int max_layers)
+{
+    PB_REQUIRE(out, "pb_lbl_create: null out");
+    *out = nullptr;
+    PB_REQUIRE(voigt && lines && wn_h && divisors_h && molrad_h && molmass_h && isoimol_h &&
+                   isomass_h && isoratio_h && isoiext_h,
+               "pb_lbl_create: null pointer");
+    PB_REQUIRE(nwave >= 2 && ndivs >= 1 && nmol >= 1 && niso >= 1 && max_layers >= 1,
+               "pb_lbl_create: bad sizes");
+    PB_REQUIRE(lines->niso == niso, "pb_lbl_create: line list has %d isotopes, got %d",
+               lines->niso, niso);
+    for (int i = 0; i < niso; i++)
+        PB_REQUIRE(isoimol_h[i] >= 0 && isoimol_h[i] < nmol,
+                   "pb_lbl_create: isoimol[%d] out of range", i);
+    PB_REQUIRE(divisors_h[0] >= 1, "pb_lbl_create: divisors must start at >= 1");
+    const double wnstep = wn_h[1] - wn_h[0];
+    if (!resolution) {
+        // the kept samples of every admissible dynamic grid must be osamp apart
+        for (int d = 0; d < ndivs; d++) {
+            const int scale = (int)round(wnstep / lines->ownstep / divisors_h[d]);
+            if ((int64_t)scale * divisors_h[d] != voigt->osamp) {
+                pb::set_error("pb_lbl_create: wn step %.9g is not osamp=%d fine steps of "
+                              "%.9g for divisor %d",
+                              wnstep, voigt->osamp, lines->ownstep, divisors_h[d]);
+                return PB_ERR_UNSUPPORTED;
+            }
+        }
+    }
+    pb_lbl *p = new (std::nothrow) pb_lbl();
+    if (!p)
+        return PB_ERR_NOMEM;
+    p->voigt = voigt;
+    p->lines = lines;
+    p->nwave = nwave;
+    p->nmol = nmol;
+    p->niso = niso;
+    p->ndivs = ndivs;
+    p->max_layers = max_layers;
+    p->resolution = resolution ? 1 : 0;
+    p->cutoff = cutoff;
+    p->ethresh = ethresh;
+    p->wnstep = wnstep;
+    p->wn0 = wn_h[0];
+    p->isoiext.assign(isoiext_h, isoiext_h + niso);
+    int rows = 1;
+    for (int i = 0; i < niso; i++)
+        rows = std::max(rows, isoiext_h[i] + 1);
+    p->nrows_sep = rows;
+    p->kmax_rows = rows;
+    const size_t L = (size_t)max_layers, LI = L * (size_t)niso;
+    int rc = PB_OK;
+    if (rc == PB_OK) rc = upload(&p->d_wn, wn_h, (size_t)nwave);
+    if (rc == PB_OK) rc = upload(&p->d_divisors, divisors_h, (size_t)ndivs);
+    if (rc == PB_OK) rc = upload(&p->d_molrad, molrad_h, (size_t)nmol);
+    if (rc == PB_OK) rc = upload(&p->d_molmass, molmass_h, (size_t)nmol);
+    if (rc == PB_OK) rc = upload(&p->d_isoimol, isoimol_h, (size_t)niso);
+    if (rc == PB_OK) rc = upload(&p->d_isomass, isomass_h, (size_t)niso);
+    if (rc == PB_OK) rc = upload(&p->d_isoratio, isoratio_h, (size_t)niso);
+    if (rc == PB_OK) rc = upload(&p->d_isoiext, isoiext_h, (size_t)niso);
+    auto alloc = [&](void **ptr, size_t bytes) {
+        if (rc == PB_OK && hipMalloc(ptr, bytes) != hipSuccess) {
+            pb::set_error("pb_lbl_create: workspace allocation failed");
+            rc = PB_ERR_NOMEM;
+        }
+    };
+    alloc((void **)&p->ls_ofactor, L * 4);
+    alloc((void **)&p->ls_scale, L * 4);
+    alloc((void **)&p->ls_dnwn, L * 8);
+    alloc((void **)&p->ls_dwnstep, L * 8);
+    alloc((void **)&p->li_alphad, LI * 8);
+    alloc((void **)&p->li_dens, LI * 8);
+    alloc((void **)&p->li_z, LI * 8);
+    alloc((void **)&p->li_ilor, LI * 4);
+    alloc((void **)&p->li_hmax, LI * 4);
+    alloc((void **)&p->kmax_bits, L * (size_t)rows * 8);
+    if (rc != PB_OK) {
+        pb_lbl_destroy(p);
+        return rc;
+    }
+    *out = p;
+    return PB_OK;
+}
+
+int pb_lbl_set_isoiext(pb_lbl *p, const int32_t *isoiext_h)
+{
+    PB_REQUIRE(p && isoiext_h, "pb_lbl_set_isoiext: null pointer");
+    for (int i = 0; i < p->niso; i++)
+        PB_REQUIRE(isoiext_h[i] < p->kmax_rows,
+                   "pb_lbl_set_isoiext: row %d exceeds the %d rows of the plan",
+                   isoiext_h[i], p->kmax_rows);
+    p->isoiext.assign(isoiext_h, isoiext_h + p->niso);
+    PB_HIP(hipMemcpy(p->d_isoiext, isoiext_h, (size_t)p->niso * 4, hipMemcpyHostToDevice));
+    return PB_OK;
+}
+
+int pb_lbl_set_ethresh(pb_lbl *p, double ethresh)
+{
+    PB_REQUIRE(p, "pb_lbl_set_ethresh: null handle");
+    p->ethresh = ethresh;
+    return PB_OK;
+}
+
+int pb_lbl_extinction(pb_lbl *p, double *ext_d, int64_t wbegin, int64_t wcount,
+                      const double *temp_d, const double *dens_d, const double *isoz_d,
+                      int64_t z_iso_stride, int64_t z_layer_stride, int nlayers, int add,
+                      void *stream)
+{
+    PB_REQUIRE(p && ext_d && temp_d && dens_d && isoz_d, "pb_lbl_extinction: null pointer");
+    PB_REQUIRE(nlayers >= 1 && nlayers <= p->max_layers,
+               "pb_lbl_extinction: nlayers=%d outside [1,%d]", nlayers, p->max_layers);
+    PB_REQUIRE(wbegin >= 0 && wcount >= 0 && wbegin + wcount <= p->nwave,
+               "pb_lbl_extinction: shard [%lld,+%lld) outside the %d-sample grid",
+               (long long)wbegin, (long long)wcount, p->nwave);
+    if (wcount == 0)
+        return PB_OK;
+    const pb_voigt *v = p->voigt;
+    const pb_lines *l = p->lines;
+    hipStream_t s = pb::as_stream(stream);
+    if (p->resolution) {
+        int rc = pb_voigt_ensure_flat(p->voigt, s);
+        if (rc)
+            return rc;
+    }
+    LblArgs a;
+    memset(&a, 0, sizeof(a));
+    a.pm = v->d_pm;
+    a.flat = v->d_flat;
+    a.pm_base = v->d_pm_base;
+    a.pm_stride = v->d_pm_stride;
+    a.psize = v->d_psize;
+    a.pindex = v->d_pindex;
+    a.doppler = v->d_doppler;
+    a.lorentz = v->d_lorentz;
+    a.ndop = v->ndop;
+    a.nlor = v->nlor;
+    a.osamp = v->osamp;
+    a.lwn = l->d_lwn;
+    a.elow = l->d_elow;
+    a.gf = l->d_gf;
+    a.lid = l->d_lid;
+    a.gfirst = l->d_gfirst;
+    a.gcount = l->d_gcount;
+    a.giown = l->d_giown;
+    a.iso_gstart = l->d_iso_gstart;
+    a.nlines = l->nlines;
+    a.molrad = p->d_molrad;
+    a.molmass = p->d_molmass;
+    a.isoimol = p->d_isoimol;
+    a.isoiext = p->d_isoiext;
+    a.isomass = p->d_isomass;
+    a.isoratio = p->d_isoratio;
+    a.divisors = p->d_divisors;
+    a.nmol = p->nmol;
+    a.niso = p->niso;
+    a.ndivs = p->ndivs;
+    a.temp = temp_d;
+    a.dens = dens_d;
+    a.isoz = isoz_d;
+    a.z_iso_stride = z_iso_stride;
+    a.z_layer_stride = z_layer_stride;
+    a.ls_ofactor = p->ls_ofactor;
+    a.ls_scale = p->ls_scale;
+    a.ls_dnwn = p->ls_dnwn;
+    a.ls_dwnstep = p->ls_dwnstep;
+    a.li_alphad = p->li_alphad;
+    a.li_dens = p->li_dens;
+    a.li_z = p->li_z;
+    a.li_ilor = p->li_ilor;
+    a.li_hmax = p->li_hmax;
+    a.kmax_bits = p->kmax_bits;
+    a.wn = p->d_wn;
+    a.own0 = l->own0;
+    a.own_last = l->own_last;
+    a.ownstep = l->ownstep;
+    a.wnstep = p->wnstep;
+    a.wn0 = p->wn0;
+    a.onwn = l->onwn;
+    a.cutoff = p->cutoff;
+    a.ethresh = p->ethresh;
+    a.add = add ? 1 : 0;
+    a.nrows = add ? 1 : p->nrows_sep;
+    a.nlayers = nlayers;
+    a.nwave = p->nwave;
+    a.wbegin = wbegin;
+    a.wcount = wcount;
+    a.ext = ext_d;
+
+    k_layer_state<<<nlayers, 64, 0, s>>>(a);
+    PB_LAUNCH_CHECK();
+    if (l->nlines > 0) {
+        const int lines_per_block = 4096;
+        dim3 grid(pb::div_up(l->nlines, lines_per_block), nlayers);
+        k_kmax<<<grid, kBlock, (size_t)a.nrows * 8, s>>>(a, lines_per_block);
+        PB_LAUNCH_CHECK();
+    }
+    const int layer_groups = (nlayers + 7) / 8;
+    if (p->resolution) {
+        a.ntiles = pb::div_up(wcount, kBlock);
+        dim3 grid((unsigned)(8 * a.ntiles * layer_groups), a.nrows);
+        k_ext_linterp<<<grid, kBlock, 0, s>>>(a);
+    } else {
+        a.ntiles = pb::div_up(wcount, kTile);
+        dim3 grid((unsigned)(8 * a.ntiles * layer_groups), a.nrows);
+        k_ext_resample<<<grid, kBlock, 0, s>>>(a);
+    }
+    PB_LAUNCH_CHECK();
+    return PB_OK;
+}
+
+int pb_lbl_last_state(pb_lbl *p, int32_t *ofactor_h, double *kmax_h, int nlayers, int nrows,
+                      void *stream)
+{
+    PB_REQUIRE(p, "pb_lbl_last_state: null handle");
+    PB_REQUIRE(nlayers >= 1 && nlayers <= p->max_layers && nrows >= 1 && nrows <= p->kmax_rows,
+               "pb_lbl_last_state: bad sizes");
+    PB_HIP(hipStreamSynchronize(pb::as_stream(stream)));
+    if (ofactor_h)
+        PB_HIP(hipMemcpy(ofactor_h, p->ls_ofactor, (size_t)nlayers * 4, hipMemcpyDeviceToHost));
+    if (kmax_h)
+        PB_HIP(hipMemcpy(kmax_h, p->kmax_bits, (size_t)nlayers * nrows * 8,
+                         hipMemcpyDeviceToHost));
+    return PB_OK;
+}
+
+void pb_lbl_destroy(pb_lbl *p)
+{
+    if (!p)
+        return;
+    (void)hipFree(p->d_wn);
+    (void)hipFree(p->d_molrad);
+    (void)hipFree(p->d_molmass);
+    (void)hipFree(p->d_isomass);
+    (void)hipFree(p->d_isoratio);
+    (void)hipFree(p->d_divisors);
+    (void)hipFree(p->d_isoimol);
+    (void)hipFree(p->d_isoiext);
+    (void)hipFree(p->ls_ofactor);
+    (void)hipFree(p->ls_scale);
+    (void)hipFree(p->ls_dnwn);
+    (void)hipFree(p->ls_dwnstep);
+    (void)hipFree(p->li_alphad);
+    (void)hipFree(p->li_dens);
+    (void)hipFree(p->li_z);
+    (void)hipFree(p->li_ilor);
+    (void)hipFree(p->li_hmax);
+    (void)hipFree(p->kmax_bits);
+    delete p;
+}
+
+int pb_interp_ec(double *extinction_d, const double *etable_d, const double *ttable_d,
+                 const double *temperatures_d, const double *density_d, int nmol, int ntemp,
+                 int nlayers, int nwave, int lay1, int lay2, int per_mol, void *stream)
+{
+    PB_REQUIRE(nmol >= 1 && ntemp >= 2 && nlayers >= 1 && nwave >= 0,
+               "pb_interp_ec: bad shape (needs >= 2 table temperatures)");
+    PB_REQUIRE(lay1 >= 0, "pb_interp_ec: lay1 < 0");
+    if (lay2 > nlayers)
+        lay2 = nlayers;
+    if (lay2 <= lay1 || nwave == 0)
+        return PB_OK;
+    PB_REQUIRE(extinction_d && etable_d && ttable_d && temperatures_d && density_d,
+               "pb_interp_ec: null pointer");
+    dim3 grid(pb::div_up(nwave, kBlock), lay2 - lay1, per_mol ? nmol : 1);
+    k_interp_ec<<<grid, kBlock, 0, pb::as_stream(stream)>>>(
+        extinction_d, etable_d, ttable_d, temperatures_d, density_d, nmol, ntemp, nlayers,
+        nwave, lay1, per_mol ? 1 : 0);
+    PB_LAUNCH_CHECK();
+    return PB_OK;
+}
+
+}  // extern "C"

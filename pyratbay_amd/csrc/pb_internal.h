@@ -1,0 +1,44 @@
+// Handle layouts shared between the translation units of libpbhip.
+#pragma once
+
+#include <cstdint>
+#include <vector>
+
+#include <hip/hip_runtime.h>
+
+#include "pbhip.h"
+
+struct pb_voigt {
+    int nlor = 0, ndop = 0, osamp = 0, ncell = 0, max_half = 0;
+    double dwn = 0.0;
+    int64_t nflat = 0;   // samples in the reference layout (sum of 2*half+1)
+    int64_t npm = 0;     // samples in the phase-major layout (padded)
+    // host mirrors, [nlor*ndop]; aliased cells repeat the previous Doppler column
+    std::vector<double> lorentz, doppler;
+    std::vector<int32_t> psize, pindex, pm_stride;
+    std::vector<int64_t> pm_base;
+    // device
+    double *d_pm = nullptr;      // phase-major table
+    double *d_flat = nullptr;    // reference-layout table (optional)
+    void *d_cells = nullptr;     // per computed cell descriptors
+    int64_t *d_flat_bases = nullptr, *d_pm_bases = nullptr;  // [ncell]
+    int32_t *d_psize = nullptr, *d_pindex = nullptr, *d_pm_stride = nullptr;  // [nlor*ndop]
+    int64_t *d_pm_base = nullptr;
+    double *d_lorentz = nullptr, *d_doppler = nullptr;
+};
+
+int pb_voigt_ensure_flat(pb_voigt *v, hipStream_t stream);
+
+struct pb_lines {
+    int64_t nlines = 0, ngroups = 0, nadd = 0, ninrange = 0;
+    int niso = 0;
+    int64_t onwn = 0;
+    double own0 = 0.0, own_last = 0.0, ownstep = 0.0;   // from the own[] array
+    std::vector<int64_t> iso_gstart;                    // [niso+1] group segments
+    // device: line records
+    double *d_lwn = nullptr, *d_elow = nullptr, *d_gf = nullptr;
+    int32_t *d_lid = nullptr;
+    // device: co-add groups, sorted by (isotope, iown)
+    int32_t *d_gfirst = nullptr, *d_gcount = nullptr, *d_giown = nullptr;
+    int64_t *d_iso_gstart = nullptr;
+};

@@ -1,0 +1,391 @@
+"""Device-resident front-end of the hot path (host side above the C ABI).
+
+Mirrors the call structure of the reference's Python layer for this path
+
+    Voigt()                         pyratbay/pyrat/voigt.py:46-149
+    extinction() per-layer loop     pyratbay/pyrat/extinction.py:129-213
+    optical_depth()                 pyratbay/opacity/optic_depth.py:16-144
+    transmission()/plane_parallel_rt()  pyratbay/spectrum/radiative_transfer.py:23-138
+    spectrum()                      pyratbay/pyrat/spectrum.py:333-385
+
+but keeps every array ([layer][wavenumber], row-major) in HBM between the stages:
+ec, depth and B never travel to the host unless asked for.  torch tensors are used
+only as owners of device memory; all arithmetic happens in libpbhip.so.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _capi
+from ._capi import call, hptr, f64h, i32h
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    if t is None:
+        return None
+    assert t.is_cuda and t.is_contiguous()
+    return C.c_void_p(t.data_ptr())
+
+
+def dev(a, dtype=torch.float64, device=None):
+    """Host array -> contiguous device tensor of the ABI's element type."""
+    if isinstance(a, torch.Tensor):
+        return a.to(device=device or 'cuda', dtype=dtype).contiguous()
+    np_dtype = {torch.float64: np.float64, torch.int32: np.int32,
+                torch.int64: np.int64}[dtype]
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np_dtype)).to(device or 'cuda')
+
+
+def require_gpu():
+    if not torch.cuda.is_available():
+        raise _capi.PbError('no GPU visible: the HIP path has no CPU fallback')
+    _capi.lib()
+
+
+# --------------------------------------------------------------------------
+# Voigt table
+# --------------------------------------------------------------------------
+class VoigtTable:
+    """Grid of Voigt profiles resident on the device (vprofile.grid, voigt.py:133-149)."""
+
+    def __init__(self, handle, nlor, ndop, lorentz, doppler, osamp):
+        self._h = handle
+        self.nlor, self.ndop, self.osamp = nlor, ndop, osamp
+        self.lorentz, self.doppler = lorentz, doppler
+        size = np.zeros((nlor, ndop), np.int32)
+        index = np.zeros((nlor, ndop), np.int32)
+        n = C.c_int64(0)
+        call('pb_voigt_meta', self._h, hptr(size), hptr(index), C.byref(n))
+        self.size, self.index, self.nprofile = size, index, n.value
+
+    @classmethod
+    def build(cls, lorentz, doppler, size, ownstep, osamp, keep_flat=False):
+        require_gpu()
+        lorentz, doppler = f64h(lorentz), f64h(doppler)
+        size = i32h(size)
+        h = C.c_void_p()
+        call('pb_voigt_create', C.byref(h), hptr(lorentz), len(lorentz), hptr(doppler),
+             len(doppler), hptr(size), float(ownstep), int(osamp), int(keep_flat), _stream())
+        return cls(h, len(lorentz), len(doppler), lorentz, doppler, int(osamp))
+
+    @classmethod
+    def from_flat(cls, profile, size, index, lorentz, doppler, osamp, keep_flat=False):
+        require_gpu()
+        profile, lorentz, doppler = f64h(profile), f64h(lorentz), f64h(doppler)
+        size, index = i32h(size), i32h(index)
+        h = C.c_void_p()
+        call('pb_voigt_from_flat', C.byref(h), hptr(profile), profile.size, hptr(lorentz),
+             len(lorentz), hptr(doppler), len(doppler), hptr(size), hptr(index), int(osamp),
+             int(keep_flat), _stream())
+        return cls(h, len(lorentz), len(doppler), lorentz, doppler, int(osamp))
+
+    def flat(self, out=None):
+        """The table in the reference's layout (what vprofile.grid fills), on the host."""
+        if out is None:
+            out = np.zeros(self.nprofile)
+        assert out.dtype == np.float64 and out.flags.c_contiguous
+        call('pb_voigt_flat_to_host', self._h, hptr(out), out.size)
+        return out
+
+    @property
+    def device_bytes(self):
+        return call('pb_voigt_device_bytes', self._h)
+
+    def close(self):
+        if self._h:
+            call('pb_voigt_destroy', self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+# --------------------------------------------------------------------------
+# Line list
+# --------------------------------------------------------------------------
+class LineList:
+    """Line transitions + the co-add groups of _extcoeff.c:243-262, on the device."""
+
+    def __init__(self, lwn, elow, gf, lid, niso, own):
+        require_gpu()
+        lwn, elow, gf, lid, own = f64h(lwn), f64h(elow), f64h(gf), i32h(lid), f64h(own)
+        self.nlines, self.niso = len(lwn), int(niso)
+        self._h = C.c_void_p()
+        call('pb_lines_create', C.byref(self._h), hptr(lwn), hptr(elow), hptr(gf), hptr(lid),
+             len(lwn), int(niso), hptr(own), len(own), float(own[0]), float(own[1] - own[0]))
+        st = (C.c_int64 * 3)()
+        call('pb_lines_stats', self._h, C.byref(st))
+        self.ninrange, self.ngroups, self.nadd = st[0], st[1], st[2]
+
+    def close(self):
+        if self._h:
+            call('pb_lines_destroy', self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+# --------------------------------------------------------------------------
+# LBL extinction
+# --------------------------------------------------------------------------
+class LBL:
+    """All-layer line-by-line extinction (the loop of extinction.py:170-213)."""
+
+    def __init__(self, voigt, lines, wn, divisors, molrad, molmass, isoimol, isomass,
+                 isoratio, isoiext, cutoff, ethresh, resolution=False, max_layers=256):
+        self.voigt, self.lines = voigt, lines       # keep the handles alive
+        wn = f64h(wn)
+        self.nwave = len(wn)
+        self.nmol, self.niso = len(molmass), len(isomass)
+        isoiext = i32h(isoiext)
+        self.nrows_sep = max(1, int(isoiext.max()) + 1)
+        self.max_layers = max_layers
+        self._h = C.c_void_p()
+        args = [f64h(molrad), f64h(molmass), i32h(isoimol), f64h(isomass), f64h(isoratio)]
+        div = i32h(divisors)
+        call('pb_lbl_create', C.byref(self._h), voigt._h, lines._h, hptr(wn), len(wn),
+             hptr(div), len(div), hptr(args[0]), hptr(args[1]), self.nmol,
+             hptr(args[2]), hptr(args[3]), hptr(args[4]), hptr(isoiext), self.niso,
+             float(cutoff), float(ethresh), int(bool(resolution)), int(max_layers))
+        self.resolution = bool(resolution)
+
+    def set_isoiext(self, isoiext):
+        isoiext = i32h(isoiext)
+        call('pb_lbl_set_isoiext', self._h, hptr(isoiext))
+
+    def set_ethresh(self, ethresh):
+        call('pb_lbl_set_ethresh', self._h, float(ethresh))
+
+    def extinction(self, temp, dens, isoz, add=True, out=None, wbegin=0, wcount=None):
+        """temp[L], dens[L,nmol], isoz[niso,L] device tensors -> ec[L,rows,wcount]."""
+        nlayers = temp.shape[0]
+        if wcount is None:
+            wcount = self.nwave - wbegin
+        rows = 1 if add else self.nrows_sep
+        if out is None:
+            alloc = torch.zeros if self.resolution else torch.empty
+            out = alloc((nlayers, rows, wcount), dtype=torch.float64, device=temp.device)
+        assert out.shape == (nlayers, rows, wcount) and out.is_contiguous()
+        assert dens.shape == (nlayers, self.nmol) and isoz.shape == (self.niso, nlayers)
+        call('pb_lbl_extinction', self._h, _ptr(out), int(wbegin), int(wcount), _ptr(temp),
+             _ptr(dens), _ptr(isoz), isoz.stride(0), isoz.stride(1), nlayers, int(bool(add)),
+             _stream())
+        return out
+
+    def last_state(self, nlayers, rows):
+        ofactor = np.zeros(nlayers, np.int32)
+        kmax = np.zeros((nlayers, rows))
+        call('pb_lbl_last_state', self._h, hptr(ofactor), hptr(kmax), nlayers, rows,
+             _stream())
+        return ofactor, kmax
+
+    def close(self):
+        if self._h:
+            call('pb_lbl_destroy', self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+# --------------------------------------------------------------------------
+# Host pre-computes of the callers
+# --------------------------------------------------------------------------
+def transit_path(radius, nskip=0):
+    """Chord segments between concentric shells for each impact parameter
+    (pyratbay/atmosphere/atmosphere.py:737-802)."""
+    rad = np.asarray(radius, float)[nskip:]
+    path = [np.empty(0) for _ in range(nskip)]
+    for r in range(len(rad)):
+        i = np.arange(r)
+        path.append(np.sqrt(rad[i]**2 - rad[r]**2) - np.sqrt(rad[i + 1]**2 - rad[r]**2))
+    return path
+
+
+def pack_raypath(raypath, itop):
+    """Lower triangle of transit_path(radius, itop) as one array (pbhip.h layout)."""
+    rows = [np.asarray(p, float) for p in raypath[itop:]]
+    for r, p in enumerate(rows):
+        assert len(p) == r, 'raypath must come from transit_path(radius, itop)'
+    return np.concatenate(rows) if rows else np.empty(0)
+
+
+# --------------------------------------------------------------------------
+# Column stages (device tensors in, device tensors out)
+# --------------------------------------------------------------------------
+def optical_depth_transit(ec, raypath_packed, itop, ibottom, maxdepth):
+    """optic_depth.py:103-112.  ec[L,W] -> depth[L,W], ideep[W] (int32)."""
+    nlayers, nwave = ec.shape
+    depth = torch.empty_like(ec)
+    ideep = torch.empty(nwave, dtype=torch.int32, device=ec.device)
+    call('pb_optical_depth_transit', _ptr(depth), _ptr(ideep), _ptr(ec),
+         _ptr(raypath_packed), int(itop), int(ibottom), float(maxdepth), nlayers, nwave,
+         _stream())
+    return depth, ideep
+
+
+def plane_parallel_optical_depth(ec, intervals, itop, ibottom, maxdepth, depth=None):
+    """optic_depth.py:122-130.  Rows below the stopping layer stay zero."""
+    nlayers, nwave = ec.shape
+    if depth is None:
+        depth = torch.zeros_like(ec)
+    ideep = torch.full((nwave,), nlayers - 1, dtype=torch.int32, device=ec.device)
+    call('pb_plane_parallel_optical_depth', _ptr(depth), _ptr(ideep), _ptr(ec),
+         _ptr(intervals), float(maxdepth), int(itop), int(ibottom), nlayers, nwave, _stream())
+    return depth, ideep
+
+
+def transmission(depth, ideep, radius, itop, rstar):
+    """radiative_transfer.py:57-71 (no cloud deck) -> spectrum[W]."""
+    nlayers, nwave = depth.shape
+    spectrum = torch.empty(nwave, dtype=torch.float64, device=depth.device)
+    call('pb_transmission', _ptr(spectrum), _ptr(depth), _ptr(ideep), _ptr(radius),
+         int(itop), float(rstar), nlayers, nwave, _stream())
+    return spectrum
+
+
+def emission_flux(depth, ideep, wn, temp, mu, weights, rtop, want_intensity=False):
+    """pyrat/spectrum.py:366-377: Planck + intensity per mu + quadrature sum."""
+    nlayers, nwave = depth.shape
+    flux = torch.empty(nwave, dtype=torch.float64, device=depth.device)
+    inten = (torch.empty((len(mu), nwave), dtype=torch.float64, device=depth.device)
+             if want_intensity else None)
+    call('pb_emission_flux', _ptr(flux), _ptr(inten), _ptr(depth), _ptr(ideep), _ptr(wn),
+         _ptr(temp), _ptr(mu), _ptr(weights), len(mu), int(rtop), nlayers, nwave, _stream())
+    return (flux, inten) if want_intensity else flux
+
+
+def blackbody_wn_2D(wn, temp, last=None):
+    B = torch.zeros((temp.shape[0], wn.shape[0]), dtype=torch.float64, device=wn.device)
+    call('pb_blackbody_wn_2D', _ptr(B), _ptr(wn), wn.shape[0], _ptr(temp), temp.shape[0],
+         _ptr(last), _stream())
+    return B
+
+
+def intensity(tau, ideep, planck, mu, rtop):
+    nlayers, nwave = tau.shape
+    out = torch.empty((mu.shape[0], nwave), dtype=torch.float64, device=tau.device)
+    call('pb_intensity', _ptr(out), _ptr(tau), _ptr(ideep), _ptr(planck), _ptr(mu),
+         mu.shape[0], int(rtop), nlayers, nwave, _stream())
+    return out
+
+
+def interp_ec(extinction, etable, ttable, temperatures, density, lay1, lay2, per_mol=False):
+    nmol, ntemp, nlayers, nwave = etable.shape
+    call('pb_interp_ec', _ptr(extinction), _ptr(etable), _ptr(ttable), _ptr(temperatures),
+         _ptr(density), nmol, ntemp, nlayers, nwave, int(lay1), int(lay2), int(per_mol),
+         _stream())
+    return extinction
+
+
+# --------------------------------------------------------------------------
+# Whole-path model: the three timed stages of Pyrat.run() (pyrat_obj.py:203-214)
+# --------------------------------------------------------------------------
+class LBLSpectrum:
+    """extinction -> optical depth -> spectrum for one wavenumber shard, all on device.
+
+    `case` is a dict as produced by pyratbay_amd.synth.lbl_case (or assembled by a caller
+    from a real Pyrat object: the same arrays the reference hands to its C extensions).
+    """
+
+    def __init__(self, case, rt_path='transit', wbegin=0, wcount=None, itop=0,
+                 quadrature_mu=None, quadrature_weights=None, keep_flat=False,
+                 voigt=None, lines=None):
+        require_gpu()
+        g, atm, ln, iso, vg = (case['grid'], case['atm'], case['lines'], case['iso'],
+                               case['voigt'])
+        self.case = case
+        self.rt_path = rt_path
+        self.nwave = g['nwave']
+        self.nlayers = atm['nlayers']
+        self.wbegin = wbegin
+        self.wcount = self.nwave - wbegin if wcount is None else wcount
+        self.itop = itop
+        self.maxdepth = case['maxdepth']
+        self.voigt = voigt or VoigtTable.build(vg['lorentz'], vg['doppler'], vg['size'],
+                                               g['ownstep'], g['wnosamp'], keep_flat)
+        self.lines = lines or LineList(ln['lwn'], ln['elow'], ln['gf'], ln['lid'],
+                                       len(iso['isomass']), g['own'])
+        self.lbl = LBL(self.voigt, self.lines, g['wn'], g['divisors'], atm['mol_radius'],
+                       atm['mol_mass'], iso['isoimol'], iso['isomass'], iso['isoratio'],
+                       iso['isoiext'], vg['cutoff'], case['ethresh'],
+                       max_layers=self.nlayers)
+        # atmosphere state, resident
+        self.temp = dev(atm['temp'])
+        self.dens = dev(atm['dens'])
+        self.isoz = dev(iso['isoz'])
+        self.radius = dev(atm['radius'])
+        self.rstar = float(atm['rstar'])
+        self.wn = dev(g['wn'][wbegin:wbegin + self.wcount])
+        if rt_path == 'transit':
+            self.raypath = dev(pack_raypath(transit_path(atm['radius'], itop), itop))
+        else:
+            self.intervals = dev(-np.diff(atm['radius']))
+            if quadrature_mu is None:
+                raygrid = np.radians([0.0, 20.0, 40.0, 60.0, 80.0])
+                quadrature_mu = np.cos(raygrid)
+                bounds = np.linspace(0, 0.5 * np.pi, len(raygrid) + 1)
+                bounds[1:-1] = 0.5 * (raygrid[:-1] + raygrid[1:])
+                quadrature_weights = np.pi * (np.sin(bounds[1:])**2 - np.sin(bounds[:-1])**2)
+            self.mu = dev(quadrature_mu)
+            self.weights = dev(quadrature_weights)
+        self.ec = torch.empty((self.nlayers, 1, self.wcount), dtype=torch.float64,
+                              device='cuda')
+        self.depth = self.ideep = self.spectrum = None
+
+    def set_atmosphere(self, temp, dens, isoz, radius=None):
+        self.temp.copy_(dev(temp))
+        self.dens.copy_(dev(dens))
+        self.isoz.copy_(dev(isoz))
+        if radius is not None:
+            self.radius.copy_(dev(radius))
+            if self.rt_path == 'transit':
+                self.raypath.copy_(dev(pack_raypath(transit_path(radius, self.itop),
+                                                    self.itop)))
+            else:
+                self.intervals.copy_(dev(-np.diff(radius)))
+
+    def extinction(self):
+        self.lbl.extinction(self.temp, self.dens, self.isoz, add=True, out=self.ec,
+                            wbegin=self.wbegin, wcount=self.wcount)
+        return self.ec
+
+    def optical_depth(self):
+        ec = self.ec.view(self.nlayers, self.wcount)
+        if self.rt_path == 'transit':
+            self.depth, self.ideep = optical_depth_transit(
+                ec, self.raypath, self.itop, self.nlayers, self.maxdepth)
+        else:
+            self.depth, self.ideep = plane_parallel_optical_depth(
+                ec, self.intervals, self.itop, self.nlayers, self.maxdepth)
+        return self.depth, self.ideep
+
+    def rt(self):
+        if self.rt_path == 'transit':
+            self.spectrum = transmission(self.depth, self.ideep, self.radius, self.itop,
+                                         self.rstar)
+        else:
+            self.spectrum = emission_flux(self.depth, self.ideep, self.wn, self.temp,
+                                          self.mu, self.weights, self.itop)
+        return self.spectrum
+
+    def run(self):
+        """One spectrum: the 'extinction', 'odepth' and 'spectrum' stages."""
+        self.extinction()
+        self.optical_depth()
+        return self.rt()

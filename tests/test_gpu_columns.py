@@ -1,0 +1,175 @@
+"""HIP column kernels (through the C ABI) against the golden vectors of the compiled
+reference and against the oracle on seeded inputs.  Needs an MI355X.
+
+Tolerance: rtol 1e-12 (binary64 throughout; device exp/pow differ from glibc by <= 1-2 ulp
+and the sums run in the same order)."""
+import numpy as np
+import pytest
+
+import cases
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-12
+
+
+@pytest.fixture(scope='module')
+def eng():
+    import torch
+    from pyratbay_amd import engine
+    engine.require_gpu()
+    return engine
+
+
+def host(t):
+    return t.cpu().numpy()
+
+
+@pytest.mark.parametrize('tag', ['a', 'b', 'c'])
+def test_transit_depth_and_transmission_golden(eng, golden, tag):
+    g4, g5 = golden('g4_depth'), golden('g5_rt')
+    itop, ibottom, maxdepth = g4[f'args_{tag}']
+    itop, ibottom = int(itop), int(ibottom)
+    ec = eng.dev(g4['ec'])
+    path = eng.dev(eng.pack_raypath(eng.transit_path(g4['radius'], itop), itop))
+    depth, ideep = eng.optical_depth_transit(ec, path, itop, ibottom, maxdepth)
+    assert np.array_equal(host(ideep), g4[f'transit_ideep_{tag}'])
+    np.testing.assert_allclose(host(depth), g4[f'transit_depth_{tag}'], rtol=RTOL)
+    spec = eng.transmission(depth, ideep, eng.dev(g4['radius']), itop, float(g5['rstar']))
+    np.testing.assert_allclose(host(spec), g5[f'transmission_{tag}'], rtol=RTOL)
+
+
+@pytest.mark.parametrize('tag', ['a', 'b', 'c'])
+def test_plane_parallel_and_emission_golden(eng, golden, tag):
+    import torch
+    g4, g5 = golden('g4_depth'), golden('g5_rt')
+    itop, ibottom, maxdepth = g4[f'args_{tag}']
+    itop, ibottom = int(itop), int(ibottom)
+    ec = eng.dev(g4['ec'])
+    h = eng.dev(-np.diff(g4['radius']))
+    depth, ideep = eng.plane_parallel_optical_depth(ec, h, itop, ibottom, maxdepth)
+    assert np.array_equal(host(ideep), g4[f'plane_ideep_{tag}'])
+    np.testing.assert_allclose(host(depth), g4[f'plane_depth_{tag}'], rtol=RTOL)
+    # unfused: Planck table + intensity
+    wn, temp, mu = eng.dev(g5['wn']), eng.dev(g5['temp']), eng.dev(g5['mu'])
+    B = eng.blackbody_wn_2D(wn, temp)
+    np.testing.assert_allclose(host(B), g5['B_full'], rtol=RTOL)
+    ideep_i = eng.dev(g5[f'intensity_ideep_{tag}'], torch.int32)
+    inten = eng.intensity(eng.dev(g4[f'plane_depth_{tag}']), ideep_i, B, mu, itop)
+    np.testing.assert_allclose(host(inten), g5[f'intensity_{tag}'], rtol=1e-11, atol=1e-300)
+    # fused: Planck in registers + quadrature
+    weights = np.array([0.3, 0.25, 0.2, 0.15, 0.1])
+    flux, inten2 = eng.emission_flux(eng.dev(g4[f'plane_depth_{tag}']), ideep_i, wn, temp, mu,
+                                     eng.dev(weights), itop, want_intensity=True)
+    np.testing.assert_allclose(host(inten2), g5[f'intensity_{tag}'], rtol=1e-11, atol=1e-300)
+    want = np.sum(g5[f'intensity_{tag}'] * weights[:, None], axis=0)
+    np.testing.assert_allclose(host(flux), want, rtol=1e-11)
+
+
+def test_blackbody_last_and_1d(eng, golden):
+    import ctypes as C
+    import torch
+    from pyratbay_amd._capi import call
+    g5 = golden('g5_rt')
+    wn, temp = eng.dev(g5['wn']), eng.dev(g5['temp'])
+    B = eng.blackbody_wn_2D(wn, temp, eng.dev(g5['last'], torch.int32))
+    np.testing.assert_allclose(host(B), g5['B_last'], rtol=RTOL)
+    b1 = torch.empty_like(wn)
+    call('pb_blackbody_wn', eng._ptr(b1), eng._ptr(wn), wn.shape[0], 1234.5, eng._stream())
+    np.testing.assert_allclose(host(b1), g5['B_1d'], rtol=RTOL)
+
+
+def test_single_optdepth_trapz_simps_ediff(eng, golden, orc):
+    """The one-call-per-reference-function entry points against the oracle."""
+    import torch
+    from pyratbay_amd._capi import call
+    c = cases.column_case(seed=9, nlayers=17, nwave=333)
+    L, W = c['nlayers'], c['nwave']
+    ec = eng.dev(c['ec'])
+    rng = np.random.default_rng(1)
+    # pb_optdepth on a row-slice view (data = ec[itop:r+1])
+    itop, r = 2, 11
+    path = orc.transit_path(c['radius'], itop)[r]
+    ideep_h = np.where(rng.uniform(size=W) < 0.3, 5, -1).astype(np.int32)
+    want_ideep = ideep_h.copy()
+    want = orc.optdepth(c['ec'][itop:r + 1], path, 3.0, want_ideep, r)
+    ideep = eng.dev(ideep_h, torch.int32)
+    tau = torch.empty(W, dtype=torch.float64, device='cuda')
+    call('pb_optdepth', eng._ptr(tau), ec[itop:].data_ptr(), W, eng._ptr(eng.dev(path)),
+         len(path), 3.0, eng._ptr(ideep), r, W, eng._stream())
+    np.testing.assert_allclose(host(tau), want, rtol=RTOL)
+    assert np.array_equal(host(ideep), want_ideep)
+    # trapezoid2D with ragged nint
+    nint_h = rng.integers(0, L, W).astype(np.int32)
+    hh = rng.uniform(0.5, 2.0, L - 1)
+    out = torch.empty(W, dtype=torch.float64, device='cuda')
+    call('pb_trapezoid2D', eng._ptr(out), eng._ptr(ec), eng._ptr(eng.dev(hh)),
+         eng._ptr(eng.dev(nint_h, torch.int32)), L, W, eng._stream())
+    np.testing.assert_allclose(host(out), orc.trapezoid2D(c['ec'], hh, nint_h), rtol=RTOL)
+    # simps2D (odd and even row counts)
+    for ny in (L, L - 1):
+        y = c['ec'][:ny] + 1e-12
+        hs, hr, hf = orc.geth(hh[:ny - 1])
+        nint_s = rng.integers(0, ny + 1, W).astype(np.int32)
+        call('pb_simps2D', eng._ptr(out), eng._ptr(eng.dev(y)), ny, W,
+             eng._ptr(eng.dev(hh[:ny - 1])), eng._ptr(eng.dev(nint_s, torch.int32)),
+             eng._ptr(eng.dev(hs)), eng._ptr(eng.dev(hr)), eng._ptr(eng.dev(hf)),
+             eng._stream())
+        np.testing.assert_allclose(host(out), orc.simps2D(y, hh[:ny - 1], nint_s, hs, hr, hf),
+                                   rtol=RTOL)
+    # ediff
+    d = torch.empty(L - 1, dtype=torch.float64, device='cuda')
+    call('pb_ediff', eng._ptr(d), eng._ptr(eng.dev(c['radius'])), L, eng._stream())
+    assert np.array_equal(host(d), orc.ediff(c['radius']))
+
+
+@pytest.mark.parametrize('shape', [(1, 1), (2, 63), (5, 64), (80, 1000), (120, 257)])
+def test_transit_vs_oracle_shapes(eng, orc, shape):
+    """Ragged sizes incl. single layer / single column; itop>0; every column thick or thin."""
+    L, W = shape
+    c = cases.column_case(seed=L * 1000 + W, nlayers=L, nwave=W)
+    for itop, ibottom, maxdepth in ((0, L, 10.0), (min(1, L - 1), L, 0.5), (0, max(L - 1, 0), np.inf)):
+        want_d, want_i = orc.optical_depth_transit(c['ec'], c['radius'], itop, ibottom, maxdepth)
+        path = eng.dev(eng.pack_raypath(eng.transit_path(c['radius'], itop), itop))
+        depth, ideep = eng.optical_depth_transit(eng.dev(c['ec']), path, itop, ibottom, maxdepth)
+        assert np.array_equal(host(ideep), want_i)
+        np.testing.assert_allclose(host(depth), want_d, rtol=RTOL)
+        spec = eng.transmission(depth, ideep, eng.dev(c['radius']), itop, c['rstar'])
+        np.testing.assert_allclose(
+            host(spec), orc.transmission(want_d, c['radius'], c['rstar'], want_i, itop),
+            rtol=RTOL)
+
+
+def test_clear_atmosphere_kats(eng):
+    """Analytic KATs of the reference's tests (test_transmission.py:43-52,
+    test_emission.py:43-52): zero extinction -> (r_bottom/R*)**2 and B(T_bottom)."""
+    import torch
+    c = cases.column_case()
+    L, W = c['nlayers'], c['nwave']
+    ec = torch.zeros((L, W), dtype=torch.float64, device='cuda')
+    path = eng.dev(eng.pack_raypath(eng.transit_path(c['radius'], 0), 0))
+    depth, ideep = eng.optical_depth_transit(ec, path, 0, L, 10.0)
+    spec = eng.transmission(depth, ideep, eng.dev(c['radius']), 0, c['rstar'])
+    np.testing.assert_allclose(host(spec), (c['radius'][-1] / c['rstar'])**2, rtol=1e-14)
+    pd, pi = eng.plane_parallel_optical_depth(ec, eng.dev(-np.diff(c['radius'])), 0, L, 10.0)
+    flux, inten = eng.emission_flux(pd, pi, eng.dev(c['wn']), eng.dev(c['temp']),
+                                    eng.dev(c['mu']), eng.dev(np.ones(5)), 0, True)
+    B = host(eng.blackbody_wn_2D(eng.dev(c['wn']), eng.dev(c['temp'])))
+    for k in range(5):
+        np.testing.assert_allclose(host(inten)[k], B[-1], rtol=1e-13)
+
+
+def test_interp_ec_golden(eng, golden):
+    import torch
+    g = golden('g3_interp')
+    nmol, ntemp, nlayers, nwave = g['etable'].shape
+    et, tt = eng.dev(g['etable']), eng.dev(g['ttable'])
+    te, de = eng.dev(g['temps']), eng.dev(g['dens'])
+    a = torch.full((nlayers, nwave), 1e-12, dtype=torch.float64, device='cuda')
+    eng.interp_ec(a, et, tt, te, de, 0, nlayers)
+    np.testing.assert_allclose(host(a), g['full'], rtol=RTOL)
+    b = torch.zeros((nlayers, nwave), dtype=torch.float64, device='cuda')
+    eng.interp_ec(b, et, tt, te, de, 2, 5)
+    np.testing.assert_allclose(host(b), g['part'], rtol=RTOL)
+    m = torch.zeros((nmol, nlayers, nwave), dtype=torch.float64, device='cuda')
+    eng.interp_ec(m, et, tt, te, de, 0, nlayers + 3, per_mol=True)
+    np.testing.assert_allclose(host(m), g['per_mol'], rtol=RTOL)

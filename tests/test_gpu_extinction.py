@@ -1,0 +1,185 @@
+"""HIP line-by-line extinction (all layers per call, through the C ABI) against the
+golden vectors of the compiled reference and against the oracle.  Needs an MI355X.
+
+Tolerance: rtol 1e-10 on every non-zero sample and an identical zero pattern.  The
+kernel sums the same terms in the same order with fma (one rounding instead of two)
+and device exp(); the table itself agrees to ~1e-13 (test_gpu_voigt.py)."""
+import numpy as np
+import pytest
+
+import cases
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-10
+
+
+@pytest.fixture(scope='module')
+def eng():
+    from pyratbay_amd import engine
+    engine.require_gpu()
+    return engine
+
+
+def host(t):
+    return t.cpu().numpy()
+
+
+def build(eng, c, resolution, table_from_oracle, orc, ethresh=1e-30, cutoff=None):
+    ownstep = c['own'][1] - c['own'][0]
+    osamp = 12
+    if table_from_oracle:
+        size = c['size'].copy()
+        index = np.zeros_like(size)
+        profile = np.zeros(np.sum(2 * size + 1))
+        orc.voigt_grid(profile, size, index, c['lorentz'], c['doppler'], ownstep)
+        vt = eng.VoigtTable.from_flat(profile, size, index, c['lorentz'], c['doppler'], osamp)
+    else:
+        vt = eng.VoigtTable.build(c['lorentz'], c['doppler'], c['size'], ownstep, osamp)
+    ll = eng.LineList(c['lwn'], c['elow'], c['gf'], c['lid'], 3, c['own'])
+    atm, iso = c['atm'], c['iso']
+    lbl = eng.LBL(vt, ll, c['wn'], c['divisors'], atm['mol_radius'], atm['mol_mass'],
+                  iso['isoimol'], iso['isomass'], iso['isoratio'], iso['isoiext'],
+                  c['cutoff'] if cutoff is None else cutoff, ethresh,
+                  resolution=resolution, max_layers=16)
+    return vt, ll, lbl
+
+
+@pytest.mark.parametrize('mode', ['step', 'res'])
+@pytest.mark.parametrize('own_table', [False, True])
+def test_g2_extinction_golden(eng, golden, orc, mode, own_table):
+    g = golden('g2_extinction')
+    c = cases.extinction_inputs(resolution=(mode == 'res'))
+    atm, iso = c['atm'], c['iso']
+    nl = atm['nlayers']
+    temp = eng.dev(atm['temp'])
+    dens = eng.dev(atm['dens'])
+    isoz = eng.dev(np.array([cases.iso_z(t, 3) for t in atm['temp']]).T)   # [niso, L]
+    worst = 0.0
+    plans = {}
+    for k, (layer, add, cut, eth, skip) in enumerate(cases.extinction_variants()):
+        key = (cut,)
+        if key not in plans:
+            plans[key] = build(eng, c, mode == 'res', not own_table, orc,
+                               cutoff=c['cutoff'] if cut else 0.0)
+        vt, ll, lbl = plans[key]
+        isoiext = iso['isoiext'].copy()
+        if skip:
+            isoiext[1] = -1
+        lbl.set_isoiext(isoiext)
+        lbl.set_ethresh(eth)
+        ext = host(lbl.extinction(temp, dens, isoz, add=bool(add)))     # [L, rows, W]
+        got = ext[layer]
+        want = g[f'ext_{mode}'][k][:got.shape[0]]
+        assert np.array_equal(got == 0, want == 0), f'variant {k}: zero pattern differs'
+        nz = want != 0
+        if nz.any():
+            worst = max(worst, np.max(np.abs(got[nz] / want[nz] - 1)))
+        np.testing.assert_allclose(got, want, rtol=RTOL, err_msg=f'variant {k}')
+    print(f'{mode} own_table={own_table}: max rel err vs reference = {worst:.2e}')
+    assert ll.nadd > 0
+
+
+def test_groups_match_oracle_counters(eng, orc):
+    """co-add grouping on the host (pb_lines_create) == the reference's sequential pass."""
+    c = cases.extinction_inputs()
+    vt, ll, lbl = build(eng, c, False, True, orc)
+    atm, iso = c['atm'], c['iso']
+    size = vt.size.copy()
+    index = vt.index.copy()
+    profile = vt.flat()
+    ext = np.zeros((2, len(c['wn'])))
+    st = orc.extinction(ext, profile, size, index, c['lorentz'], c['doppler'], c['wn'],
+                        c['own'], c['divisors'], atm['dens'][3], atm['mol_radius'],
+                        atm['mol_mass'], iso['isoimol'], iso['isomass'], iso['isoratio'],
+                        cases.iso_z(atm['temp'][3], 3), iso['isoiext'], c['lwn'], c['elow'],
+                        c['gf'], c['lid'], c['cutoff'], 1e-30, atm['temp'][3], 0, 0, 0,
+                        return_stats=True)
+    assert ll.nadd == st['nadd']
+    assert ll.ngroups == st['neval'] + st['nskip']
+    # dynamic-sampling factor and kmax per layer
+    temp, dens = eng.dev(atm['temp']), eng.dev(atm['dens'])
+    isoz = eng.dev(np.array([cases.iso_z(t, 3) for t in atm['temp']]).T)
+    lbl.extinction(temp, dens, isoz, add=False)
+    ofactor, kmax = lbl.last_state(atm['nlayers'], 2)
+    for layer in range(atm['nlayers']):
+        st = orc.extinction(ext, profile, size, index, c['lorentz'], c['doppler'], c['wn'],
+                            c['own'], c['divisors'], atm['dens'][layer], atm['mol_radius'],
+                            atm['mol_mass'], iso['isoimol'], iso['isomass'], iso['isoratio'],
+                            cases.iso_z(atm['temp'][layer], 3), iso['isoiext'], c['lwn'],
+                            c['elow'], c['gf'], c['lid'], c['cutoff'], 1e-30,
+                            atm['temp'][layer], 0, 0, 0, return_stats=True)
+        assert ofactor[layer] == st['ofactor'], layer
+    assert np.all(kmax > 0)
+
+
+@pytest.mark.parametrize('nwave,nlines,niso', [(2, 1, 1), (65, 40, 1), (1025, 3000, 2),
+                                               (4097, 20000, 4)])
+def test_synthetic_cases_vs_oracle(eng, orc, nwave, nlines, niso):
+    """Ragged grid sizes (tile edges), several isotopes, every layer; own table."""
+    from pyratbay_amd import synth
+    case = synth.lbl_case(nwave, 6, nlines, wnosamp=24, nlor=18, ndop=9, extent=80.0,
+                          cutoff=3.0, niso=niso, seed=nwave)
+    g, atm, ln, iso, vg = (case[k] for k in ('grid', 'atm', 'lines', 'iso', 'voigt'))
+    vt = eng.VoigtTable.build(vg['lorentz'], vg['doppler'], vg['size'], g['ownstep'], 24)
+    ll = eng.LineList(ln['lwn'], ln['elow'], ln['gf'], ln['lid'], niso, g['own'])
+    lbl = eng.LBL(vt, ll, g['wn'], g['divisors'], atm['mol_radius'], atm['mol_mass'],
+                  iso['isoimol'], iso['isomass'], iso['isoratio'], iso['isoiext'],
+                  vg['cutoff'], 1e-30, max_layers=6)
+    ext = host(lbl.extinction(eng.dev(atm['temp']), eng.dev(atm['dens']),
+                              eng.dev(iso['isoz']), add=True))
+    profile = vt.flat()
+    worst = 0.0
+    for layer in range(6):
+        want = np.zeros((1, g['nwave']))
+        orc.extinction(want, profile, vt.size, vt.index, vg['lorentz'], vg['doppler'],
+                       g['wn'], g['own'], g['divisors'], atm['dens'][layer],
+                       atm['mol_radius'], atm['mol_mass'], iso['isoimol'], iso['isomass'],
+                       iso['isoratio'], iso['isoz'][:, layer].copy(), iso['isoiext'],
+                       ln['lwn'], ln['elow'], ln['gf'], ln['lid'], vg['cutoff'], 1e-30,
+                       atm['temp'][layer], 0, 1, 0)
+        got = ext[layer]
+        assert np.array_equal(got == 0, want == 0), layer
+        nz = want != 0
+        if nz.any():
+            worst = max(worst, np.max(np.abs(got[nz] / want[nz] - 1)))
+        np.testing.assert_allclose(got, want, rtol=RTOL)
+    print(f'W={nwave} N={nlines}: max rel err vs oracle (same table) = {worst:.2e}')
+
+
+def test_wavenumber_shards_concatenate(eng, orc):
+    """Shards [wbegin, wbegin+wcount) of the global grid reproduce the full spectrum
+    bit for bit (no exchange between shards)."""
+    from pyratbay_amd import synth
+    case = synth.lbl_case(3001, 5, 6000, wnosamp=24, nlor=18, ndop=9, extent=80.0,
+                          cutoff=3.0, niso=2, seed=5)
+    g, atm, ln, iso, vg = (case[k] for k in ('grid', 'atm', 'lines', 'iso', 'voigt'))
+    vt = eng.VoigtTable.build(vg['lorentz'], vg['doppler'], vg['size'], g['ownstep'], 24)
+    ll = eng.LineList(ln['lwn'], ln['elow'], ln['gf'], ln['lid'], 2, g['own'])
+    lbl = eng.LBL(vt, ll, g['wn'], g['divisors'], atm['mol_radius'], atm['mol_mass'],
+                  iso['isoimol'], iso['isomass'], iso['isoratio'], iso['isoiext'],
+                  vg['cutoff'], 1e-30, max_layers=5)
+    t, d, z = eng.dev(atm['temp']), eng.dev(atm['dens']), eng.dev(iso['isoz'])
+    full = host(lbl.extinction(t, d, z))
+    bounds = [0, 377, 1024, 1025, 2500, 3001]
+    parts = [host(lbl.extinction(t, d, z, wbegin=a, wcount=b - a))
+             for a, b in zip(bounds[:-1], bounds[1:])]
+    assert np.array_equal(np.concatenate(parts, axis=2), full)
+    # and twice the same call is bitwise reproducible
+    assert np.array_equal(host(lbl.extinction(t, d, z)), full)
+
+
+def test_empty_and_out_of_range_lines(eng):
+    from pyratbay_amd import synth
+    case = synth.lbl_case(513, 3, 50, wnosamp=12, nlor=8, ndop=4, extent=30.0, cutoff=2.0)
+    g, atm, ln, iso, vg = (case[k] for k in ('grid', 'atm', 'lines', 'iso', 'voigt'))
+    vt = eng.VoigtTable.build(vg['lorentz'], vg['doppler'], vg['size'], g['ownstep'], 12)
+    for lwn in (ln['lwn'] + 1e4, ln['lwn'][:0]):          # all out of range / no lines
+        n = len(lwn)
+        ll = eng.LineList(lwn, ln['elow'][:n], ln['gf'][:n], ln['lid'][:n], 1, g['own'])
+        assert ll.ngroups == 0
+        lbl = eng.LBL(vt, ll, g['wn'], g['divisors'], atm['mol_radius'], atm['mol_mass'],
+                      iso['isoimol'], iso['isomass'], iso['isoratio'], iso['isoiext'],
+                      vg['cutoff'], 1e-30, max_layers=3)
+        ext = host(lbl.extinction(eng.dev(atm['temp']), eng.dev(atm['dens']),
+                                  eng.dev(iso['isoz'])))
+        assert ext.shape == (3, 1, 513) and np.all(ext == 0)
