@@ -1,0 +1,225 @@
+#!/usr/bin/env python3
+"""Headline benchmark: transmission spectra per second at 1e5 wavenumbers x 80 layers
+(BASELINE.json configs[1]: 1e5 synthetic lines, transit geometry).
+
+    python bench.py --gpus N --steps K --warmup W
+
+One step = one pass of the hot path over the synthetic workload with every input
+resident in HBM: LBL extinction (all layers) -> transit optical depth -> transmission
+spectrum (the 'extinction' + 'odepth' + 'spectrum' stages of Pyrat.run(),
+pyratbay/pyrat/pyrat_obj.py:203-214).  With N > 1 the spectrum is sharded over
+wavenumber, one rank per GPU, and re-assembled with an RCCL all-gather (strong
+scaling: the total work per step is fixed).  Rank 0 prints ONE JSON line.
+
+The oracle / compiled reference is used only for the `cpu_baseline` leg (and never
+inside the timed region).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WORKLOADS = {
+    # name: (nwave, nlayers, nlines, wnstep, niso)
+    'c2': dict(nwave=100001, nlayers=80, nlines=100000, wnstep=0.05, niso=1,
+               label='1e5 wavenumbers x 80 layers, 1e5 synthetic lines, transit'),
+    'c2-1e6': dict(nwave=100001, nlayers=80, nlines=1000000, wnstep=0.05, niso=1,
+                   label='1e5 wavenumbers x 80 layers, 1e6 synthetic lines, transit'),
+    'small': dict(nwave=10001, nlayers=20, nlines=10000, wnstep=0.05, niso=1,
+                  label='1e4 wavenumbers x 20 layers, 1e4 synthetic lines, transit'),
+}
+HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+def shard_bounds(nwave, world):
+    """Contiguous, balanced wavenumber shards (rank r owns [b[r], b[r+1]))."""
+    base, rem = divmod(nwave, world)
+    sizes = [base + (1 if r < rem else 0) for r in range(world)]
+    return np.concatenate([[0], np.cumsum(sizes)]).astype(int)
+
+
+def cpu_baseline(case, voigt, budget_layers=8):
+    """Reference CPU path on a bounded sample: `budget_layers` of the layers through the
+    unmodified reference _extcoeff.extinction (oracle/_ref; falls back to the oracle's
+    C restatement), extrapolated to all layers, plus the full optical-depth and
+    transmission stages.  Single thread (the reference holds the GIL)."""
+    from oracle import oracle as orc, ref
+    g, atm, ln, iso, vg = (case[k] for k in ('grid', 'atm', 'lines', 'iso', 'voigt'))
+    nlayers = atm['nlayers']
+    size = voigt.size.astype(np.int64)
+    index = voigt.index.astype(np.int64)
+    profile = voigt.flat()
+    if ref.available():
+        kind = 'reference'
+        ext_fn = ref.module('_extcoeff').extinction
+        int_t = np.int64
+    else:
+        kind = 'port'
+        ext_fn = orc.extinction
+        int_t = np.int32
+    layers = np.unique(np.linspace(0, nlayers - 1, budget_layers).round().astype(int))
+    ec = np.zeros((nlayers, g['nwave']))
+    t_ext = 0.0
+    for layer in layers:
+        row = np.zeros((1, g['nwave']))
+        t0 = time.perf_counter()
+        ext_fn(row, profile, size.astype(int_t), index.astype(int_t), vg['lorentz'],
+               vg['doppler'], g['wn'], g['own'], g['divisors'].astype(int_t),
+               atm['dens'][layer], atm['mol_radius'], atm['mol_mass'],
+               iso['isoimol'].astype(int_t), iso['isomass'], iso['isoratio'],
+               iso['isoz'][:, layer].copy(), iso['isoiext'].astype(int_t), ln['lwn'],
+               ln['elow'], ln['gf'], ln['lid'].astype(int_t), vg['cutoff'], case['ethresh'],
+               atm['temp'][layer], 0, 1, 0)
+        t_ext += time.perf_counter() - t0
+        ec[layer] = row[0]
+    # fill the layers that were not sampled so that the later stages see realistic columns
+    for layer in range(nlayers):
+        if layer not in layers:
+            near = layers[np.argmin(np.abs(layers - layer))]
+            ec[layer] = ec[near] * atm['press'][layer] / atm['press'][near]
+    t0 = time.perf_counter()
+    if kind == 'reference':
+        t = ref.module('_trapezoid')
+        raypath = orc.transit_path(atm['radius'], 0)
+        depth = np.zeros_like(ec)
+        ideep = np.full(g['nwave'], -1, np.intc)
+        for r in range(nlayers):
+            depth[r] = t.optdepth(ec[0:r + 1], raypath[r], case['maxdepth'], ideep, r)
+        ideep[ideep < 0] = nlayers - 1
+        h = np.ediff1d(atm['radius'])
+        integ = np.exp(-depth) * np.expand_dims(atm['radius'], 1)
+        spec = t.trapezoid2D(integ, h, (ideep).astype(np.intc))
+        spec = (atm['radius'][0]**2 + 2 * spec) / atm['rstar']**2
+    else:
+        depth, ideep = orc.optical_depth_transit(ec, atm['radius'], 0, nlayers,
+                                                 case['maxdepth'])
+        spec = orc.transmission(depth, atm['radius'], atm['rstar'], ideep, 0)
+    t_rest = time.perf_counter() - t0
+    seconds = t_ext * nlayers / len(layers) + t_rest
+    return dict(value=1.0 / seconds, unit='spectra/s', cores=1, kind=kind,
+                sample=(f'{len(layers)} of {nlayers} layers through extinction '
+                        f'({t_ext:.2f} s), extrapolated x{nlayers / len(layers):.1f}; full '
+                        f'optical depth + transmission ({t_rest:.2f} s); '
+                        f'{seconds:.2f} s per spectrum'))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--workload', default='c2', choices=sorted(WORKLOADS))
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-layers', type=int, default=8)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from pyratbay_amd import engine, synth
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus:
+        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with '
+                         'python -m torch.distributed.run --nproc-per-node N bench.py --gpus N')
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', rank=rank, world_size=world,
+                                device_id=torch.device('cuda', local_rank))
+
+    w = WORKLOADS[args.workload]
+    case = synth.lbl_case(w['nwave'], w['nlayers'], w['nlines'], wnstep=w['wnstep'],
+                          niso=w['niso'], seed=42)
+    nwave, nlayers = case['grid']['nwave'], case['atm']['nlayers']
+    bounds = shard_bounds(nwave, world)
+    wbegin, wcount = int(bounds[rank]), int(bounds[rank + 1] - bounds[rank])
+    t0 = time.perf_counter()
+    model = engine.LBLSpectrum(case, rt_path='transit', wbegin=wbegin, wcount=wcount)
+    torch.cuda.synchronize()
+    t_init = time.perf_counter() - t0
+
+    pad = int(np.max(np.diff(bounds)))
+    if world > 1:
+        send = torch.zeros(pad, dtype=torch.float64, device='cuda')
+        recv = torch.zeros(world * pad, dtype=torch.float64, device='cuda')
+
+    def step():
+        spec = model.run()
+        if world > 1:
+            send[:wcount].copy_(spec)
+            dist.all_gather_into_tensor(recv, send)
+        return spec
+
+    for _ in range(args.warmup):
+        step()
+    model.lbl.timing_begin(args.steps)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    gather_ms, launches = model.lbl.timing_end()
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    if rank == 0:
+        ms_per_step = 1e3 * elapsed / args.steps
+        value = args.steps / elapsed
+        # dominant kernel: k_ext_resample.  Algorithmic bytes per launch = the part of
+        # SURVEY 8(d)'s per-spectrum figure that this kernel moves: read the line list
+        # once (26 B/line), write ec once (8 B per layer x sample of the shard).
+        n_lines = model.lines.nlines
+        kernel_bytes = 26.0 * n_lines + 8.0 * nlayers * wcount
+        path_bytes = 26.0 * n_lines + 32.0 * nlayers * nwave + 8.0 * nwave
+        kernel_ms = gather_ms / max(launches, 1)
+        achieved = kernel_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
+        traffic = None
+        tfile = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
+        if os.path.exists(tfile):
+            try:
+                traffic = json.load(open(tfile)).get(args.workload, {}).get('hbm_bytes_per_launch')
+            except Exception:
+                traffic = None
+        out = {
+            'metric': 'spectra/sec (1e5 wavenumbers x 80 layers)',
+            'value': value, 'unit': 'spectra/s', 'n_gpus': world, 'steps': args.steps,
+            'warmup': args.warmup, 'ms_per_step': ms_per_step, 'higher_is_better': True,
+            'scaling': 'strong', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
+            'config': {'workload': w['label'], 'nwave': nwave, 'nlayers': nlayers,
+                       'nlines': n_lines, 'wnosamp': case['grid']['wnosamp'],
+                       'voigt_grid': 'nlor=100 ndop=50 extent=300 cutoff=25',
+                       'voigt_table_bytes': int(model.voigt.device_bytes),
+                       'parallelism': f'wavenumber shards x{world}' if world > 1 else 'single GPU',
+                       'init_seconds': round(t_init, 3)},
+            'roofline': {'bound': 'hbm', 'kernel': 'k_ext_resample', 'achieved': achieved,
+                         'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                         'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
+                         'kernel_ms': kernel_ms, 'kernel_bytes': kernel_bytes,
+                         'path_bytes_per_spectrum': path_bytes,
+                         'path_GBps': path_bytes * value / 1e9},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline(case, model.voigt, args.cpu_layers)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -116,6 +116,12 @@ int pb_lbl_extinction(pb_lbl *p, double *ext_d, int64_t wbegin, int64_t wcount,
  * kmax_h[nlayers*nrows] (per-species maximum line strength, :225). */
 int pb_lbl_last_state(pb_lbl *p, int32_t *ofactor_h, double *kmax_h, int nlayers,
                       int nrows, void *stream);
+/* Per-launch timing of the gather kernel with HIP events on the call's stream:
+ * begin() arms up to max_launches start/stop pairs, every following
+ * pb_lbl_extinction records one pair around its gather launch, end() returns the summed
+ * kernel time and the number of launches (used by bench.py for the roofline figure). */
+int pb_lbl_timing_begin(pb_lbl *p, int max_launches);
+int pb_lbl_timing_end(pb_lbl *p, double *total_ms, int *launches);
 void pb_lbl_destroy(pb_lbl *p);
 
 /* =========================================================================

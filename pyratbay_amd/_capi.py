@@ -43,6 +43,8 @@ _PROTOS = {
     'pb_lbl_set_ethresh': [vp, f64],
     'pb_lbl_extinction': [vp, vp, i64, i64, vp, vp, vp, i64, i64, i32, i32, vp],
     'pb_lbl_last_state': [vp, vp, vp, i32, i32, vp],
+    'pb_lbl_timing_begin': [vp, i32],
+    'pb_lbl_timing_end': [vp, C.POINTER(f64), C.POINTER(i32)],
     'pb_lbl_destroy': [vp],
     'pb_interp_ec': [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp],
     'pb_optdepth': [vp, vp, i64, vp, i32, f64, vp, i32, i32, vp],
@@ -66,6 +68,18 @@ def exported_names():
     return sorted(list(_PROTOS) + ['pb_last_error'])
 
 
+def _preload_torch_hip_runtime():
+    """One HIP runtime per process.  torch bundles its own libamdhip64 (SONAME
+    libamdhip64.so.7, file name libamdhip64.so); libpbhip.so needs the same SONAME.  If
+    libpbhip were loaded first it would pull /opt/rocm's copy and torch would later add
+    its own: two runtimes, and device pointers / streams handed across would break.
+    Loading torch's copy first makes the dynamic loader reuse it for libpbhip."""
+    import torch
+    cand = os.path.join(os.path.dirname(torch.__file__), 'lib', 'libamdhip64.so')
+    if os.path.exists(cand):
+        C.CDLL(cand, mode=C.RTLD_GLOBAL)
+
+
 def lib():
     """Load libpbhip.so or fail loudly."""
     global _lib
@@ -74,6 +88,7 @@ def lib():
             raise PbError(
                 f'{LIBPATH} is missing: build it with `make -C pyratbay_amd/csrc` '
                 '(or __graft_entry__.build()); there is no CPU fallback')
+        _preload_torch_hip_runtime()
         handle = C.CDLL(LIBPATH)
         handle.pb_last_error.restype = C.c_char_p
         handle.pb_last_error.argtypes = []

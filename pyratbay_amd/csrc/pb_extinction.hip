@@ -604,6 +604,9 @@ struct pb_lbl {
     double *ls_dwnstep = nullptr, *li_alphad = nullptr, *li_dens = nullptr, *li_z = nullptr;
     unsigned long long *kmax_bits = nullptr;
     int kmax_rows = 0;
+    // optional per-launch timing of the gather kernel (bench.py's roofline figure)
+    std::vector<hipEvent_t> ev;      // start/stop pairs
+    int ev_used = 0;
 };
 
 extern "C" {
@@ -936,6 +939,9 @@ int pb_lbl_extinction(pb_lbl *p, double *ext_d, int64_t wbegin, int64_t wcount,
         PB_LAUNCH_CHECK();
     }
     const int layer_groups = (nlayers + 7) / 8;
+    const bool timed = p->ev_used + 2 <= (int)p->ev.size();
+    if (timed)
+        PB_HIP(hipEventRecord(p->ev[p->ev_used], s));
     if (p->resolution) {
         a.ntiles = pb::div_up(wcount, kBlock);
         dim3 grid((unsigned)(8 * a.ntiles * layer_groups), a.nrows);
@@ -946,6 +952,45 @@ int pb_lbl_extinction(pb_lbl *p, double *ext_d, int64_t wbegin, int64_t wcount,
         k_ext_resample<<<grid, kBlock, 0, s>>>(a);
     }
     PB_LAUNCH_CHECK();
+    if (timed) {
+        PB_HIP(hipEventRecord(p->ev[p->ev_used + 1], s));
+        p->ev_used += 2;
+    }
+    return PB_OK;
+}
+
+int pb_lbl_timing_begin(pb_lbl *p, int max_launches)
+{
+    PB_REQUIRE(p && max_launches >= 0, "pb_lbl_timing_begin: bad argument");
+    while ((int)p->ev.size() < 2 * max_launches) {
+        hipEvent_t e;
+        PB_HIP(hipEventCreate(&e));
+        p->ev.push_back(e);
+    }
+    while ((int)p->ev.size() > 2 * max_launches) {
+        (void)hipEventDestroy(p->ev.back());
+        p->ev.pop_back();
+    }
+    p->ev_used = 0;
+    return PB_OK;
+}
+
+int pb_lbl_timing_end(pb_lbl *p, double *total_ms, int *launches)
+{
+    PB_REQUIRE(p && total_ms && launches, "pb_lbl_timing_end: null pointer");
+    double sum = 0.0;
+    for (int i = 0; i + 1 < p->ev_used; i += 2) {
+        PB_HIP(hipEventSynchronize(p->ev[i + 1]));
+        float ms = 0.f;
+        PB_HIP(hipEventElapsedTime(&ms, p->ev[i], p->ev[i + 1]));
+        sum += ms;
+    }
+    *total_ms = sum;
+    *launches = p->ev_used / 2;
+    p->ev_used = 0;
+    for (hipEvent_t e : p->ev)
+        (void)hipEventDestroy(e);
+    p->ev.clear();
     return PB_OK;
 }
 
@@ -986,6 +1031,8 @@ void pb_lbl_destroy(pb_lbl *p)
     (void)hipFree(p->li_ilor);
     (void)hipFree(p->li_hmax);
     (void)hipFree(p->kmax_bits);
+    for (hipEvent_t e : p->ev)
+        (void)hipEventDestroy(e);
     delete p;
 }
 

@@ -184,6 +184,15 @@ class LBL:
              _stream())
         return out
 
+    def timing_begin(self, max_launches):
+        call('pb_lbl_timing_begin', self._h, int(max_launches))
+
+    def timing_end(self):
+        """(summed gather-kernel milliseconds, launches) since timing_begin()."""
+        ms, n = C.c_double(0), C.c_int(0)
+        call('pb_lbl_timing_end', self._h, C.byref(ms), C.byref(n))
+        return ms.value, n.value
+
     def last_state(self, nlayers, rows):
         ofactor = np.zeros(nlayers, np.int32)
         kmax = np.zeros((nlayers, rows))

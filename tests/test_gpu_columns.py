@@ -94,7 +94,10 @@ def test_single_optdepth_trapz_simps_ediff(eng, golden, orc):
     want = orc.optdepth(c['ec'][itop:r + 1], path, 3.0, want_ideep, r)
     ideep = eng.dev(ideep_h, torch.int32)
     tau = torch.empty(W, dtype=torch.float64, device='cuda')
-    call('pb_optdepth', eng._ptr(tau), ec[itop:].data_ptr(), W, eng._ptr(eng.dev(path)),
+    # NB: every device buffer whose raw pointer is passed must stay referenced until the
+    # call is issued (a temporary would be recycled by the caching allocator)
+    path_d = eng.dev(path)
+    call('pb_optdepth', eng._ptr(tau), ec[itop:].data_ptr(), W, eng._ptr(path_d),
          len(path), 3.0, eng._ptr(ideep), r, W, eng._stream())
     np.testing.assert_allclose(host(tau), want, rtol=RTOL)
     assert np.array_equal(host(ideep), want_ideep)
@@ -102,23 +105,26 @@ def test_single_optdepth_trapz_simps_ediff(eng, golden, orc):
     nint_h = rng.integers(0, L, W).astype(np.int32)
     hh = rng.uniform(0.5, 2.0, L - 1)
     out = torch.empty(W, dtype=torch.float64, device='cuda')
-    call('pb_trapezoid2D', eng._ptr(out), eng._ptr(ec), eng._ptr(eng.dev(hh)),
-         eng._ptr(eng.dev(nint_h, torch.int32)), L, W, eng._stream())
+    hh_d, nint_d = eng.dev(hh), eng.dev(nint_h, torch.int32)
+    call('pb_trapezoid2D', eng._ptr(out), eng._ptr(ec), eng._ptr(hh_d), eng._ptr(nint_d),
+         L, W, eng._stream())
     np.testing.assert_allclose(host(out), orc.trapezoid2D(c['ec'], hh, nint_h), rtol=RTOL)
     # simps2D (odd and even row counts)
     for ny in (L, L - 1):
         y = c['ec'][:ny] + 1e-12
         hs, hr, hf = orc.geth(hh[:ny - 1])
         nint_s = rng.integers(0, ny + 1, W).astype(np.int32)
-        call('pb_simps2D', eng._ptr(out), eng._ptr(eng.dev(y)), ny, W,
-             eng._ptr(eng.dev(hh[:ny - 1])), eng._ptr(eng.dev(nint_s, torch.int32)),
-             eng._ptr(eng.dev(hs)), eng._ptr(eng.dev(hr)), eng._ptr(eng.dev(hf)),
+        bufs = [eng.dev(y), eng.dev(hh[:ny - 1]), eng.dev(nint_s, torch.int32),
+                eng.dev(hs), eng.dev(hr), eng.dev(hf)]
+        call('pb_simps2D', eng._ptr(out), eng._ptr(bufs[0]), ny, W, eng._ptr(bufs[1]),
+             eng._ptr(bufs[2]), eng._ptr(bufs[3]), eng._ptr(bufs[4]), eng._ptr(bufs[5]),
              eng._stream())
         np.testing.assert_allclose(host(out), orc.simps2D(y, hh[:ny - 1], nint_s, hs, hr, hf),
                                    rtol=RTOL)
     # ediff
     d = torch.empty(L - 1, dtype=torch.float64, device='cuda')
-    call('pb_ediff', eng._ptr(d), eng._ptr(eng.dev(c['radius'])), L, eng._stream())
+    rad_d = eng.dev(c['radius'])
+    call('pb_ediff', eng._ptr(d), eng._ptr(rad_d), L, eng._stream())
     assert np.array_equal(host(d), orc.ediff(c['radius']))
 
 
