@@ -384,22 +384,36 @@ __global__ __launch_bounds__(kBlock) void k_ext_resample(LblArgs a)
                 const int64_t my_off = s_off[e & (kBlock - 1)];
                 const int my_lo = s_lo[e & (kBlock - 1)];
                 const int my_hi = s_hi[e & (kBlock - 1)];
+                // Two records per trip, all eight 512-byte loads issued before the first
+                // fma (memory-level parallelism); no branches inside: lanes outside a
+                // record's window read a clamped (valid) address and add 0 * value.
                 while (mask) {
-                    const int src = __builtin_amdgcn_readfirstlane(__builtin_ctzll(mask));
+                    const int src0 = __builtin_amdgcn_readfirstlane(__builtin_ctzll(mask));
                     mask &= mask - 1;
-                    const double k = bcast(my_k, src);
-                    const int64_t off = bcast(my_off, src);
-                    const int lo = __builtin_amdgcn_readlane(my_lo, src);
-                    const int hi = __builtin_amdgcn_readlane(my_hi, src);
-                    const double *tab = a.pm + off;
+                    const bool two = mask != 0;
+                    const int src1 =
+                        two ? __builtin_amdgcn_readfirstlane(__builtin_ctzll(mask)) : src0;
+                    mask &= mask - 1;            // no-op when mask is already 0
+                    const double k0 = bcast(my_k, src0);
+                    const double k1 = two ? bcast(my_k, src1) : 0.0;
+                    const double *tab0 = a.pm + bcast(my_off, src0);
+                    const double *tab1 = a.pm + bcast(my_off, src1);
+                    const int lo0 = __builtin_amdgcn_readlane(my_lo, src0);
+                    const int hi0 = __builtin_amdgcn_readlane(my_hi, src0);
+                    const int lo1 = __builtin_amdgcn_readlane(my_lo, src1);
+                    const int hi1 = __builtin_amdgcn_readlane(my_hi, src1);
+                    double v0[kChunks], v1[kChunks];
 #pragma unroll
                     for (int s = 0; s < kChunks; s++) {
-                        const int c0 = rlo + s * 64;
-                        if (lo < c0 + 64 && hi > c0) {
-                            const int j = c0 + lane;
-                            if (j >= lo && j < hi)
-                                acc[s] = fma(k, tab[j], acc[s]);
-                        }
+                        const int j = rlo + s * 64 + lane;
+                        v0[s] = tab0[min(max(j, lo0), hi0 - 1)];
+                        v1[s] = tab1[min(max(j, lo1), hi1 - 1)];
+                    }
+#pragma unroll
+                    for (int s = 0; s < kChunks; s++) {
+                        const int j = rlo + s * 64 + lane;
+                        acc[s] = fma((j >= lo0 && j < hi0) ? k0 : 0.0, v0[s], acc[s]);
+                        acc[s] = fma((j >= lo1 && j < hi1) ? k1 : 0.0, v1[s], acc[s]);
                     }
                 }
             }

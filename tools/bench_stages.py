@@ -1,0 +1,31 @@
+"""Per-stage device timing of the hot path (torch events on the current stream).
+usage: python tools/bench_stages.py [workload] [steps]"""
+import sys
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import bench
+from pyratbay_amd import engine, synth
+
+name = sys.argv[1] if len(sys.argv) > 1 else 'c2'
+steps = int(sys.argv[2]) if len(sys.argv) > 2 else 10
+w = bench.WORKLOADS[name]
+case = synth.lbl_case(w['nwave'], w['nlayers'], w['nlines'], wnstep=w['wnstep'],
+                      niso=w['niso'], seed=42)
+model = engine.LBLSpectrum(case, rt_path='transit')
+for _ in range(2):
+    model.run()
+torch.cuda.synchronize()
+ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+tot = [0.0, 0.0, 0.0]
+for _ in range(steps):
+    ev[0].record(); model.extinction()
+    ev[1].record(); model.optical_depth()
+    ev[2].record(); model.rt()
+    ev[3].record()
+    torch.cuda.synchronize()
+    for i in range(3):
+        tot[i] += ev[i].elapsed_time(ev[i + 1])
+print(f'{name}: extinction {tot[0]/steps:.3f} ms  odepth {tot[1]/steps:.3f} ms  '
+      f'spectrum {tot[2]/steps:.3f} ms  total {sum(tot)/steps:.3f} ms '
+      f'({steps/sum(tot)*1e3:.1f} spectra/s)')
