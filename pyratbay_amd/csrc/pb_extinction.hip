@@ -31,6 +31,7 @@
 // that XCD's 4 MiB L2), heaviest (deepest) layers first.
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <new>
 #include <vector>
 
@@ -40,8 +41,14 @@
 namespace {
 
 constexpr int kBlock = 256;
-constexpr int kChunks = 4;                       // 64-sample chunks per wavefront
-constexpr int kTile = kBlock * kChunks;          // output samples per workgroup
+constexpr int kChunks = 2;                       // 128-sample chunks per wavefront
+constexpr int kLaneSamples = 2;                  // consecutive samples per lane (16-B loads)
+constexpr int kChunk = 64 * kLaneSamples;        // samples per chunk
+constexpr int kWaveSpan = kChunks * kChunk;      // samples per wavefront
+constexpr int kTile = 4 * kWaveSpan;             // output samples per workgroup
+constexpr int kRecs = 4;                         // records in flight per wavefront trip
+static_assert(kTile <= kPmPad, "table padding must cover one tile");
+static_assert(kTile < 65536, "window coordinates are packed in 16 bits");
 
 struct LblArgs {
     // Voigt table
@@ -84,6 +91,7 @@ struct LblArgs {
     int add, nrows, nlayers, nwave;
     int64_t wbegin, wcount;
     int ntiles;
+    int experiment;      // diagnostics only (PB_EXPERIMENT): 1 = every record reads one slice
     double *ext;
 };
 
@@ -215,13 +223,6 @@ __device__ inline double bcast(double v, int lane)
     int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
     return __hiloint2double(hi, lo);
 }
-__device__ inline int64_t bcast(int64_t v, int lane)
-{
-    unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(v & 0xffffffff), lane);
-    int hi = __builtin_amdgcn_readlane((int)(v >> 32), lane);
-    return ((int64_t)hi << 32) | lo;
-}
-
 // Window of one group on the dynamic grid, exactly as _extcoeff.c:274-299.
 struct Window {
     long minj, maxj;
@@ -230,11 +231,15 @@ struct Window {
 
 __device__ inline Window group_window(const LblArgs &a, double wavn, int iown, int ilor,
                                       double alphad, int ofactor, double dwnstep,
-                                      int64_t dnwn)
+                                      int64_t dnwn, int idop_lo, int idop_hi)
 {
+    // [idop_lo, idop_hi] brackets the answer (nearest index is monotonic in wavn), which
+    // turns the bisection over the whole Doppler grid into 0-2 steps
     Window w;
     const int idwn = (int)((wavn - a.own0) / dwnstep);
-    const int idop = pb::nearest_index(a.doppler, alphad * wavn, 0, a.ndop - 1);
+    const int idop = idop_lo == idop_hi
+                         ? idop_lo
+                         : pb::nearest_index(a.doppler, alphad * wavn, idop_lo, idop_hi);
     w.cell = ilor * a.ndop + idop;
     w.half = a.psize[w.cell];
     const int subw = iown - idwn * ofactor;
@@ -279,12 +284,22 @@ __device__ inline void decode_block(const LblArgs &a, int &tile, int &layer)
 
 // ---------------------------------------------------------------------------
 // 3a. gather, constant-step output grid (resample mode)
+//
+// Record of one candidate group (16 B in LDS): strength k, 32-bit table offset relative
+// to a per-(workgroup, isotope) base pointer, window [lo, hi) packed as two 16-bit tile
+// coordinates.  A lane owns the two consecutive samples c0 + 2*lane + {0,1} of each
+// 128-sample chunk, so its byte offset from a record's table pointer is a per-lane
+// CONSTANT: the load is `global_load_dwordx4 v, v_lane_off, s[tab]` with no per-record
+// address arithmetic.  Lanes outside a record's window read whatever lies there (the
+// table is padded by kTile samples on both sides, all finite); whether a chunk is
+// fully inside (fma with the scalar k), partial (k or 0 selected per sample) or outside
+// (skipped) is decided by scalar compares.
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(kBlock) void k_ext_resample(LblArgs a)
 {
     __shared__ double s_k[kBlock];
-    __shared__ int64_t s_off[kBlock];
-    __shared__ int s_lo[kBlock], s_hi[kBlock];
+    __shared__ unsigned s_off[kBlock];
+    __shared__ unsigned s_win[kBlock];           // lo | hi << 16
 
     int tile, layer;
     decode_block(a, tile, layer);
@@ -296,8 +311,8 @@ __global__ __launch_bounds__(kBlock) void k_ext_resample(LblArgs a)
 
     const int64_t t0 = a.wbegin + (int64_t)tile * kTile;           // global sample index
     const int64_t tend = min(t0 + kTile, a.wbegin + a.wcount);
-    const int64_t wlo = t0 + (int64_t)wave * (64 * kChunks);
-    const int64_t whi = min(wlo + 64 * kChunks, tend);
+    const int rlo = wave * kWaveSpan;                              // tile coordinates
+    const int rhi = (int)min((int64_t)rlo + kWaveSpan, tend - t0);
 
     const int ofactor = a.ls_ofactor[layer];
     const int scale = a.ls_scale[layer];
@@ -308,10 +323,10 @@ __global__ __launch_bounds__(kBlock) void k_ext_resample(LblArgs a)
         a.ethresh * __longlong_as_double((long long)a.kmax_bits[(int64_t)layer * a.nrows + row]);
     const int osamp = a.osamp;
 
-    double acc[kChunks];
+    double acc[kChunks][kLaneSamples];
 #pragma unroll
     for (int s = 0; s < kChunks; s++)
-        acc[s] = 0.0;
+        acc[s][0] = acc[s][1] = 0.0;
 
     for (int iso = 0; iso < a.niso; iso++) {
         const int iext = a.isoiext[iso];
@@ -331,6 +346,18 @@ __global__ __launch_bounds__(kBlock) void k_ext_resample(LblArgs a)
         const int64_t seg0 = a.iso_gstart[iso], seg1 = a.iso_gstart[iso + 1];
         const int64_t g0 = lower_bound_i32(a.giown, seg0, seg1, t0 * osamp - reach);
         const int64_t g1 = lower_bound_i32(a.giown, seg0, seg1, (tend - 1) * osamp + reach + 1);
+        if (g0 >= g1)
+            continue;
+        // Doppler-grid indices that the candidates can take: the nearest-index map is
+        // monotonic in the line position, so it is bracketed by the images of the first
+        // and last candidate positions (a leader lies within one fine step of own[iown]).
+        const double vmin = a.own0 + ((double)a.giown[g0] - 1.0) * a.ownstep;
+        const double vmax = a.own0 + ((double)a.giown[g1 - 1] + 1.0) * a.ownstep;
+        const int idop_lo = pb::nearest_index(a.doppler, alphad * vmin, 0, a.ndop - 1);
+        const int idop_hi = pb::nearest_index(a.doppler, alphad * vmax, 0, a.ndop - 1);
+        const int64_t cell_lo = (int64_t)ilor * a.ndop + idop_lo;
+        const int64_t base_idx = a.pm_base[cell_lo] - kTile;       // inside the front pad
+        const double *base = a.pm + base_idx;
 
         for (int64_t gb = g0; gb < g1; gb += kBlock) {
             __syncthreads();
@@ -338,8 +365,7 @@ __global__ __launch_bounds__(kBlock) void k_ext_resample(LblArgs a)
             {
                 const int64_t g = gb + threadIdx.x;
                 double k = 0.0;
-                int64_t off = 0;
-                int jlo = 0, jhi = 0;
+                unsigned off = 0, win = 0;
                 if (g < g1) {
                     const int first = a.gfirst[g];
                     const int iown = a.giown[g];
@@ -348,7 +374,7 @@ __global__ __launch_bounds__(kBlock) void k_ext_resample(LblArgs a)
                         if (a.add)
                             k *= dens;
                         const Window w = group_window(a, a.lwn[first], iown, ilor, alphad,
-                                                      ofactor, dwnstep, dnwn);
+                                                      ofactor, dwnstep, dnwn, idop_lo, idop_hi);
                         // kept samples: minj <= scale*jo < maxj, inside the profile
                         int64_t lo = (w.minj + scale - 1) / scale;
                         int64_t hi = (w.maxj + scale - 1) / scale;
@@ -357,75 +383,90 @@ __global__ __launch_bounds__(kBlock) void k_ext_resample(LblArgs a)
                         lo = max(lo, t0);
                         hi = min(hi, tend);
                         if (lo < hi) {
-                            jlo = (int)(lo - t0);
-                            jhi = (int)(hi - t0);
+                            win = (unsigned)(lo - t0) | ((unsigned)(hi - t0) << 16);
                             const int64_t f0 = (int64_t)w.half - iown;
                             const int64_t q = pb::floor_div(f0, osamp);
                             const int64_t phi = f0 - q * osamp;
-                            // sample jo reads pm[off + (jo - t0)]
-                            off = a.pm_base[w.cell] + phi * a.pm_stride[w.cell] + q + t0;
+                            // tile sample j reads base[off + j]
+                            off = (unsigned)(a.pm_base[w.cell] + phi * a.pm_stride[w.cell] + q +
+                                             t0 - base_idx);
+                            if (a.experiment == 1)
+                                off = (unsigned)(kTile + (lo - t0));
                         }
                     }
                 }
                 s_k[threadIdx.x] = k;
                 s_off[threadIdx.x] = off;
-                s_lo[threadIdx.x] = jlo;
-                s_hi[threadIdx.x] = jhi;
+                s_win[threadIdx.x] = win;
             }
             __syncthreads();
-            // ---- every wavefront walks the records that reach its 256 samples ----
+            // ---- every wavefront walks the records that reach its samples ----
             const int nrec = (int)min((int64_t)kBlock, g1 - gb);
-            const int rlo = (int)(wlo - t0), rhi = (int)(whi - t0);
-            for (int base = 0; base < nrec; base += 64) {
-                const int e = base + lane;
-                const bool hit = e < nrec && s_lo[e] < rhi && s_hi[e] > rlo;
+            for (int b = 0; b < nrec; b += 64) {
+                const int e = (b + lane) & (kBlock - 1);
+                const unsigned my_win = s_win[e];
+                const bool hit = b + lane < nrec && (int)(my_win & 0xffff) < rhi &&
+                                 (int)(my_win >> 16) > rlo;
                 unsigned long long mask = __ballot(hit);
-                const double my_k = s_k[e & (kBlock - 1)];
-                const int64_t my_off = s_off[e & (kBlock - 1)];
-                const int my_lo = s_lo[e & (kBlock - 1)];
-                const int my_hi = s_hi[e & (kBlock - 1)];
-                // Two records per trip, all eight 512-byte loads issued before the first
-                // fma (memory-level parallelism); no branches inside: lanes outside a
-                // record's window read a clamped (valid) address and add 0 * value.
+                const double my_k = s_k[e];
+                const unsigned my_off = s_off[e];
+                // kRecs records per trip: all loads are issued before the first fma
                 while (mask) {
-                    const int src0 = __builtin_amdgcn_readfirstlane(__builtin_ctzll(mask));
-                    mask &= mask - 1;
-                    const bool two = mask != 0;
-                    const int src1 =
-                        two ? __builtin_amdgcn_readfirstlane(__builtin_ctzll(mask)) : src0;
-                    mask &= mask - 1;            // no-op when mask is already 0
-                    const double k0 = bcast(my_k, src0);
-                    const double k1 = two ? bcast(my_k, src1) : 0.0;
-                    const double *tab0 = a.pm + bcast(my_off, src0);
-                    const double *tab1 = a.pm + bcast(my_off, src1);
-                    const int lo0 = __builtin_amdgcn_readlane(my_lo, src0);
-                    const int hi0 = __builtin_amdgcn_readlane(my_hi, src0);
-                    const int lo1 = __builtin_amdgcn_readlane(my_lo, src1);
-                    const int hi1 = __builtin_amdgcn_readlane(my_hi, src1);
-                    double v0[kChunks], v1[kChunks];
+                    int src[kRecs];
 #pragma unroll
-                    for (int s = 0; s < kChunks; s++) {
-                        const int j = rlo + s * 64 + lane;
-                        v0[s] = tab0[min(max(j, lo0), hi0 - 1)];
-                        v1[s] = tab1[min(max(j, lo1), hi1 - 1)];
+                    for (int r = 0; r < kRecs; r++) {
+                        src[r] = mask ? __builtin_amdgcn_readfirstlane(__builtin_ctzll(mask))
+                                      : -1;
+                        mask &= mask - 1;        // no-op once mask is 0
+                    }
+                    double2 v[kRecs][kChunks];
+                    double kk[kRecs];
+                    int lo[kRecs], hi[kRecs];
+#pragma unroll
+                    for (int r = 0; r < kRecs; r++) {
+                        const int sl = src[r] < 0 ? src[0] : src[r];
+                        kk[r] = bcast(my_k, sl);
+                        const unsigned win = (unsigned)__builtin_amdgcn_readlane((int)my_win, sl);
+                        const unsigned off = (unsigned)__builtin_amdgcn_readlane((int)my_off, sl);
+                        lo[r] = (int)(win & 0xffff);
+                        hi[r] = (int)(win >> 16);
+                        if (src[r] < 0)
+                            kk[r] = 0.0;                                // padding slot
+                        const double *tab = base + off;
+#pragma unroll
+                        for (int s = 0; s < kChunks; s++) {
+                            // pair address clamped to [lo-1, hi-1]: in-window samples stay
+                            // in their own slot, lanes outside re-read an edge line
+                            const int j = rlo + s * kChunk + 2 * lane;
+                            const int jc = min(max(j, lo[r] - 1), hi[r] - 1);
+                            v[r][s] = *reinterpret_cast<const double2 *>(tab + jc);
+                        }
                     }
 #pragma unroll
-                    for (int s = 0; s < kChunks; s++) {
-                        const int j = rlo + s * 64 + lane;
-                        acc[s] = fma((j >= lo0 && j < hi0) ? k0 : 0.0, v0[s], acc[s]);
-                        acc[s] = fma((j >= lo1 && j < hi1) ? k1 : 0.0, v1[s], acc[s]);
+                    for (int r = 0; r < kRecs; r++) {
+                        const unsigned span = (unsigned)(hi[r] - lo[r]);
+#pragma unroll
+                        for (int s = 0; s < kChunks; s++) {
+                            const int j = rlo + s * kChunk + 2 * lane;
+                            acc[s][0] = fma((unsigned)(j - lo[r]) < span ? kk[r] : 0.0,
+                                            v[r][s].x, acc[s][0]);
+                            acc[s][1] = fma((unsigned)(j + 1 - lo[r]) < span ? kk[r] : 0.0,
+                                            v[r][s].y, acc[s][1]);
+                        }
                     }
                 }
             }
         }
     }
 
-    double *dst = a.ext + ((int64_t)layer * a.nrows + row) * a.wcount + (wlo - a.wbegin);
+    double *dst = a.ext + ((int64_t)layer * a.nrows + row) * a.wcount + (t0 - a.wbegin);
 #pragma unroll
     for (int s = 0; s < kChunks; s++) {
-        const int64_t jo = wlo + s * 64 + lane;
-        if (jo < whi)
-            dst[s * 64 + lane] = acc[s];
+        const int j = rlo + s * kChunk + 2 * lane;
+        if (j < rhi)
+            dst[j] = acc[s][0];
+        if (j + 1 < rhi)
+            dst[j + 1] = acc[s][1];
     }
 }
 
@@ -501,7 +542,7 @@ __global__ __launch_bounds__(kBlock) void k_ext_linterp(LblArgs a)
                         if (a.add)
                             k *= dens;
                         const Window w = group_window(a, a.lwn[first], iown, ilor, alphad,
-                                                      ofactor, dwnstep, dnwn);
+                                                      ofactor, dwnstep, dnwn, 0, a.ndop - 1);
                         // dynamic sample j reads flat[pindex + half + ofactor*j - iown]
                         mn = (int)w.minj;
                         mx = (int)w.maxj;
@@ -785,6 +826,17 @@ int pb_lbl_create(pb_lbl **out, pb_voigt *voigt, pb_lines *lines, const double *
             }
         }
     }
+    // the gather kernel addresses one Lorentz row of the table with 32-bit offsets
+    for (int m = 0; m < voigt->nlor; m++) {
+        const size_t k0 = (size_t)m * voigt->ndop, k1 = k0 + voigt->ndop - 1;
+        const int64_t span = voigt->pm_base[k1] + (int64_t)voigt->pm_stride[k1] * voigt->osamp -
+                             voigt->pm_base[k0] + 4 * (int64_t)kPmPad;
+        if (span >= 4294967296LL) {
+            pb::set_error("pb_lbl_create: Lorentz row %d of the Voigt table spans %lld "
+                          "samples (> 2^32)", m, (long long)span);
+            return PB_ERR_UNSUPPORTED;
+        }
+    }
     pb_lbl *p = new (std::nothrow) pb_lbl();
     if (!p)
         return PB_ERR_NOMEM;
@@ -943,6 +995,10 @@ int pb_lbl_extinction(pb_lbl *p, double *ext_d, int64_t wbegin, int64_t wcount,
     a.wbegin = wbegin;
     a.wcount = wcount;
     a.ext = ext_d;
+    {
+        const char *e = getenv("PB_EXPERIMENT");
+        a.experiment = e ? atoi(e) : 0;
+    }
 
     k_layer_state<<<nlayers, 64, 0, s>>>(a);
     PB_LAUNCH_CHECK();

@@ -8,6 +8,8 @@
 
 #include "pbhip.h"
 
+constexpr int kPmPad = 1024;   // >= the gather kernel's tile (pb_extinction.hip kTile)
+
 struct pb_voigt {
     int nlor = 0, ndop = 0, osamp = 0, ncell = 0, max_half = 0;
     double dwn = 0.0;
@@ -18,7 +20,10 @@ struct pb_voigt {
     std::vector<int32_t> psize, pindex, pm_stride;
     std::vector<int64_t> pm_base;
     // device
-    double *d_pm = nullptr;      // phase-major table
+    double *d_pm = nullptr;      // phase-major table (= d_pm_alloc + kPmPad)
+    double *d_pm_alloc = nullptr; // allocation: kPmPad zero samples before and after; the
+                                  // gather kernel's lanes outside a line's window read
+                                  // (and discard) up to one tile beyond it
     double *d_flat = nullptr;    // reference-layout table (optional)
     void *d_cells = nullptr;     // per computed cell descriptors
     int64_t *d_flat_bases = nullptr, *d_pm_bases = nullptr;  // [ncell]

@@ -338,6 +338,20 @@ int grid_for(int64_t n, unsigned *out)
     return PB_OK;
 }
 
+// Allocate the phase-major table with kPmPad zeroed samples on either side.
+int alloc_pm(pb_voigt *v, hipStream_t s)
+{
+    const size_t n = (size_t)v->npm + 2 * kPmPad;
+    if (hipMalloc(&v->d_pm_alloc, n * sizeof(double)) != hipSuccess) {
+        pb::set_error("voigt: cannot allocate %zu B for the table", n * 8);
+        return PB_ERR_NOMEM;
+    }
+    v->d_pm = v->d_pm_alloc + kPmPad;
+    PB_HIP(hipMemsetAsync(v->d_pm_alloc, 0, kPmPad * sizeof(double), s));
+    PB_HIP(hipMemsetAsync(v->d_pm + v->npm, 0, kPmPad * sizeof(double), s));
+    return PB_OK;
+}
+
 }  // namespace
 
 int pb_voigt_ensure_flat(pb_voigt *v, hipStream_t stream)
@@ -378,13 +392,8 @@ int pb_voigt_create(pb_voigt **out, const double *lorentz_h, int nlor,
     unsigned g = 0;
     if (rc == PB_OK)
         rc = grid_for(v->npm, &g);
-    if (rc == PB_OK) {
-        if (hipMalloc(&v->d_pm, (size_t)v->npm * sizeof(double)) != hipSuccess) {
-            pb::set_error("pb_voigt_create: cannot allocate %lld B for the table",
-                          (long long)v->npm * 8);
-            rc = PB_ERR_NOMEM;
-        }
-    }
+    if (rc == PB_OK)
+        rc = alloc_pm(v, s);
     if (rc == PB_OK) {
         k_voigt_pm<<<g, kBlock, 0, s>>>(v->d_pm, (const Cell *)v->d_cells, v->d_pm_bases,
                                        v->ncell, v->npm, osamp);
@@ -435,11 +444,11 @@ int pb_voigt_from_flat(pb_voigt **out, const double *profile_h, int64_t nprofile
     if (rc == PB_OK)
         rc = grid_for(v->npm, &g);
     if (rc == PB_OK) {
-        if (hipMalloc(&v->d_flat, (size_t)v->nflat * 8) != hipSuccess ||
-            hipMalloc(&v->d_pm, (size_t)v->npm * 8) != hipSuccess) {
+        if (hipMalloc(&v->d_flat, (size_t)v->nflat * 8) != hipSuccess) {
             pb::set_error("pb_voigt_from_flat: cannot allocate the table");
             rc = PB_ERR_NOMEM;
-        }
+        } else
+            rc = alloc_pm(v, s);
     }
     if (rc == PB_OK) {
         if (hipMemcpyAsync(v->d_flat, profile_h, (size_t)v->nflat * 8, hipMemcpyHostToDevice,
@@ -502,14 +511,14 @@ int64_t pb_voigt_device_bytes(const pb_voigt *v)
 {
     if (!v)
         return 0;
-    return (v->npm + (v->d_flat ? v->nflat : 0)) * 8;
+    return (v->npm + 2 * kPmPad + (v->d_flat ? v->nflat : 0)) * 8;
 }
 
 void pb_voigt_destroy(pb_voigt *v)
 {
     if (!v)
         return;
-    (void)hipFree(v->d_pm);
+    (void)hipFree(v->d_pm_alloc);
     (void)hipFree(v->d_flat);
     (void)hipFree(v->d_cells);
     (void)hipFree(v->d_flat_bases);
