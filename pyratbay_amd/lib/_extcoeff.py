@@ -1,0 +1,113 @@
+"""pyratbay.lib._extcoeff (src_c/_extcoeff.c) on the GPU.
+
+`extinction` keeps the reference's one-layer-per-call signature; the Voigt table and the
+line list are uploaded once and cached on the device between calls (keyed on the
+caller's arrays), so the per-layer loop of pyratbay/pyrat/extinction.py:170-213 does not
+re-upload them."""
+import numpy as np
+import torch
+
+from .. import engine
+from . import _np
+
+_cache = {}
+
+
+def _key(*arrays):
+    out = []
+    for a in arrays:
+        a = np.asarray(a)
+        step = max(1, a.size // 16)
+        out.append((a.__array_interface__['data'][0], a.shape, a.strides,
+                    a.reshape(-1)[::step][:16].tobytes() if a.size else b''))
+    return tuple(out)
+
+
+def _voigt(profile, psize, pindex, lorentz, doppler, osamp):
+    key = ('voigt', osamp) + _key(profile, psize, pindex, lorentz, doppler)
+    if _cache.get('voigt_key') != key:
+        old = _cache.pop('voigt', None)
+        if old is not None:
+            old.close()
+        _cache['voigt'] = engine.VoigtTable.from_flat(
+            _np.f64(profile), _np.read_int(psize), _np.read_int(pindex), _np.f64(lorentz),
+            _np.f64(doppler), osamp, keep_flat=False)
+        _cache['voigt_key'] = key
+        _cache.pop('lbl_key', None)
+    return _cache['voigt']
+
+
+def _lines(lwn, elow, gf, lID, niso, own):
+    key = ('lines', niso) + _key(lwn, elow, gf, lID, own)
+    if _cache.get('lines_key') != key:
+        old = _cache.pop('lines', None)
+        if old is not None:
+            old.close()
+        _cache['lines'] = engine.LineList(_np.f64(lwn), _np.f64(elow), _np.f64(gf),
+                                          _np.read_int(lID), niso, _np.f64(own))
+        _cache['lines_key'] = key
+        _cache.pop('lbl_key', None)
+    return _cache['lines']
+
+
+def extinction(ext, profile, psize, pindex, lorentz, doppler, wn, own, divisors,
+               moldensity, molrad, molmass, isoimol, isomass, isoratio, isoz, isoiext,
+               lwn, elow, gf, lID, cutoff, ethresh, temp, verb, add=0, resolution=0):
+    """extinction(ext, profile, psize, pindex, lorentz, doppler, wn, own, divisors,
+    moldensity, molrad, molmass, isoimol, isomass, isoratio, isoz, isoiext, lwn, elow,
+    gf, lID, cutoff, ethresh, temp, verb[, add, resolution]) -> 1
+
+    Writes ext[nextinct, nwave] in place: assigned in constant-step mode, accumulated in
+    resolution mode (linterp), exactly like _extcoeff.c:320-332."""
+    wn = _np.f64(wn)
+    own = _np.f64(own)
+    div = _np.read_int(divisors)
+    osamp = int(div[-1])
+    niso = len(np.atleast_1d(isomass))
+    voigt = _voigt(profile, psize, pindex, lorentz, doppler, osamp)
+    lines = _lines(lwn, elow, gf, lID, niso, own)
+    iext = _np.read_int(isoiext)
+    key = ('lbl',) + _key(wn, div, molrad, molmass, isoimol, isomass, isoratio) + (
+        float(cutoff), int(bool(resolution)), int(iext.max()))
+    if _cache.get('lbl_key') != key:
+        old = _cache.pop('lbl', None)
+        if old is not None:
+            old.close()
+        _cache['lbl'] = engine.LBL(voigt, lines, wn, div, _np.f64(molrad), _np.f64(molmass),
+                                   _np.read_int(isoimol), _np.f64(isomass),
+                                   _np.f64(isoratio), iext, float(cutoff), float(ethresh),
+                                   resolution=bool(resolution), max_layers=1)
+        _cache['lbl_key'] = key
+    lbl = _cache['lbl']
+    lbl.set_isoiext(iext)
+    lbl.set_ethresh(float(ethresh))
+    rows = 1 if add else lbl.nrows_sep
+    if ext.shape[0] < rows or ext.shape[1] != len(wn):
+        raise ValueError(f'ext has shape {ext.shape}, expected ({rows}, {len(wn)})')
+    out = _np.dev(np.ascontiguousarray(ext[:rows], dtype=np.float64)).reshape(1, rows, len(wn))
+    temp_d = _np.dev(np.array([temp], float))
+    dens_d = _np.dev(_np.f64(moldensity).reshape(1, -1))
+    z_d = _np.dev(_np.f64(isoz).reshape(-1, 1))
+    lbl.extinction(temp_d, dens_d, z_d, add=bool(add), out=out)
+    ext[:rows] = _np.host(out)[0]
+    return 1
+
+
+def _interp(extinction_, etable, ttable, temperatures, density, lay1, lay2, per_mol):
+    ext_d = _np.dev(_np.f64(extinction_))
+    et = _np.dev(_np.f64(etable))
+    engine.interp_ec(ext_d, et, _np.dev(_np.f64(ttable)), _np.dev(_np.f64(temperatures)),
+                     _np.dev(_np.f64(density)), int(lay1), int(lay2), per_mol)
+    extinction_[...] = _np.host(ext_d)
+    return 1
+
+
+def interp_ec(extinction, etable, ttable, temperatures, density, lay1, lay2):
+    """interp_ec(extinction, etable, ttable, temperatures, density, lay1, lay2) -> 1
+    (src_c/_extcoeff.c:367-418); accumulates into extinction[nlayers, nwave]."""
+    return _interp(extinction, etable, ttable, temperatures, density, lay1, lay2, False)
+
+
+def interp_ec_per_mol(extinction, etable, ttable, temperatures, density, lay1, lay2):
+    """Same with extinction[nmol, nlayers, nwave] (src_c/_extcoeff.c:422-472)."""
+    return _interp(extinction, etable, ttable, temperatures, density, lay1, lay2, True)
