@@ -37,13 +37,6 @@ WORKLOADS = {
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 
 
-def shard_bounds(nwave, world):
-    """Contiguous, balanced wavenumber shards (rank r owns [b[r], b[r+1]))."""
-    base, rem = divmod(nwave, world)
-    sizes = [base + (1 if r < rem else 0) for r in range(world)]
-    return np.concatenate([[0], np.cumsum(sizes)]).astype(int)
-
-
 def cpu_baseline(case, voigt, budget_layers=8):
     """Reference CPU path on a bounded sample: `budget_layers` of the layers through the
     unmodified reference _extcoeff.extinction (oracle/_ref; falls back to the oracle's
@@ -122,6 +115,7 @@ def main():
     import torch
     import torch.distributed as dist
     from pyratbay_amd import engine, synth
+    from pyratbay_amd.dist import SpectrumGather
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
@@ -139,24 +133,17 @@ def main():
     case = synth.lbl_case(w['nwave'], w['nlayers'], w['nlines'], wnstep=w['wnstep'],
                           niso=w['niso'], seed=42)
     nwave, nlayers = case['grid']['nwave'], case['atm']['nlayers']
-    bounds = shard_bounds(nwave, world)
-    wbegin, wcount = int(bounds[rank]), int(bounds[rank + 1] - bounds[rank])
+    gather = SpectrumGather(nwave, world, rank, 'cuda')
+    wbegin, wcount = gather.wbegin, gather.wcount
     t0 = time.perf_counter()
     model = engine.LBLSpectrum(case, rt_path='transit', wbegin=wbegin, wcount=wcount)
     torch.cuda.synchronize()
     t_init = time.perf_counter() - t0
 
-    pad = int(np.max(np.diff(bounds)))
-    if world > 1:
-        send = torch.zeros(pad, dtype=torch.float64, device='cuda')
-        recv = torch.zeros(world * pad, dtype=torch.float64, device='cuda')
-
     def step():
-        spec = model.run()
-        if world > 1:
-            send[:wcount].copy_(spec)
-            dist.all_gather_into_tensor(recv, send)
-        return spec
+        # one spectrum: every rank computes its wavenumber shard, then the shards are
+        # re-assembled on every rank (RCCL all-gather over xGMI when world > 1)
+        return gather(model.run())
 
     for _ in range(args.warmup):
         step()

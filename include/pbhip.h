@@ -195,6 +195,21 @@ int pb_simps2D(double *out_d, const double *y_d, int ny, int nwave, const double
 /* cutils.ediff (src_c/cutils.c:27-42) */
 int pb_ediff(double *out_d, const double *arr_d, int n, void *stream);
 
+/* =========================================================================
+ * Band integration (first "next" row after the path):
+ * PassBand.integrate (pyratbay/spectrum/spec_tools.py:193-233) for nbands pass bands:
+ * bandflux_d[b] = sum over the pairs (i,i+1) of band b's contiguous index range
+ * [band_start, band_start+band_count) of 0.5*(wn[i+1]-wn[i])*(y_i+y_{i+1}),
+ * y_i = spectrum[i]*response_b[i-band_start].  Only pairs whose left sample lies in
+ * [wbegin, wbegin+wcount) are summed, so wavenumber shards can be all-reduced;
+ * spectrum_d and wn_d are indexed on the global grid.  The caller applies the band's
+ * `height` (and the wl factor of photon counting through the response).
+ * ========================================================================= */
+int pb_band_integrate(double *bandflux_d, const double *spectrum_d, const double *wn_d,
+                      const int32_t *band_start_d, const int32_t *band_count_d,
+                      const double *response_d, const int64_t *response_offset_d,
+                      int nbands, int64_t wbegin, int64_t wcount, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -58,6 +58,7 @@ _PROTOS = {
     'pb_emission_flux': [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp],
     'pb_simps2D': [vp, vp, i32, i32, vp, vp, vp, vp, vp, vp],
     'pb_ediff': [vp, vp, i32, vp],
+    'pb_band_integrate': [vp, vp, vp, vp, vp, vp, vp, i32, i64, i64, vp],
 }
 _RESTYPES = {'pb_voigt_destroy': None, 'pb_lines_destroy': None, 'pb_lbl_destroy': None,
              'pb_voigt_device_bytes': i64}

@@ -376,6 +376,43 @@ __global__ void k_simps2d(double *out, const double *y, int ny, int nwave,
     out[i] = res;
 }
 
+// ---------------------------------------------------------------------------
+// Band integration (PassBand.integrate, pyratbay/spectrum/spec_tools.py:193-233):
+// trapezoid over wavenumber of spectrum[idx]*response for each band's contiguous
+// index range.  One workgroup per band; only the pairs (i, i+1) whose left sample lies
+// in [wbegin, wbegin+wcount) are summed, so that wavenumber shards add up.  The
+// per-thread partial sums are combined in a fixed order (reproducible).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_band_integrate(
+    double *bandflux, const double *spectrum, const double *wn, const int32_t *band_start,
+    const int32_t *band_count, const double *response, const int64_t *response_offset,
+    int64_t wbegin, int64_t wcount)
+{
+    __shared__ double s_part[kBlock];
+    const int b = blockIdx.x;
+    const int start = band_start[b];
+    const int count = band_count[b];
+    const double *resp = response + response_offset[b];
+    double acc = 0.0;
+    for (int i = threadIdx.x; i + 1 < count; i += kBlock) {
+        const int64_t g = (int64_t)start + i;
+        if (g < wbegin || g >= wbegin + wcount)
+            continue;
+        const double y0 = spectrum[g] * resp[i];
+        const double y1 = spectrum[g + 1] * resp[i + 1];
+        acc += 0.5 * (wn[g + 1] - wn[g]) * (y0 + y1);
+    }
+    s_part[threadIdx.x] = acc;
+    __syncthreads();
+    for (int w = kBlock / 2; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w)
+            s_part[threadIdx.x] += s_part[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0)
+        bandflux[b] = s_part[0];
+}
+
 }  // namespace
 
 // ===========================================================================
@@ -555,6 +592,24 @@ int pb_simps2D(double *out_d, const double *y_d, int ny, int nwave, const double
     PB_REQUIRE(ny < 3 || (h_d && hsum_d && hratio_d && hfactor_d), "pb_simps2D: null h");
     k_simps2d<<<pb::div_up(nwave, kBlock), kBlock, 0, pb::as_stream(stream)>>>(
         out_d, y_d, ny, nwave, h_d, nint_d, hsum_d, hratio_d, hfactor_d);
+    PB_LAUNCH_CHECK();
+    return PB_OK;
+}
+
+int pb_band_integrate(double *bandflux_d, const double *spectrum_d, const double *wn_d,
+                      const int32_t *band_start_d, const int32_t *band_count_d,
+                      const double *response_d, const int64_t *response_offset_d,
+                      int nbands, int64_t wbegin, int64_t wcount, void *stream)
+{
+    PB_REQUIRE(nbands >= 0 && wbegin >= 0 && wcount >= 0, "pb_band_integrate: bad sizes");
+    if (nbands == 0)
+        return PB_OK;
+    PB_REQUIRE(bandflux_d && spectrum_d && wn_d && band_start_d && band_count_d &&
+                   response_d && response_offset_d,
+               "pb_band_integrate: null pointer");
+    k_band_integrate<<<nbands, kBlock, 0, pb::as_stream(stream)>>>(
+        bandflux_d, spectrum_d, wn_d, band_start_d, band_count_d, response_d,
+        response_offset_d, wbegin, wcount);
     PB_LAUNCH_CHECK();
     return PB_OK;
 }

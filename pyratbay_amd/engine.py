@@ -302,6 +302,34 @@ def interp_ec(extinction, etable, ttable, temperatures, density, lay1, lay2, per
     return extinction
 
 
+class PassBands:
+    """A set of pass bands resident on the device (PassBand.set_sampling/integrate,
+    pyratbay/spectrum/spec_tools.py:120-233).  Each band is (start index on the global
+    wavenumber grid, response sampled on wn[start:start+count], height); for photon
+    counting the caller folds the wavelength factor into the response."""
+
+    def __init__(self, wn, bands):
+        self.nbands = len(bands)
+        self.wn = dev(wn)
+        start = np.array([b[0] for b in bands], np.int32)
+        count = np.array([len(b[1]) for b in bands], np.int32)
+        offset = np.concatenate([[0], np.cumsum(count)[:-1]]).astype(np.int64)
+        self.start, self.count = dev(start, torch.int32), dev(count, torch.int32)
+        self.offset = dev(offset, torch.int64)
+        self.response = dev(np.concatenate([np.asarray(b[1], float) for b in bands]))
+        self.heights = dev(np.array([b[2] for b in bands], float))
+        self.partial = torch.zeros(self.nbands, dtype=torch.float64, device='cuda')
+
+    def partial_integrate(self, spectrum_full, wbegin=0, wcount=None):
+        """Un-scaled partial sums over the pairs whose left sample is in the shard."""
+        if wcount is None:
+            wcount = spectrum_full.shape[0] - wbegin
+        call('pb_band_integrate', _ptr(self.partial), _ptr(spectrum_full), _ptr(self.wn),
+             _ptr(self.start), _ptr(self.count), _ptr(self.response), _ptr(self.offset),
+             self.nbands, int(wbegin), int(wcount), _stream())
+        return self.partial
+
+
 # --------------------------------------------------------------------------
 # Whole-path model: the three timed stages of Pyrat.run() (pyrat_obj.py:203-214)
 # --------------------------------------------------------------------------

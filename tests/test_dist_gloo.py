@@ -1,0 +1,103 @@
+"""The N > 1 path on CPU: two gloo ranks shard the wavenumber axis, all-gather the
+spectrum and all-reduce the band fluxes (world_size 2, 127.0.0.1).
+
+The per-shard spectra come from the oracle (test infrastructure) because the HIP kernels
+need a GPU; what is under test is the product's sharding / collective code
+(pyratbay_amd.dist) -- that shards computed on the GLOBAL grid concatenate to exactly the
+single-rank result and that partial band integrals add up."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
+
+
+def _bands(wn):
+    out = []
+    n = len(wn)
+    for lo, hi in ((n // 10, 2 * n // 5), (2 * n // 5 - 3, 9 * n // 10), (0, n)):
+        x = np.linspace(-1, 1, hi - lo)
+        resp = np.exp(-4 * x**2)
+        out.append((lo, resp, 1.0 / np.trapezoid(resp, wn[lo:hi])))
+    return out
+
+
+def _partial_band(spectrum, wn, bands, wbegin, wcount):
+    """NumPy statement of pb_band_integrate's contract (pairs with left sample in shard)."""
+    out = np.zeros(len(bands))
+    for b, (start, resp, _) in enumerate(bands):
+        i = np.arange(len(resp) - 1)
+        g = start + i
+        keep = (g >= wbegin) & (g < wbegin + wcount)
+        y = spectrum[start:start + len(resp)] * resp
+        out[b] = np.sum((0.5 * (wn[g + 1] - wn[g]) * (y[i] + y[i + 1]))[keep])
+    return out
+
+
+def _worker(rank, world, port, nwave, tmp):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from pyratbay_amd import dist as pbd
+    import cases
+    from oracle import oracle as orc
+
+    c = cases.column_case(seed=21, nlayers=12, nwave=nwave)
+    gather = pbd.SpectrumGather(nwave, world, rank, 'cpu')
+    a, n = gather.wbegin, gather.wcount
+    # this rank's columns only, computed on the global grid
+    depth, ideep = orc.optical_depth_transit(c['ec'][:, a:a + n].copy(), c['radius'], 0, 12,
+                                             10.0)
+    local = orc.transmission(depth, c['radius'], c['rstar'], ideep, 0)
+    full = gather(torch.from_numpy(local)).numpy().copy()
+    bands = _bands(c['wn'])
+    partial = torch.from_numpy(_partial_band(full, c['wn'], bands, a, n))
+    heights = torch.tensor([b[2] for b in bands], dtype=torch.float64)
+    bandflux = pbd.allreduce_bandflux(partial, heights).numpy()
+    np.savez(os.path.join(tmp, f'rank{rank}.npz'), full=full, bandflux=bandflux,
+             bounds=gather.bounds)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('nwave', [1001, 64])
+def test_two_rank_shards_reassemble(tmp_path, orc, nwave):
+    import cases
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), nwave, str(tmp_path)), nprocs=world,
+             join=True)
+    c = cases.column_case(seed=21, nlayers=12, nwave=nwave)
+    depth, ideep = orc.optical_depth_transit(c['ec'], c['radius'], 0, 12, 10.0)
+    want = orc.transmission(depth, c['radius'], c['rstar'], ideep, 0)
+    bands = _bands(c['wn'])
+    want_flux = np.array([np.trapezoid(want[s:s + len(r)] * r, c['wn'][s:s + len(r)]) * h
+                          for s, r, h in bands])
+    for rank in range(world):
+        got = np.load(tmp_path / f'rank{rank}.npz')
+        assert np.array_equal(got['full'], want)          # bit-exact re-assembly
+        np.testing.assert_allclose(got['bandflux'], want_flux, rtol=1e-13)
+        assert got['bounds'][0] == 0 and got['bounds'][-1] == nwave
+
+
+def test_shard_bounds_properties():
+    from pyratbay_amd.dist import shard_bounds
+    for nwave in (1, 7, 8, 100001, 1000001):
+        for world in (1, 2, 3, 4, 8):
+            b = shard_bounds(nwave, world)
+            assert b[0] == 0 and b[-1] == nwave and len(b) == world + 1
+            sizes = np.diff(b)
+            assert sizes.min() >= 0 and sizes.max() - sizes.min() <= 1

@@ -1,0 +1,135 @@
+"""Whole hot path on the device (extinction -> optical depth -> spectrum) against the
+oracle driven through the reference's call sequence, transit and emission, plus the
+wavenumber-sharded form and band integration.  Needs an MI355X.
+
+Tolerance: rtol 1e-10 on the spectrum (north_star asks <= 1e-6)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-10
+
+
+@pytest.fixture(scope='module')
+def eng():
+    from pyratbay_amd import engine
+    engine.require_gpu()
+    return engine
+
+
+@pytest.fixture(scope='module')
+def case():
+    from pyratbay_amd import synth
+    return synth.lbl_case(3001, 14, 12000, wnosamp=24, nlor=20, ndop=10, extent=80.0,
+                          cutoff=4.0, niso=2, seed=11)
+
+
+@pytest.fixture(scope='module')
+def oracle_ec(case, orc):
+    g, atm, ln, iso, vg = (case[k] for k in ('grid', 'atm', 'lines', 'iso', 'voigt'))
+    size = vg['size'].copy()
+    index = np.zeros_like(size)
+    profile = np.zeros(np.sum(2 * size + 1))
+    orc.voigt_grid(profile, size, index, vg['lorentz'], vg['doppler'], g['ownstep'])
+    ec = np.zeros((atm['nlayers'], g['nwave']))
+    for layer in range(atm['nlayers']):
+        row = np.zeros((1, g['nwave']))
+        orc.extinction(row, profile, size, index, vg['lorentz'], vg['doppler'], g['wn'],
+                       g['own'], g['divisors'], atm['dens'][layer], atm['mol_radius'],
+                       atm['mol_mass'], iso['isoimol'], iso['isomass'], iso['isoratio'],
+                       iso['isoz'][:, layer].copy(), iso['isoiext'], ln['lwn'], ln['elow'],
+                       ln['gf'], ln['lid'], vg['cutoff'], case['ethresh'],
+                       atm['temp'][layer], 0, 1, 0)
+        ec[layer] = row[0]
+    return ec
+
+
+def test_transit_pipeline(eng, case, orc, oracle_ec):
+    atm = case['atm']
+    model = eng.LBLSpectrum(case, rt_path='transit')
+    spectrum = model.run().cpu().numpy()
+    np.testing.assert_allclose(model.ec.cpu().numpy()[:, 0], oracle_ec, rtol=RTOL)
+    depth, ideep = orc.optical_depth_transit(oracle_ec, atm['radius'], 0, atm['nlayers'],
+                                             case['maxdepth'])
+    assert np.array_equal(model.ideep.cpu().numpy(), ideep)
+    want = orc.transmission(depth, atm['radius'], atm['rstar'], ideep, 0)
+    np.testing.assert_allclose(spectrum, want, rtol=RTOL)
+    # the modulation is there (not a flat, clear-atmosphere spectrum)
+    assert want.max() / want.min() > 1.0005
+
+
+def test_emission_pipeline(eng, case, orc, oracle_ec):
+    g, atm = case['grid'], case['atm']
+    model = eng.LBLSpectrum(case, rt_path='emission')
+    flux = model.run().cpu().numpy()
+    nl, nw = atm['nlayers'], g['nwave']
+    depth = np.zeros((nl, nw))
+    ideep = np.full(nw, nl - 1, np.int32)
+    orc.plane_parallel_optical_depth(depth, ideep, oracle_ec, -orc.ediff(atm['radius']),
+                                     case['maxdepth'], 0, nl)
+    B = orc.blackbody_wn_2D(g['wn'], atm['temp'])
+    mu = model.mu.cpu().numpy()
+    w = model.weights.cpu().numpy()
+    inten = orc.intensity(depth, ideep, B, mu, 0)
+    want = np.sum(inten * w[:, None], axis=0)
+    assert np.array_equal(model.ideep.cpu().numpy(), ideep)
+    np.testing.assert_allclose(flux, want, rtol=RTOL)
+
+
+@pytest.mark.parametrize('world', [2, 3, 8])
+def test_sharded_pipeline_equals_single(eng, case, world):
+    """Each 'rank' computes its shard of the global grid; concatenation is bit-identical
+    to the one-GPU spectrum (no halo exchange needed: SURVEY.md section 8e)."""
+    from pyratbay_amd.dist import shard_bounds
+    single = eng.LBLSpectrum(case, rt_path='transit')
+    want = single.run().cpu().numpy()
+    b = shard_bounds(case['grid']['nwave'], world)
+    parts = []
+    for r in range(world):
+        m = eng.LBLSpectrum(case, rt_path='transit', wbegin=int(b[r]),
+                            wcount=int(b[r + 1] - b[r]), voigt=single.voigt,
+                            lines=single.lines)
+        parts.append(m.run().cpu().numpy())
+    assert np.array_equal(np.concatenate(parts), want)
+
+
+def test_band_integration(eng, case):
+    """PassBand.integrate (spec_tools.py:193-233) on the device, whole and in shards."""
+    import torch
+    from pyratbay_amd.dist import shard_bounds
+    wn = case['grid']['wn']
+    rng = np.random.default_rng(3)
+    spectrum = 0.01 + 1e-4 * rng.uniform(size=len(wn))
+    bands = []
+    for lo, hi in ((10, 700), (650, 2200), (0, len(wn)), (2999, 3001)):
+        x = np.linspace(-1, 1, hi - lo)
+        resp = np.exp(-3 * x**2) * (1e4 / wn[lo:hi])       # photon counting: wl folded in
+        bands.append((lo, resp, 1.0 / np.trapezoid(resp, wn[lo:hi])))
+    want = np.array([np.trapezoid(spectrum[s:s + len(r)] * r, wn[s:s + len(r)]) * h
+                     for s, r, h in bands])
+    pb = eng.PassBands(wn, bands)
+    spec_d = eng.dev(spectrum)
+    got = (pb.partial_integrate(spec_d) * pb.heights).cpu().numpy()
+    np.testing.assert_allclose(got, want, rtol=1e-13)
+    b = shard_bounds(len(wn), 4)
+    total = torch.zeros(len(bands), dtype=torch.float64, device='cuda')
+    for r in range(4):
+        total += pb.partial_integrate(spec_d, int(b[r]), int(b[r + 1] - b[r]))
+    np.testing.assert_allclose((total * pb.heights).cpu().numpy(), want, rtol=1e-13)
+
+
+def test_set_atmosphere_changes_result(eng, case):
+    """eval()-style update of T / densities / partition functions without re-uploading
+    lines or the Voigt table (pyrat_obj.py:258-300)."""
+    from pyratbay_amd import synth
+    model = eng.LBLSpectrum(case, rt_path='transit')
+    base = model.run().cpu().numpy().copy()
+    atm, iso = case['atm'], case['iso']
+    temp = atm['temp'] * 1.1
+    dens = atm['dens'] / 1.1
+    isoz = synth.partition_function(temp)[None, :].repeat(len(iso['isomass']), 0)
+    model.set_atmosphere(temp, dens, isoz)
+    hot = model.run().cpu().numpy()
+    assert np.max(np.abs(hot / base - 1)) > 1e-6
+    model.set_atmosphere(atm['temp'], atm['dens'], iso['isoz'])
+    assert np.array_equal(model.run().cpu().numpy(), base)
