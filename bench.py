@@ -109,7 +109,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--workload', default='c2', choices=sorted(WORKLOADS))
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--cpu-layers', type=int, default=8)
+    ap.add_argument("--cpu-layers", type=int, default=80)
     args = ap.parse_args()
 
     import torch
