@@ -66,6 +66,10 @@ struct LblArgs {
     const int32_t *lid;
     const int32_t *gfirst, *gcount, *giown;
     const int64_t *iso_gstart;
+    // the same groups sorted by (isotope, iown mod osamp, iown) for the staged kernel
+    const int32_t *ph_first, *ph_count, *ph_iown;
+    const int64_t *ph_start;          // [niso*(osamp+1)+1]
+    int rowcap;                       // longest phase row of the table (samples)
     int64_t nlines;
     // static species data
     const double *molrad, *molmass;
@@ -366,7 +370,16 @@ __global__ __launch_bounds__(kBlock) void k_ext_resample(LblArgs a)
                 const int64_t g = gb + threadIdx.x;
                 double k = 0.0;
                 unsigned off = 0, win = 0;
-                if (g < g1) {
+                if (g < g1 && a.experiment == 3) {
+                    const int iown = a.giown[g];
+                    int c = (int)(iown / osamp - t0);
+                    int l3 = max(c - 104, 0), h3 = min(c + 104, (int)(tend - t0));
+                    if (l3 < h3) {
+                        k = 1e-30;
+                        win = (unsigned)l3 | ((unsigned)h3 << 16);
+                        off = (unsigned)(kTile + l3);
+                    }
+                } else if (g < g1) {
                     const int first = a.gfirst[g];
                     const int iown = a.giown[g];
                     k = group_strength(a, first, a.gcount[g], ratio, temp, z);
@@ -401,7 +414,7 @@ __global__ __launch_bounds__(kBlock) void k_ext_resample(LblArgs a)
             }
             __syncthreads();
             // ---- every wavefront walks the records that reach its samples ----
-            const int nrec = (int)min((int64_t)kBlock, g1 - gb);
+            const int nrec = a.experiment == 2 ? 0 : (int)min((int64_t)kBlock, g1 - gb);
             for (int b = 0; b < nrec; b += 64) {
                 const int e = (b + lane) & (kBlock - 1);
                 const unsigned my_win = s_win[e];
@@ -467,6 +480,321 @@ __global__ __launch_bounds__(kBlock) void k_ext_resample(LblArgs a)
             dst[j] = acc[s][0];
         if (j + 1 < rhi)
             dst[j + 1] = acc[s][1];
+    }
+}
+
+// ---------------------------------------------------------------------------
+// 3a'. LDS-staged gather (constant-step grid), for line lists dense enough that several
+// lines of a tile share one phase row of the Voigt table.
+//
+// Groups are visited in (isotope, phase key = iown mod osamp, iown) order.  All records
+// with one (cell, phase, row window) key form a SEGMENT; the phase row is copied once
+// into LDS -- zero outside the window, zero pads of kStagePad samples on both sides --
+// and every record of the segment then adds k * row[j + q] to the samples it reaches
+// with `ds_read_b64` + `v_fma_f64` and NO per-lane predicate: lanes beyond the window
+// read zeros.  Compared with the global gather this moves each table sample through the
+// texture path once per (tile, layer) instead of once per line, reads the operands at
+// the LDS rate and executes ~1 VALU instruction per 64 samples.
+// A lane owns the samples rlo + 64*c + lane (c < 4*G); a wavefront tests a record's
+// window against groups of 4 chunks with scalar compares.
+// ---------------------------------------------------------------------------
+constexpr int kStagePad = 256;       // zero samples on either side of a staged row
+constexpr int kStageSpan = 256;      // samples per wavefront (4 chunks of 64)
+constexpr int kStageRowMax = 1024;   // longest phase row the kernel stages
+
+// Segment [i0, i1) of the current record batch: i1 = next set bit of the boundary masks.
+template <int NW>
+__device__ inline int next_boundary(const unsigned long long *segmask, int i0, int nrec)
+{
+    int w = i0 >> 6;
+    unsigned long long m = segmask[w] & ~((2ull << (i0 & 63)) - 1ull);
+    int i1 = nrec;
+    for (;;) {
+        if (m) {
+            i1 = min(nrec, w * 64 + (int)__builtin_ctzll(m));
+            break;
+        }
+        if (++w >= NW)
+            break;
+        m = segmask[w];
+    }
+    return __builtin_amdgcn_readfirstlane(i1);
+}
+
+// NW wavefronts per workgroup; tile = NW * 256 samples; one record per thread per batch.
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void k_ext_staged(LblArgs a)
+{
+    constexpr int kThreads = NW * 64;
+    constexpr int kT = NW * kStageSpan;           // samples per workgroup
+    constexpr int kRowRegs = (kStageRowMax + kThreads - 1) / kThreads;
+    static_assert(kT < 65536, "window coordinates are packed in 16 bits");
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int osamp = a.osamp;
+    const int rowlen = a.rowcap + 2 * kStagePad;
+    double *s_row = reinterpret_cast<double *>(smem);                    // [2][rowlen]
+    double *s_k = s_row + 2 * rowlen;                                    // [kThreads]
+    unsigned long long *s_segmask =
+        reinterpret_cast<unsigned long long *>(s_k + kThreads);          // [NW]
+    unsigned *s_win = reinterpret_cast<unsigned *>(s_segmask + NW);      // lo | hi << 16
+    int *s_qoff = reinterpret_cast<int *>(s_win + kThreads);
+    int *s_cell = s_qoff + kThreads;                                     // -1 = empty record
+    int *s_phi = s_cell + kThreads;
+    int *s_mlo = s_phi + kThreads;
+    int *s_mhi = s_mlo + kThreads;
+    int *s_part = s_mhi + kThreads;                                      // [NW] scan scratch
+    int *s_cum = s_part + NW;                                            // [osamp+1]
+    int *s_phs = s_cum + (osamp + 1);                                    // [osamp]
+
+    int tile, layer;
+    decode_block(a, tile, layer);
+    if (layer < 0)
+        return;
+    const int row = blockIdx.y;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    const int64_t t0 = a.wbegin + (int64_t)tile * kT;
+    const int64_t tend = min(t0 + kT, a.wbegin + a.wcount);
+    const int rlo = wave * kStageSpan;
+    const int rhi = (int)min((int64_t)rlo + kStageSpan, tend - t0);
+
+    const int ofactor = a.ls_ofactor[layer];
+    const int scale = a.ls_scale[layer];
+    const int64_t dnwn = a.ls_dnwn[layer];
+    const double dwnstep = a.ls_dwnstep[layer];
+    const double temp = a.temp[layer];
+    const double kthresh =
+        a.ethresh * __longlong_as_double((long long)a.kmax_bits[(int64_t)layer * a.nrows + row]);
+
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int i = tid; i < 2 * rowlen; i += kThreads)
+        s_row[i] = 0.0;                            // the pads stay zero for good
+
+    // Row of one segment -> registers (issued early), registers -> LDS (after the walk).
+    double rowreg[kRowRegs];
+    auto load_row = [&](int i0) {
+        const int cell = __builtin_amdgcn_readfirstlane(s_cell[i0]);
+        const int phi = __builtin_amdgcn_readfirstlane(s_phi[i0]);
+        const int mlo = __builtin_amdgcn_readfirstlane(s_mlo[i0]);
+        const int mhi = __builtin_amdgcn_readfirstlane(s_mhi[i0]);
+        const double *src = a.pm + a.pm_base[cell] + (int64_t)phi * a.pm_stride[cell];
+#pragma unroll
+        for (int r = 0; r < kRowRegs; r++) {
+            const int m = tid + r * kThreads;
+            rowreg[r] = (m >= mlo && m < mhi) ? src[m] : 0.0;
+        }
+    };
+    auto store_row = [&](int buf) {
+        double *dst = s_row + buf * rowlen + kStagePad;
+#pragma unroll
+        for (int r = 0; r < kRowRegs; r++) {
+            const int m = tid + r * kThreads;
+            if (m < a.rowcap)
+                dst[m] = rowreg[r];
+        }
+    };
+    // first non-empty segment at or after i0 (nrec if none)
+    auto next_live = [&](int i0, int nrec, int &i1) {
+        while (i0 < nrec) {
+            i1 = next_boundary<NW>(s_segmask, i0, nrec);
+            if (__builtin_amdgcn_readfirstlane(s_cell[i0]) >= 0)
+                return i0;
+            i0 = i1;
+        }
+        i1 = nrec;
+        return nrec;
+    };
+
+    for (int iso = 0; iso < a.niso; iso++) {
+        const int iext = a.isoiext[iso];
+        if (iext < 0 || (a.add ? 0 : iext) != row)
+            continue;
+        const int64_t li = (int64_t)layer * a.niso + iso;
+        const int ilor = a.li_ilor[li];
+        const double alphad = a.li_alphad[li];
+        const double ratio = a.isoratio[iso];
+        const double z = a.li_z[li];
+        const double dens = a.li_dens[li];
+        int64_t reach = a.li_hmax[li];
+        if (a.cutoff > 0.0)
+            reach = min(reach, (int64_t)(a.cutoff / a.ownstep) + 2 * (int64_t)ofactor + 2);
+        reach += osamp + ofactor;
+        const int64_t flo = t0 * osamp - reach, fhi = (tend - 1) * osamp + reach;
+        // bracket of the Doppler index over the fine-grid range the tile can see
+        const double vmin = a.own0 + ((double)max(flo, (int64_t)0) - 1.0) * a.ownstep;
+        const double vmax = a.own0 + ((double)min(fhi, a.onwn - 1) + 1.0) * a.ownstep;
+        const int idop_lo = pb::nearest_index(a.doppler, alphad * vmin, 0, a.ndop - 1);
+        const int idop_hi = pb::nearest_index(a.doppler, alphad * vmax, 0, a.ndop - 1);
+
+        // candidates of every phase key: [s_phs[p], s_phs[p] + count) in the phase list,
+        // then an exclusive scan of the counts (thread t owns a run of `per` phases)
+        __syncthreads();
+        const int per = (osamp + kThreads - 1) / kThreads;
+        int mine = 0;
+        for (int r = 0; r < per; r++) {
+            const int p = tid * per + r;
+            if (p < osamp) {
+                const int64_t seg0 = a.ph_start[(int64_t)iso * (osamp + 1) + p];
+                const int64_t seg1 = a.ph_start[(int64_t)iso * (osamp + 1) + p + 1];
+                const int64_t s0 = lower_bound_i32(a.ph_iown, seg0, seg1, flo);
+                const int64_t s1 = lower_bound_i32(a.ph_iown, seg0, seg1, fhi + 1);
+                s_phs[p] = (int)s0;
+                s_cum[p] = (int)(s1 - s0);
+                mine += (int)(s1 - s0);
+            }
+        }
+        int incl = mine;                           // inclusive scan inside the wavefront
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int up = __shfl_up(incl, d);
+            if (lane >= d)
+                incl += up;
+        }
+        if (lane == 63)
+            s_part[wave] = incl;
+        __syncthreads();
+        int base = 0, total = 0;
+        for (int w = 0; w < NW; w++) {
+            const int pw = s_part[w];
+            if (w < wave)
+                base += pw;
+            total += pw;
+        }
+        int run = base + incl - mine;
+        for (int r = 0; r < per; r++) {
+            const int p = tid * per + r;
+            if (p < osamp) {
+                const int c = s_cum[p];
+                s_cum[p] = run;
+                run += c;
+            }
+        }
+        if (tid == 0)
+            s_cum[osamp] = total;
+        __syncthreads();
+
+        for (int x0 = 0; x0 < total; x0 += kThreads) {
+            const int nrec = min(kThreads, total - x0);
+            __syncthreads();
+            // ---- one record per lane, in (phase, iown) order ----
+            {
+                double k = 0.0;
+                unsigned win = 0;
+                int qoff = 0, cell = -1, phi = 0, mlo = 0, mhi = 0;
+                const int x = x0 + tid;
+                if (x < total) {
+                    int plo = 0, pup = osamp;           // largest p with s_cum[p] <= x
+                    while (pup - plo > 1) {
+                        const int mid = (plo + pup) >> 1;
+                        if (s_cum[mid] <= x)
+                            plo = mid;
+                        else
+                            pup = mid;
+                    }
+                    const int64_t g = (int64_t)s_phs[plo] + (x - s_cum[plo]);
+                    const int first = a.ph_first[g];
+                    const int iown = a.ph_iown[g];
+                    k = group_strength(a, first, a.ph_count[g], ratio, temp, z);
+                    if (!(k < kthresh)) {
+                        if (a.add)
+                            k *= dens;
+                        const Window w = group_window(a, a.lwn[first], iown, ilor, alphad,
+                                                      ofactor, dwnstep, dnwn, idop_lo, idop_hi);
+                        int64_t ulo = (w.minj + scale - 1) / scale;
+                        int64_t uhi = (w.maxj + scale - 1) / scale;
+                        ulo = max(ulo, pb::ceil_div((int64_t)iown - w.half, osamp));
+                        uhi = min(uhi, pb::floor_div((int64_t)iown + w.half, osamp) + 1);
+                        uhi = min(uhi, (int64_t)a.nwave);
+                        const int64_t lo = max(ulo, t0), hi = min(uhi, tend);
+                        if (lo < hi) {
+                            const int64_t f0 = (int64_t)w.half - iown;
+                            const int64_t q = pb::floor_div(f0, osamp);
+                            win = (unsigned)(lo - t0) | ((unsigned)(hi - t0) << 16);
+                            qoff = (int)(q + t0) * 8;   // tile sample j reads row[j + q + t0]
+                            cell = w.cell;
+                            phi = (int)(f0 - q * osamp);
+                            mlo = (int)(ulo + q);
+                            mhi = (int)(uhi + q);
+                        }
+                    }
+                }
+                s_k[tid] = k;
+                s_win[tid] = win;
+                s_qoff[tid] = qoff;
+                s_cell[tid] = cell;
+                s_phi[tid] = phi;
+                s_mlo[tid] = mlo;
+                s_mhi[tid] = mhi;
+            }
+            __syncthreads();
+            // ---- segment starts: the (cell, phase, row window) key changes ----
+            {
+                bool start = tid == 0;
+                if (tid > 0 && tid < nrec)
+                    start = s_cell[tid] != s_cell[tid - 1] || s_phi[tid] != s_phi[tid - 1] ||
+                            s_mlo[tid] != s_mlo[tid - 1] || s_mhi[tid] != s_mhi[tid - 1];
+                const unsigned long long m = __ballot(start && tid < nrec);
+                if (lane == 0)
+                    s_segmask[wave] = m;
+            }
+            __syncthreads();
+            // ---- segments, double-buffered: the next row is loaded into registers before
+            // the current one is walked and written to the other LDS buffer afterwards ----
+            int i1 = 0;
+            int i0 = next_live(0, nrec, i1);
+            int buf = 0;
+            if (i0 < nrec) {
+                load_row(i0);
+                store_row(buf);
+            }
+            __syncthreads();
+            while (i0 < nrec) {
+                int n1 = 0;
+                const int n0 = next_live(i1, nrec, n1);
+                if (n0 < nrec)
+                    load_row(n0);
+                // byte address of this lane's first sample in the staged row
+                const char *rowp = reinterpret_cast<const char *>(
+                    s_row + buf * rowlen + kStagePad + rlo + lane);
+                // The records of a segment have equal window lengths and ascending
+                // positions, so the ones that reach this wavefront are consecutive.
+                for (int b = i0; b < i1; b += 64) {
+                    const int e = b + lane;
+                    const unsigned my_win = e < i1 ? s_win[e] : 0u;
+                    const bool hit = (int)(my_win & 0xffff) < rhi && (int)(my_win >> 16) > rlo;
+                    const unsigned long long mask = __ballot(hit);
+                    if (!mask)
+                        continue;
+                    const int first = b + __builtin_amdgcn_readfirstlane(__builtin_ctzll(mask));
+                    const int last = first + __builtin_amdgcn_readfirstlane(__builtin_popcountll(mask));
+                    for (int r = first; r < last; r++) {
+                        const double k = s_k[r];                         // LDS broadcast
+                        const double *rp = reinterpret_cast<const double *>(rowp + s_qoff[r]);
+                        const double v0 = rp[0], v1 = rp[64], v2 = rp[128], v3 = rp[192];
+                        acc[0] = fma(k, v0, acc[0]);
+                        acc[1] = fma(k, v1, acc[1]);
+                        acc[2] = fma(k, v2, acc[2]);
+                        acc[3] = fma(k, v3, acc[3]);
+                    }
+                }
+                if (n0 < nrec)
+                    store_row(buf ^ 1);
+                __syncthreads();
+                i0 = n0;
+                i1 = n1;
+                buf ^= 1;
+            }
+        }
+    }
+
+    double *dst = a.ext + ((int64_t)layer * a.nrows + row) * a.wcount + (t0 - a.wbegin);
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+        const int j = rlo + c * 64 + lane;
+        if (j < rhi)
+            dst[j] = acc[c];
     }
 }
 
@@ -659,6 +987,11 @@ struct pb_lbl {
     double *ls_dwnstep = nullptr, *li_alphad = nullptr, *li_dens = nullptr, *li_z = nullptr;
     unsigned long long *kmax_bits = nullptr;
     int kmax_rows = 0;
+    // phase-sorted copy of the groups for the LDS-staged kernel
+    int32_t *ph_first = nullptr, *ph_count = nullptr, *ph_iown = nullptr;
+    int64_t *ph_start = nullptr;
+    int rowcap = 0;
+    int gather_mode = 0;     // 0 = choose, 1 = global gather, 2 = LDS-staged
     // optional per-launch timing of the gather kernel (bench.py's roofline figure)
     std::vector<hipEvent_t> ev;      // start/stop pairs
     int ev_used = 0;
@@ -743,7 +1076,10 @@ int pb_lines_create(pb_lines **out, const double *lwn_h, const double *elow_h,
         l->iso_gstart[(size_t)g.iso + 1]++;
     for (int i = 0; i < niso; i++)
         l->iso_gstart[(size_t)i + 1] += l->iso_gstart[(size_t)i];
-    std::vector<int32_t> gfirst(groups.size()), gcount(groups.size()), giown(groups.size());
+    std::vector<int32_t> &gfirst = l->h_gfirst, &gcount = l->h_gcount, &giown = l->h_giown;
+    gfirst.resize(groups.size());
+    gcount.resize(groups.size());
+    giown.resize(groups.size());
     for (size_t k = 0; k < groups.size(); k++) {
         gfirst[k] = groups[k].first;
         gcount[k] = groups[k].count;
@@ -884,6 +1220,52 @@ int pb_lbl_create(pb_lbl **out, pb_voigt *voigt, pb_lines *lines, const double *
     alloc((void **)&p->li_ilor, LI * 4);
     alloc((void **)&p->li_hmax, LI * 4);
     alloc((void **)&p->kmax_bits, L * (size_t)rows * 8);
+    if (rc == PB_OK && !resolution) {
+        // groups re-sorted by (isotope, iown mod osamp, iown): all lines that read the same
+        // phase row of a profile become neighbours (k_ext_staged)
+        const int osamp = voigt->osamp;
+        const size_t ng = lines->h_giown.size();
+        std::vector<int32_t> order(ng);
+        for (size_t k = 0; k < ng; k++)
+            order[k] = (int32_t)k;
+        std::vector<int64_t> start((size_t)niso * (osamp + 1) + 1, 0);
+        for (int i = 0; i < niso; i++) {
+            const int64_t s0 = lines->iso_gstart[i], s1 = lines->iso_gstart[i + 1];
+            std::stable_sort(order.begin() + s0, order.begin() + s1, [&](int32_t x, int32_t y) {
+                return lines->h_giown[x] % osamp < lines->h_giown[y] % osamp;
+            });
+            std::vector<int64_t> cnt((size_t)osamp + 1, 0);
+            for (int64_t k = s0; k < s1; k++)
+                cnt[(size_t)(lines->h_giown[order[k]] % osamp) + 1]++;
+            int64_t run = s0;
+            for (int ph = 0; ph <= osamp; ph++) {
+                run += cnt[ph];
+                start[(size_t)i * (osamp + 1) + ph] = run;
+            }
+        }
+        start[(size_t)niso * (osamp + 1)] = (int64_t)ng;
+        std::vector<int32_t> f(ng), c(ng), w(ng);
+        for (size_t k = 0; k < ng; k++) {
+            f[k] = lines->h_gfirst[order[k]];
+            c[k] = lines->h_gcount[order[k]];
+            w[k] = lines->h_giown[order[k]];
+        }
+        if (rc == PB_OK) rc = upload(&p->ph_first, f.data(), ng);
+        if (rc == PB_OK) rc = upload(&p->ph_count, c.data(), ng);
+        if (rc == PB_OK) rc = upload(&p->ph_iown, w.data(), ng);
+        if (rc == PB_OK) rc = upload(&p->ph_start, start.data(), start.size());
+        int cap = 0;
+        for (int32_t st : voigt->pm_stride)
+            cap = std::max(cap, st);
+        p->rowcap = cap;
+    }
+    {
+        const char *e = getenv("PB_GATHER");
+        if (e && !strcmp(e, "global"))
+            p->gather_mode = 1;
+        else if (e && !strcmp(e, "staged"))
+            p->gather_mode = 2;
+    }
     if (rc != PB_OK) {
         pb_lbl_destroy(p);
         return rc;
@@ -954,6 +1336,11 @@ int pb_lbl_extinction(pb_lbl *p, double *ext_d, int64_t wbegin, int64_t wcount,
     a.giown = l->d_giown;
     a.iso_gstart = l->d_iso_gstart;
     a.nlines = l->nlines;
+    a.ph_first = p->ph_first;
+    a.ph_count = p->ph_count;
+    a.ph_iown = p->ph_iown;
+    a.ph_start = p->ph_start;
+    a.rowcap = p->rowcap;
     a.molrad = p->d_molrad;
     a.molmass = p->d_molmass;
     a.isoimol = p->d_isoimol;
@@ -1017,9 +1404,28 @@ int pb_lbl_extinction(pb_lbl *p, double *ext_d, int64_t wbegin, int64_t wcount,
         dim3 grid((unsigned)(8 * a.ntiles * layer_groups), a.nrows);
         k_ext_linterp<<<grid, kBlock, 0, s>>>(a);
     } else {
-        a.ntiles = pb::div_up(wcount, kTile);
-        dim3 grid((unsigned)(8 * a.ntiles * layer_groups), a.nrows);
-        k_ext_resample<<<grid, kBlock, 0, s>>>(a);
+        // LDS-staged kernel when several groups share a (tile, phase) row; else the
+        // global gather.  The choice depends only on global properties (never on the
+        // shard), so shards and the full grid run the same arithmetic.
+        constexpr int kStagedWaves = 8;
+        constexpr int kStagedThreads = kStagedWaves * 64;
+        const size_t lds_fixed = (size_t)kStagedThreads * 8 + kStagedWaves * 8 +
+                                 (size_t)kStagedThreads * 4 * 6 + kStagedWaves * 4 +
+                                 (size_t)(2 * v->osamp + 1) * 4 + 64;
+        const size_t lds = 2 * ((size_t)a.rowcap + 2 * kStagePad) * 8 + lds_fixed;
+        const double per_phase = (double)l->ngroups / std::max(1, p->nwave) * 2048.0 / v->osamp;
+        const bool can_stage = a.rowcap <= kStageRowMax && lds <= 64 * 1024;
+        bool staged = can_stage && (p->gather_mode == 2 ||
+                                    (p->gather_mode == 0 && per_phase >= 40.0));
+        if (staged) {
+            a.ntiles = pb::div_up(wcount, kStagedWaves * kStageSpan);
+            dim3 grid((unsigned)(8 * a.ntiles * layer_groups), a.nrows);
+            k_ext_staged<kStagedWaves><<<grid, kStagedThreads, lds, s>>>(a);
+        } else {
+            a.ntiles = pb::div_up(wcount, kTile);
+            dim3 grid((unsigned)(8 * a.ntiles * layer_groups), a.nrows);
+            k_ext_resample<<<grid, kBlock, 0, s>>>(a);
+        }
     }
     PB_LAUNCH_CHECK();
     if (timed) {
@@ -1101,6 +1507,10 @@ void pb_lbl_destroy(pb_lbl *p)
     (void)hipFree(p->li_ilor);
     (void)hipFree(p->li_hmax);
     (void)hipFree(p->kmax_bits);
+    (void)hipFree(p->ph_first);
+    (void)hipFree(p->ph_count);
+    (void)hipFree(p->ph_iown);
+    (void)hipFree(p->ph_start);
     for (hipEvent_t e : p->ev)
         (void)hipEventDestroy(e);
     delete p;
