@@ -70,6 +70,14 @@ struct LblArgs {
     const int32_t *ph_first, *ph_count, *ph_iown;
     const int64_t *ph_start;          // [niso*(osamp+1)+1]
     int rowcap;                       // longest phase row of the table (samples)
+    const int32_t *ph_iso;            // isotope of every phase-sorted group
+    int64_t ngroups;
+    // per (layer, phase-sorted group) records written by k_records [nlayers][ngroups]
+    double *rec_k;                    // co-added strength (before threshold / density)
+    int32_t *rec_ulo, *rec_uhi;       // window on the global output grid
+    int32_t *rec_q;                   // row index = output sample + q
+    int32_t *rec_cell, *rec_phi;      // table cell and phase row
+    double inv_osamp;
     int64_t nlines;
     // static species data
     const double *molrad, *molmass;
@@ -484,6 +492,84 @@ __global__ __launch_bounds__(kBlock) void k_ext_resample(LblArgs a)
 }
 
 // ---------------------------------------------------------------------------
+// 2'. Records for the staged gather: everything about a (layer, group) pair that does
+// not depend on the output tile -- co-added strength, table cell and phase row, window on
+// the global grid -- is computed ONCE here (coalesced, no workgroup synchronisation) and
+// streamed by the gather kernel; the per-row maximum strength (k_kmax) is fused in.
+// ---------------------------------------------------------------------------
+// floor(a / d) for |a| < 2^31 and 0 < d < 2^20, with inv = 1.0/d: (a + 0.5)/d is never an
+// integer, so the product cannot round across one.
+__device__ inline int floor_div_inv(int a, double inv)
+{
+    return (int)floor(((double)a + 0.5) * inv);
+}
+
+__global__ __launch_bounds__(kBlock) void k_records(LblArgs a)
+{
+    extern __shared__ unsigned long long s_max[];
+    const int layer = blockIdx.y;
+    const int64_t g = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    for (int r = threadIdx.x; r < a.nrows; r += kBlock)
+        s_max[r] = 0ull;
+    __syncthreads();
+    double k = 0.0, lmax = 0.0;
+    int ulo = 0, uhi = 0, q = 0, cell = 0, phi = 0, row = -1;
+    if (g < a.ngroups) {
+        const int iso = a.ph_iso[g];
+        row = a.isoiext[iso];
+        if (row >= 0 && a.add)
+            row = 0;
+        if (row >= 0) {
+            const int64_t li = (int64_t)layer * a.niso + iso;
+            const double temp = a.temp[layer];
+            const double ratio = a.isoratio[iso];
+            const double z = a.li_z[li];
+            const int first = a.ph_first[g];
+            const int count = a.ph_count[g];
+            const int iown = a.ph_iown[g];
+            k = line_strength(ratio, a.gf[first], a.elow[first], a.lwn[first], temp, z);
+            lmax = k;
+            for (int m = 1; m < count; m++) {
+                const double kp = line_strength(ratio, a.gf[first + m], a.elow[first + m],
+                                                a.lwn[first + m], temp, z);
+                k += kp;
+                lmax = fmax(lmax, kp);
+            }
+            const int ofactor = a.ls_ofactor[layer];
+            const int scale = a.ls_scale[layer];
+            const Window w = group_window(a, a.lwn[first], iown, a.li_ilor[li], a.li_alphad[li],
+                                          ofactor, a.ls_dwnstep[layer], a.ls_dnwn[layer], 0,
+                                          a.ndop - 1);
+            // kept samples: minj <= scale*jo < maxj, inside the profile and the grid
+            const double inv_scale = 1.0 / (double)scale;
+            ulo = -floor_div_inv(-(int)w.minj, inv_scale);
+            uhi = -floor_div_inv(-(int)w.maxj, inv_scale);
+            ulo = max(ulo, -floor_div_inv(w.half - iown, a.inv_osamp));
+            uhi = min(uhi, floor_div_inv(iown + w.half, a.inv_osamp) + 1);
+            uhi = min(uhi, a.nwave);
+            q = floor_div_inv(w.half - iown, a.inv_osamp);
+            phi = (w.half - iown) - q * a.osamp;
+            cell = w.cell;
+            if (uhi < ulo)
+                uhi = ulo;
+        }
+        const int64_t idx = (int64_t)layer * a.ngroups + g;
+        a.rec_k[idx] = k;
+        a.rec_ulo[idx] = ulo;
+        a.rec_uhi[idx] = uhi;
+        a.rec_q[idx] = q;
+        a.rec_cell[idx] = cell;
+        a.rec_phi[idx] = phi;
+    }
+    if (row >= 0)
+        atomicMax(&s_max[row], (unsigned long long)__double_as_longlong(lmax));
+    __syncthreads();
+    for (int r = threadIdx.x; r < a.nrows; r += kBlock)
+        if (s_max[r] != 0ull)
+            atomicMax(&a.kmax_bits[(int64_t)layer * a.nrows + r], s_max[r]);
+}
+
+// ---------------------------------------------------------------------------
 // 3a'. LDS-staged gather (constant-step grid), for line lists dense enough that several
 // lines of a tile share one phase row of the Voigt table.
 //
@@ -499,50 +585,40 @@ __global__ __launch_bounds__(kBlock) void k_ext_resample(LblArgs a)
 // window against groups of 4 chunks with scalar compares.
 // ---------------------------------------------------------------------------
 constexpr int kStagePad = 256;       // zero samples on either side of a staged row
-constexpr int kStageSpan = 256;      // samples per wavefront (4 chunks of 64)
+constexpr int kStageSpan = 256;      // samples per wavefront and sub-tile (4 chunks of 64)
 constexpr int kStageRowMax = 1024;   // longest phase row the kernel stages
 
-// Segment [i0, i1) of the current record batch: i1 = next set bit of the boundary masks.
-template <int NW>
-__device__ inline int next_boundary(const unsigned long long *segmask, int i0, int nrec)
-{
-    int w = i0 >> 6;
-    unsigned long long m = segmask[w] & ~((2ull << (i0 & 63)) - 1ull);
-    int i1 = nrec;
-    for (;;) {
-        if (m) {
-            i1 = min(nrec, w * 64 + (int)__builtin_ctzll(m));
-            break;
-        }
-        if (++w >= NW)
-            break;
-        m = segmask[w];
-    }
-    return __builtin_amdgcn_readfirstlane(i1);
-}
-
-// NW wavefronts per workgroup; tile = NW * 256 samples; one record per thread per batch.
-template <int NW>
+// NW wavefronts per workgroup, S sub-tiles of NW*256 samples each (tile = S*NW*256); one
+// record per thread per batch.
+template <int NW, int S>
 __global__ __launch_bounds__(NW * 64) void k_ext_staged(LblArgs a)
 {
     constexpr int kThreads = NW * 64;
-    constexpr int kT = NW * kStageSpan;           // samples per workgroup
+    constexpr int kSub = NW * kStageSpan;         // samples per sub-tile
+    constexpr int kT = S * kSub;                  // samples per workgroup
     constexpr int kRowRegs = (kStageRowMax + kThreads - 1) / kThreads;
     static_assert(kT < 65536, "window coordinates are packed in 16 bits");
     extern __shared__ __align__(16) unsigned char smem[];
     const int osamp = a.osamp;
-    const int rowlen = a.rowcap + 2 * kStagePad;
-    double *s_row = reinterpret_cast<double *>(smem);                    // [2][rowlen]
-    double *s_k = s_row + 2 * rowlen;                                    // [kThreads]
+    const int rowlen = (a.rowcap + 2 * kStagePad + 1) & ~1;    // even: 16-byte aligned copies
+    // row buffers: [2 buffers][2 copies][rowlen]; copy 1 holds the row shifted by one
+    // sample, so that every record finds its samples 16-byte aligned in one of the two
+    double *s_row = reinterpret_cast<double *>(smem);
+    struct __align__(16) Rec {
+        double k;
+        int qoff;                 // byte offset of tile sample 0 in the right row copy
+        unsigned win;             // lo | hi << 16 (tile coordinates)
+    };
+    Rec *s_rec = reinterpret_cast<Rec *>(s_row + 4 * rowlen);            // [kThreads]
     unsigned long long *s_segmask =
-        reinterpret_cast<unsigned long long *>(s_k + kThreads);          // [NW]
-    unsigned *s_win = reinterpret_cast<unsigned *>(s_segmask + NW);      // lo | hi << 16
-    int *s_qoff = reinterpret_cast<int *>(s_win + kThreads);
-    int *s_cell = s_qoff + kThreads;                                     // -1 = empty record
+        reinterpret_cast<unsigned long long *>(s_rec + kThreads);        // [NW]
+    int *s_cell = reinterpret_cast<int *>(s_segmask + NW);               // -1 = empty record
     int *s_phi = s_cell + kThreads;
     int *s_mlo = s_phi + kThreads;
     int *s_mhi = s_mlo + kThreads;
-    int *s_part = s_mhi + kThreads;                                      // [NW] scan scratch
+    int *s_seg0 = s_mhi + kThreads;                                      // live segments
+    int *s_seg1 = s_seg0 + kThreads;
+    int *s_part = s_seg1 + kThreads;                                     // [NW] scan scratch
     int *s_cum = s_part + NW;                                            // [osamp+1]
     int *s_phs = s_cum + (osamp + 1);                                    // [osamp]
 
@@ -557,19 +633,18 @@ __global__ __launch_bounds__(NW * 64) void k_ext_staged(LblArgs a)
 
     const int64_t t0 = a.wbegin + (int64_t)tile * kT;
     const int64_t tend = min(t0 + kT, a.wbegin + a.wcount);
-    const int rlo = wave * kStageSpan;
-    const int rhi = (int)min((int64_t)rlo + kStageSpan, tend - t0);
+    const int tlen = (int)(tend - t0);
+    const int rlo = wave * kStageSpan;            // first sample of sub-tile 0 (tile coords)
 
-    const int ofactor = a.ls_ofactor[layer];
-    const int scale = a.ls_scale[layer];
-    const int64_t dnwn = a.ls_dnwn[layer];
-    const double dwnstep = a.ls_dwnstep[layer];
-    const double temp = a.temp[layer];
     const double kthresh =
         a.ethresh * __longlong_as_double((long long)a.kmax_bits[(int64_t)layer * a.nrows + row]);
+    const int64_t recbase = (int64_t)layer * a.ngroups;
 
-    double acc[4] = {0.0, 0.0, 0.0, 0.0};
-    for (int i = tid; i < 2 * rowlen; i += kThreads)
+    double acc[S][4];
+#pragma unroll
+    for (int u = 0; u < S; u++)
+        acc[u][0] = acc[u][1] = acc[u][2] = acc[u][3] = 0.0;
+    for (int i = tid; i < 4 * rowlen; i += kThreads)
         s_row[i] = 0.0;                            // the pads stay zero for good
 
     // Row of one segment -> registers (issued early), registers -> LDS (after the walk).
@@ -587,24 +662,15 @@ __global__ __launch_bounds__(NW * 64) void k_ext_staged(LblArgs a)
         }
     };
     auto store_row = [&](int buf) {
-        double *dst = s_row + buf * rowlen + kStagePad;
+        double *dst = s_row + (2 * buf) * rowlen + kStagePad;
 #pragma unroll
         for (int r = 0; r < kRowRegs; r++) {
             const int m = tid + r * kThreads;
-            if (m < a.rowcap)
+            if (m < a.rowcap) {
                 dst[m] = rowreg[r];
+                dst[rowlen + m - 1] = rowreg[r];       // copy 1: shifted by one sample
+            }
         }
-    };
-    // first non-empty segment at or after i0 (nrec if none)
-    auto next_live = [&](int i0, int nrec, int &i1) {
-        while (i0 < nrec) {
-            i1 = next_boundary<NW>(s_segmask, i0, nrec);
-            if (__builtin_amdgcn_readfirstlane(s_cell[i0]) >= 0)
-                return i0;
-            i0 = i1;
-        }
-        i1 = nrec;
-        return nrec;
     };
 
     for (int iso = 0; iso < a.niso; iso++) {
@@ -612,21 +678,12 @@ __global__ __launch_bounds__(NW * 64) void k_ext_staged(LblArgs a)
         if (iext < 0 || (a.add ? 0 : iext) != row)
             continue;
         const int64_t li = (int64_t)layer * a.niso + iso;
-        const int ilor = a.li_ilor[li];
-        const double alphad = a.li_alphad[li];
-        const double ratio = a.isoratio[iso];
-        const double z = a.li_z[li];
         const double dens = a.li_dens[li];
         int64_t reach = a.li_hmax[li];
         if (a.cutoff > 0.0)
-            reach = min(reach, (int64_t)(a.cutoff / a.ownstep) + 2 * (int64_t)ofactor + 2);
-        reach += osamp + ofactor;
+            reach = min(reach, (int64_t)(a.cutoff / a.ownstep) + 2 * (int64_t)a.ls_ofactor[layer] + 2);
+        reach += osamp + a.ls_ofactor[layer];
         const int64_t flo = t0 * osamp - reach, fhi = (tend - 1) * osamp + reach;
-        // bracket of the Doppler index over the fine-grid range the tile can see
-        const double vmin = a.own0 + ((double)max(flo, (int64_t)0) - 1.0) * a.ownstep;
-        const double vmax = a.own0 + ((double)min(fhi, a.onwn - 1) + 1.0) * a.ownstep;
-        const int idop_lo = pb::nearest_index(a.doppler, alphad * vmin, 0, a.ndop - 1);
-        const int idop_hi = pb::nearest_index(a.doppler, alphad * vmax, 0, a.ndop - 1);
 
         // candidates of every phase key: [s_phs[p], s_phs[p] + count) in the phase list,
         // then an exclusive scan of the counts (thread t owns a run of `per` phases)
@@ -678,7 +735,7 @@ __global__ __launch_bounds__(NW * 64) void k_ext_staged(LblArgs a)
         for (int x0 = 0; x0 < total; x0 += kThreads) {
             const int nrec = min(kThreads, total - x0);
             __syncthreads();
-            // ---- one record per lane, in (phase, iown) order ----
+            // ---- one record per lane, in (phase, iown) order, from k_records ----
             {
                 double k = 0.0;
                 unsigned win = 0;
@@ -693,97 +750,156 @@ __global__ __launch_bounds__(NW * 64) void k_ext_staged(LblArgs a)
                         else
                             pup = mid;
                     }
-                    const int64_t g = (int64_t)s_phs[plo] + (x - s_cum[plo]);
-                    const int first = a.ph_first[g];
-                    const int iown = a.ph_iown[g];
-                    k = group_strength(a, first, a.ph_count[g], ratio, temp, z);
-                    if (!(k < kthresh)) {
+                    const int64_t idx = recbase + s_phs[plo] + (x - s_cum[plo]);
+                    k = a.rec_k[idx];
+                    const int ulo = a.rec_ulo[idx], uhi = a.rec_uhi[idx];
+                    const int lo = (int)(max((int64_t)ulo, t0) - t0);
+                    const int hi = (int)(min((int64_t)uhi, tend) - t0);
+                    if (!(k < kthresh) && lo < hi) {
                         if (a.add)
                             k *= dens;
-                        const Window w = group_window(a, a.lwn[first], iown, ilor, alphad,
-                                                      ofactor, dwnstep, dnwn, idop_lo, idop_hi);
-                        int64_t ulo = (w.minj + scale - 1) / scale;
-                        int64_t uhi = (w.maxj + scale - 1) / scale;
-                        ulo = max(ulo, pb::ceil_div((int64_t)iown - w.half, osamp));
-                        uhi = min(uhi, pb::floor_div((int64_t)iown + w.half, osamp) + 1);
-                        uhi = min(uhi, (int64_t)a.nwave);
-                        const int64_t lo = max(ulo, t0), hi = min(uhi, tend);
-                        if (lo < hi) {
-                            const int64_t f0 = (int64_t)w.half - iown;
-                            const int64_t q = pb::floor_div(f0, osamp);
-                            win = (unsigned)(lo - t0) | ((unsigned)(hi - t0) << 16);
-                            qoff = (int)(q + t0) * 8;   // tile sample j reads row[j + q + t0]
-                            cell = w.cell;
-                            phi = (int)(f0 - q * osamp);
-                            mlo = (int)(ulo + q);
-                            mhi = (int)(uhi + q);
-                        }
+                        const int q = a.rec_q[idx];
+                        win = (unsigned)lo | ((unsigned)hi << 16);
+                        // tile sample j reads row[j + q + t0]; a lane reads the pair that
+                        // starts at an even j, so the parity of q + t0 picks the copy
+                        const int qq = (int)(q + t0);
+                        qoff = (qq & 1) ? (qq - 1 + rowlen) * 8 : qq * 8;   // copy1[i] = row[i+1]
+                        cell = a.rec_cell[idx];
+                        phi = a.rec_phi[idx];
+                        mlo = ulo + q;
+                        mhi = uhi + q;
+                    } else {
+                        k = 0.0;
                     }
                 }
-                s_k[tid] = k;
-                s_win[tid] = win;
-                s_qoff[tid] = qoff;
+                s_rec[tid].k = k;
+                s_rec[tid].qoff = qoff;
+                s_rec[tid].win = win;
                 s_cell[tid] = cell;
                 s_phi[tid] = phi;
                 s_mlo[tid] = mlo;
                 s_mhi[tid] = mhi;
             }
             __syncthreads();
-            // ---- segment starts: the (cell, phase, row window) key changes ----
+            // ---- segments: runs of equal (cell, phase, row window); live ones are listed ----
+            bool start = false;
             {
-                bool start = tid == 0;
-                if (tid > 0 && tid < nrec)
-                    start = s_cell[tid] != s_cell[tid - 1] || s_phi[tid] != s_phi[tid - 1] ||
-                            s_mlo[tid] != s_mlo[tid - 1] || s_mhi[tid] != s_mhi[tid - 1];
-                const unsigned long long m = __ballot(start && tid < nrec);
+                if (tid < nrec)
+                    start = tid == 0 || s_cell[tid] != s_cell[tid - 1] ||
+                            s_phi[tid] != s_phi[tid - 1] || s_mlo[tid] != s_mlo[tid - 1] ||
+                            s_mhi[tid] != s_mhi[tid - 1];
+                const unsigned long long m = __ballot(start);
                 if (lane == 0)
                     s_segmask[wave] = m;
             }
+            const bool live = start && s_cell[tid] >= 0;
+            const unsigned long long livemask = __ballot(live);
+            if (lane == 0)
+                s_part[wave] = __builtin_popcountll(livemask);
             __syncthreads();
-            // ---- segments, double-buffered: the next row is loaded into registers before
-            // the current one is walked and written to the other LDS buffer afterwards ----
-            int i1 = 0;
-            int i0 = next_live(0, nrec, i1);
-            int buf = 0;
-            if (i0 < nrec) {
-                load_row(i0);
-                store_row(buf);
+            int nseg = 0;
+            {
+                int before = 0;
+                for (int w = 0; w < NW; w++) {
+                    const int c = s_part[w];
+                    if (w < wave)
+                        before += c;
+                    nseg += c;
+                }
+                if (live) {
+                    // end of my segment = next start after me
+                    int w = tid >> 6;
+                    unsigned long long m = s_segmask[w] & ~((2ull << (tid & 63)) - 1ull);
+                    int end = nrec;
+                    for (;;) {
+                        if (m) {
+                            end = min(nrec, w * 64 + (int)__builtin_ctzll(m));
+                            break;
+                        }
+                        if (++w >= NW)
+                            break;
+                        m = s_segmask[w];
+                    }
+                    const int pos = before + __builtin_popcountll(livemask & ((1ull << lane) - 1ull));
+                    s_seg0[pos] = tid;
+                    s_seg1[pos] = end;
+                }
             }
             __syncthreads();
-            while (i0 < nrec) {
-                int n1 = 0;
-                const int n0 = next_live(i1, nrec, n1);
-                if (n0 < nrec)
-                    load_row(n0);
-                // byte address of this lane's first sample in the staged row
+            if (nseg == 0)
+                continue;
+            // ---- double-buffered rows: the next row is loaded into registers before the
+            // current segment is walked and written to the other LDS buffer afterwards ----
+            int buf = 0;
+            load_row(__builtin_amdgcn_readfirstlane(s_seg0[0]));
+            store_row(0);
+            __syncthreads();
+            if (a.experiment == 5)
+                nseg = 0;
+            for (int sg = 0; sg < nseg; sg++) {
+                const int i0 = __builtin_amdgcn_readfirstlane(s_seg0[sg]);
+                const int i1 = __builtin_amdgcn_readfirstlane(s_seg1[sg]);
+                if (sg + 1 < nseg && a.experiment != 4)
+                    load_row(__builtin_amdgcn_readfirstlane(s_seg0[sg + 1]));
+                // byte address of this lane's first sample pair in copy 0 of the row
                 const char *rowp = reinterpret_cast<const char *>(
-                    s_row + buf * rowlen + kStagePad + rlo + lane);
+                    s_row + (2 * buf) * rowlen + kStagePad + rlo + 2 * lane);
                 // The records of a segment have equal window lengths and ascending
-                // positions, so the ones that reach this wavefront are consecutive.
+                // positions, so the ones that reach a sub-tile range are consecutive.
                 for (int b = i0; b < i1; b += 64) {
                     const int e = b + lane;
-                    const unsigned my_win = e < i1 ? s_win[e] : 0u;
-                    const bool hit = (int)(my_win & 0xffff) < rhi && (int)(my_win >> 16) > rlo;
-                    const unsigned long long mask = __ballot(hit);
-                    if (!mask)
-                        continue;
-                    const int first = b + __builtin_amdgcn_readfirstlane(__builtin_ctzll(mask));
-                    const int last = first + __builtin_amdgcn_readfirstlane(__builtin_popcountll(mask));
-                    for (int r = first; r < last; r++) {
-                        const double k = s_k[r];                         // LDS broadcast
-                        const double *rp = reinterpret_cast<const double *>(rowp + s_qoff[r]);
-                        const double v0 = rp[0], v1 = rp[64], v2 = rp[128], v3 = rp[192];
-                        acc[0] = fma(k, v0, acc[0]);
-                        acc[1] = fma(k, v1, acc[1]);
-                        acc[2] = fma(k, v2, acc[2]);
-                        acc[3] = fma(k, v3, acc[3]);
+                    const unsigned my_win = e < i1 ? s_rec[e].win : 0u;
+                    const int my_lo = (int)(my_win & 0xffff), my_hi = (int)(my_win >> 16);
+#pragma unroll
+                    for (int u = 0; u < S; u++) {
+                        const int ulo_ = rlo + u * kSub;
+                        if (ulo_ >= tlen)
+                            continue;
+                        const unsigned long long mask =
+                            __ballot(my_lo < ulo_ + kStageSpan && my_hi > ulo_);
+                        if (!mask || a.experiment == 2)
+                            continue;
+                        const int first =
+                            b + __builtin_amdgcn_readfirstlane(__builtin_ctzll(mask));
+                        const int last =
+                            first + __builtin_amdgcn_readfirstlane(__builtin_popcountll(mask));
+                        // per record: one 16-byte broadcast read of {k, offset}, two
+                        // aligned 16-byte row reads (2 x 128 samples), four fma
+                        const char *rs = rowp + (size_t)u * kSub * 8;
+                        int r = first;
+                        for (; r + 1 < last; r += 2) {
+                            const Rec r0 = s_rec[r];
+                            const Rec r1 = s_rec[r + 1];
+                            const double2 a0 = *reinterpret_cast<const double2 *>(rs + r0.qoff);
+                            const double2 a1 =
+                                *reinterpret_cast<const double2 *>(rs + r0.qoff + 128 * 8);
+                            const double2 b0 = *reinterpret_cast<const double2 *>(rs + r1.qoff);
+                            const double2 b1 =
+                                *reinterpret_cast<const double2 *>(rs + r1.qoff + 128 * 8);
+                            acc[u][0] = fma(r0.k, a0.x, acc[u][0]);
+                            acc[u][1] = fma(r0.k, a0.y, acc[u][1]);
+                            acc[u][2] = fma(r0.k, a1.x, acc[u][2]);
+                            acc[u][3] = fma(r0.k, a1.y, acc[u][3]);
+                            acc[u][0] = fma(r1.k, b0.x, acc[u][0]);
+                            acc[u][1] = fma(r1.k, b0.y, acc[u][1]);
+                            acc[u][2] = fma(r1.k, b1.x, acc[u][2]);
+                            acc[u][3] = fma(r1.k, b1.y, acc[u][3]);
+                        }
+                        if (r < last) {
+                            const Rec r0 = s_rec[r];
+                            const double2 a0 = *reinterpret_cast<const double2 *>(rs + r0.qoff);
+                            const double2 a1 =
+                                *reinterpret_cast<const double2 *>(rs + r0.qoff + 128 * 8);
+                            acc[u][0] = fma(r0.k, a0.x, acc[u][0]);
+                            acc[u][1] = fma(r0.k, a0.y, acc[u][1]);
+                            acc[u][2] = fma(r0.k, a1.x, acc[u][2]);
+                            acc[u][3] = fma(r0.k, a1.y, acc[u][3]);
+                        }
                     }
                 }
-                if (n0 < nrec)
+                if (sg + 1 < nseg)
                     store_row(buf ^ 1);
                 __syncthreads();
-                i0 = n0;
-                i1 = n1;
                 buf ^= 1;
             }
         }
@@ -791,10 +907,14 @@ __global__ __launch_bounds__(NW * 64) void k_ext_staged(LblArgs a)
 
     double *dst = a.ext + ((int64_t)layer * a.nrows + row) * a.wcount + (t0 - a.wbegin);
 #pragma unroll
-    for (int c = 0; c < 4; c++) {
-        const int j = rlo + c * 64 + lane;
-        if (j < rhi)
-            dst[j] = acc[c];
+    for (int u = 0; u < S; u++) {
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            // acc[u][2h + e] = sample rlo + u*kSub + 128*h + 2*lane + e
+            const int j = rlo + u * kSub + (c >> 1) * 128 + 2 * lane + (c & 1);
+            if (j < tlen)
+                dst[j] = acc[u][c];
+        }
     }
 }
 
@@ -990,8 +1110,12 @@ struct pb_lbl {
     // phase-sorted copy of the groups for the LDS-staged kernel
     int32_t *ph_first = nullptr, *ph_count = nullptr, *ph_iown = nullptr;
     int64_t *ph_start = nullptr;
+    int32_t *ph_iso = nullptr;
+    double *rec_k = nullptr;
+    int32_t *rec_i32 = nullptr;      // 5 arrays of max_layers*ngroups
     int rowcap = 0;
     int gather_mode = 0;     // 0 = choose, 1 = global gather, 2 = LDS-staged
+    double stage_threshold = 40.0;   // groups per (2048-sample tile, phase) to go staged
     // optional per-launch timing of the gather kernel (bench.py's roofline figure)
     std::vector<hipEvent_t> ev;      // start/stop pairs
     int ev_used = 0;
@@ -1254,6 +1378,14 @@ int pb_lbl_create(pb_lbl **out, pb_voigt *voigt, pb_lines *lines, const double *
         if (rc == PB_OK) rc = upload(&p->ph_count, c.data(), ng);
         if (rc == PB_OK) rc = upload(&p->ph_iown, w.data(), ng);
         if (rc == PB_OK) rc = upload(&p->ph_start, start.data(), start.size());
+        {
+            std::vector<int32_t> iso_of(ng);
+            for (int i = 0; i < niso; i++)
+                for (int64_t k = lines->iso_gstart[i]; k < lines->iso_gstart[i + 1]; k++)
+                    iso_of[(size_t)k] = i;
+            if (rc == PB_OK) rc = upload(&p->ph_iso, iso_of.data(), ng);
+        }
+        // per (layer, group) records of k_records: allocated on first use
         int cap = 0;
         for (int32_t st : voigt->pm_stride)
             cap = std::max(cap, st);
@@ -1265,6 +1397,9 @@ int pb_lbl_create(pb_lbl **out, pb_voigt *voigt, pb_lines *lines, const double *
             p->gather_mode = 1;
         else if (e && !strcmp(e, "staged"))
             p->gather_mode = 2;
+        const char *t = getenv("PB_STAGE_THRESHOLD");
+        if (t)
+            p->stage_threshold = atof(t);
     }
     if (rc != PB_OK) {
         pb_lbl_destroy(p);
@@ -1341,6 +1476,9 @@ int pb_lbl_extinction(pb_lbl *p, double *ext_d, int64_t wbegin, int64_t wcount,
     a.ph_iown = p->ph_iown;
     a.ph_start = p->ph_start;
     a.rowcap = p->rowcap;
+    a.ph_iso = p->ph_iso;
+    a.ngroups = l->ngroups;
+    a.inv_osamp = 1.0 / (double)v->osamp;
     a.molrad = p->d_molrad;
     a.molmass = p->d_molmass;
     a.isoimol = p->d_isoimol;
@@ -1387,9 +1525,46 @@ int pb_lbl_extinction(pb_lbl *p, double *ext_d, int64_t wbegin, int64_t wcount,
         a.experiment = e ? atoi(e) : 0;
     }
 
+    // Kernel choice (constant-step grids): the LDS-staged kernel when several groups share
+    // a (tile, phase) row, else the global gather.  The choice depends only on global
+    // properties (never on the shard), so shards and the full grid run the same arithmetic.
+    constexpr int kStagedWaves = 8;
+    constexpr int kStagedThreads = kStagedWaves * 64;
+    const size_t lds_fixed = (size_t)kStagedThreads * 16 + kStagedWaves * 8 +
+                             (size_t)kStagedThreads * 4 * 6 + kStagedWaves * 4 +
+                             (size_t)(2 * v->osamp + 1) * 4 + 64;
+    const size_t rowlen_h = ((size_t)a.rowcap + 2 * kStagePad + 1) & ~(size_t)1;
+    const size_t lds = 4 * rowlen_h * 8 + lds_fixed;
+    const double per_phase = (double)l->ngroups / std::max(1, p->nwave) * 2048.0 / v->osamp;
+    const bool can_stage = !p->resolution && a.rowcap <= kStageRowMax && lds <= 160 * 1024 &&
+                           l->onwn < (1LL << 30) && l->ngroups > 0;
+    const bool staged = can_stage && (p->gather_mode == 2 ||
+                                      (p->gather_mode == 0 && per_phase >= p->stage_threshold));
+    if (staged && !p->rec_k) {
+        const size_t n = (size_t)p->max_layers * (size_t)l->ngroups;
+        if (hipMalloc(&p->rec_k, n * 8) != hipSuccess ||
+            hipMalloc(&p->rec_i32, n * 4 * 5) != hipSuccess) {
+            pb::set_error("pb_lbl_extinction: cannot allocate %zu B of line records", n * 28);
+            return PB_ERR_NOMEM;
+        }
+    }
+    if (staged) {
+        const size_t n = (size_t)p->max_layers * (size_t)l->ngroups;
+        a.rec_k = p->rec_k;
+        a.rec_ulo = p->rec_i32;
+        a.rec_uhi = p->rec_i32 + n;
+        a.rec_q = p->rec_i32 + 2 * n;
+        a.rec_cell = p->rec_i32 + 3 * n;
+        a.rec_phi = p->rec_i32 + 4 * n;
+    }
+
     k_layer_state<<<nlayers, 64, 0, s>>>(a);
     PB_LAUNCH_CHECK();
-    if (l->nlines > 0) {
+    if (staged) {
+        dim3 grid(pb::div_up(l->ngroups, kBlock), nlayers);
+        k_records<<<grid, kBlock, (size_t)a.nrows * 8, s>>>(a);
+        PB_LAUNCH_CHECK();
+    } else if (l->nlines > 0) {
         const int lines_per_block = 4096;
         dim3 grid(pb::div_up(l->nlines, lines_per_block), nlayers);
         k_kmax<<<grid, kBlock, (size_t)a.nrows * 8, s>>>(a, lines_per_block);
@@ -1403,29 +1578,27 @@ int pb_lbl_extinction(pb_lbl *p, double *ext_d, int64_t wbegin, int64_t wcount,
         a.ntiles = pb::div_up(wcount, kBlock);
         dim3 grid((unsigned)(8 * a.ntiles * layer_groups), a.nrows);
         k_ext_linterp<<<grid, kBlock, 0, s>>>(a);
+    } else if (staged) {
+        // sub-tiles per workgroup: as many as keep >= ~1500 workgroups in flight
+        const int64_t sub = kStagedWaves * kStageSpan;
+        int S = 4;
+        while (S > 1 && pb::div_up(wcount, S * sub) * (int64_t)nlayers < 1500)
+            S >>= 1;
+        if (const char *e = getenv("PB_STAGE_S"))
+            S = atoi(e) >= 4 ? 4 : atoi(e) >= 2 ? 2 : 1;
+        a.ntiles = pb::div_up(wcount, S * sub);
+        dim3 grid((unsigned)(8 * a.ntiles * layer_groups), a.nrows);
+        void (*kern)(LblArgs) = S == 4   ? k_ext_staged<kStagedWaves, 4>
+                                : S == 2 ? k_ext_staged<kStagedWaves, 2>
+                                         : k_ext_staged<kStagedWaves, 1>;
+        if (lds > 64 * 1024)
+            PB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        kern<<<grid, kStagedThreads, lds, s>>>(a);
     } else {
-        // LDS-staged kernel when several groups share a (tile, phase) row; else the
-        // global gather.  The choice depends only on global properties (never on the
-        // shard), so shards and the full grid run the same arithmetic.
-        constexpr int kStagedWaves = 8;
-        constexpr int kStagedThreads = kStagedWaves * 64;
-        const size_t lds_fixed = (size_t)kStagedThreads * 8 + kStagedWaves * 8 +
-                                 (size_t)kStagedThreads * 4 * 6 + kStagedWaves * 4 +
-                                 (size_t)(2 * v->osamp + 1) * 4 + 64;
-        const size_t lds = 2 * ((size_t)a.rowcap + 2 * kStagePad) * 8 + lds_fixed;
-        const double per_phase = (double)l->ngroups / std::max(1, p->nwave) * 2048.0 / v->osamp;
-        const bool can_stage = a.rowcap <= kStageRowMax && lds <= 64 * 1024;
-        bool staged = can_stage && (p->gather_mode == 2 ||
-                                    (p->gather_mode == 0 && per_phase >= 40.0));
-        if (staged) {
-            a.ntiles = pb::div_up(wcount, kStagedWaves * kStageSpan);
-            dim3 grid((unsigned)(8 * a.ntiles * layer_groups), a.nrows);
-            k_ext_staged<kStagedWaves><<<grid, kStagedThreads, lds, s>>>(a);
-        } else {
-            a.ntiles = pb::div_up(wcount, kTile);
-            dim3 grid((unsigned)(8 * a.ntiles * layer_groups), a.nrows);
-            k_ext_resample<<<grid, kBlock, 0, s>>>(a);
-        }
+        a.ntiles = pb::div_up(wcount, kTile);
+        dim3 grid((unsigned)(8 * a.ntiles * layer_groups), a.nrows);
+        k_ext_resample<<<grid, kBlock, 0, s>>>(a);
     }
     PB_LAUNCH_CHECK();
     if (timed) {
@@ -1511,6 +1684,9 @@ void pb_lbl_destroy(pb_lbl *p)
     (void)hipFree(p->ph_count);
     (void)hipFree(p->ph_iown);
     (void)hipFree(p->ph_start);
+    (void)hipFree(p->ph_iso);
+    (void)hipFree(p->rec_k);
+    (void)hipFree(p->rec_i32);
     for (hipEvent_t e : p->ev)
         (void)hipEventDestroy(e);
     delete p;
