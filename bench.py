@@ -167,7 +167,8 @@ def main():
     if rank == 0:
         ms_per_step = 1e3 * elapsed / args.steps
         value = args.steps / elapsed
-        # dominant kernel: k_ext_resample.  Algorithmic bytes per launch = the part of
+        # dominant kernel: the extinction gather (k_ext_staged or k_ext_resample, see
+        # roofline.kernel).  Algorithmic bytes per launch = the part of
         # SURVEY 8(d)'s per-spectrum figure that this kernel moves: read the line list
         # once (26 B/line), write ec once (8 B per layer x sample of the shard).
         n_lines = model.lines.nlines
@@ -193,7 +194,8 @@ def main():
                        'voigt_table_bytes': int(model.voigt.device_bytes),
                        'parallelism': f'wavenumber shards x{world}' if world > 1 else 'single GPU',
                        'init_seconds': round(t_init, 3)},
-            'roofline': {'bound': 'hbm', 'kernel': 'k_ext_resample', 'achieved': achieved,
+            'roofline': {'bound': 'hbm', 'kernel': model.lbl.last_gather_kernel,
+                         'achieved': achieved,
                          'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
                          'kernel_ms': kernel_ms, 'kernel_bytes': kernel_bytes,

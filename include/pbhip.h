@@ -102,6 +102,13 @@ int pb_lbl_create(pb_lbl **out, pb_voigt *voigt, pb_lines *lines,
 /* Change the species-selection flags (isoiext < 0 = neglect; extinction.py:164-167) */
 int pb_lbl_set_isoiext(pb_lbl *p, const int32_t *isoiext_h);
 int pb_lbl_set_ethresh(pb_lbl *p, double ethresh);
+/* Gather-kernel selection for constant-step grids: 0 = automatic (LDS-staged kernel when
+ * several lines share a phase row of a tile, else the global gather), 1 = global gather,
+ * 2 = LDS-staged (falls back to 1 when a phase row does not fit in LDS).  Both sum the
+ * same terms; only the order differs (global: isotope, position; staged: isotope, phase,
+ * position).  last_gather_mode reports what the last call ran (3 = resolution mode). */
+int pb_lbl_set_gather_mode(pb_lbl *p, int mode);
+int pb_lbl_last_gather_mode(const pb_lbl *p, int *mode);
 /* ext_d[nlayers, nrows, wcount] with nrows = 1 if add else (max isoiext)+1, for the
  * output samples [wbegin, wbegin+wcount) of the global grid (wavenumber shard).
  * temp_d[nlayers]; dens_d[nlayers, nmol]; isoz_d element (i,l) at

@@ -41,6 +41,8 @@ _PROTOS = {
                       i32, f64, f64, i32, i32],
     'pb_lbl_set_isoiext': [vp, vp],
     'pb_lbl_set_ethresh': [vp, f64],
+    'pb_lbl_set_gather_mode': [vp, i32],
+    'pb_lbl_last_gather_mode': [vp, C.POINTER(i32)],
     'pb_lbl_extinction': [vp, vp, i64, i64, vp, vp, vp, i64, i64, i32, i32, vp],
     'pb_lbl_last_state': [vp, vp, vp, i32, i32, vp],
     'pb_lbl_timing_begin': [vp, i32],

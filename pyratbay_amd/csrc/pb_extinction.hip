@@ -648,8 +648,8 @@ __global__ __launch_bounds__(NW * 64) void k_ext_staged(LblArgs a)
         s_row[i] = 0.0;                            // the pads stay zero for good
 
     // Row of one segment -> registers (issued early), registers -> LDS (after the walk).
-    double rowreg[kRowRegs];
-    auto load_row = [&](int i0) {
+    double rowreg[2][kRowRegs];
+    auto load_row = [&](int i0, double (&reg)[kRowRegs]) {
         const int cell = __builtin_amdgcn_readfirstlane(s_cell[i0]);
         const int phi = __builtin_amdgcn_readfirstlane(s_phi[i0]);
         const int mlo = __builtin_amdgcn_readfirstlane(s_mlo[i0]);
@@ -658,17 +658,17 @@ __global__ __launch_bounds__(NW * 64) void k_ext_staged(LblArgs a)
 #pragma unroll
         for (int r = 0; r < kRowRegs; r++) {
             const int m = tid + r * kThreads;
-            rowreg[r] = (m >= mlo && m < mhi) ? src[m] : 0.0;
+            reg[r] = (m >= mlo && m < mhi) ? src[m] : 0.0;
         }
     };
-    auto store_row = [&](int buf) {
+    auto store_row = [&](int buf, const double (&reg)[kRowRegs]) {
         double *dst = s_row + (2 * buf) * rowlen + kStagePad;
 #pragma unroll
         for (int r = 0; r < kRowRegs; r++) {
             const int m = tid + r * kThreads;
             if (m < a.rowcap) {
-                dst[m] = rowreg[r];
-                dst[rowlen + m - 1] = rowreg[r];       // copy 1: shifted by one sample
+                dst[m] = reg[r];
+                dst[rowlen + m - 1] = reg[r];          // copy 1: shifted by one sample
             }
         }
     };
@@ -828,19 +828,12 @@ __global__ __launch_bounds__(NW * 64) void k_ext_staged(LblArgs a)
             __syncthreads();
             if (nseg == 0)
                 continue;
-            // ---- double-buffered rows: the next row is loaded into registers before the
-            // current segment is walked and written to the other LDS buffer afterwards ----
-            int buf = 0;
-            load_row(__builtin_amdgcn_readfirstlane(s_seg0[0]));
-            store_row(0);
-            __syncthreads();
-            if (a.experiment == 5)
-                nseg = 0;
-            for (int sg = 0; sg < nseg; sg++) {
+            // ---- rows are double-buffered in LDS and fetched two segments ahead: segment
+            // sg+2's row is already in flight (in registers) while sg is walked, and is
+            // written to the free LDS buffer one segment later ----
+            auto walk = [&](int sg, int buf) {
                 const int i0 = __builtin_amdgcn_readfirstlane(s_seg0[sg]);
                 const int i1 = __builtin_amdgcn_readfirstlane(s_seg1[sg]);
-                if (sg + 1 < nseg && a.experiment != 4)
-                    load_row(__builtin_amdgcn_readfirstlane(s_seg0[sg + 1]));
                 // byte address of this lane's first sample pair in copy 0 of the row
                 const char *rowp = reinterpret_cast<const char *>(
                     s_row + (2 * buf) * rowlen + kStagePad + rlo + 2 * lane);
@@ -897,10 +890,33 @@ __global__ __launch_bounds__(NW * 64) void k_ext_staged(LblArgs a)
                         }
                     }
                 }
-                if (sg + 1 < nseg)
-                    store_row(buf ^ 1);
+            };
+            if (a.experiment == 5)
+                nseg = 0;
+            if (nseg > 0) {
+                load_row(__builtin_amdgcn_readfirstlane(s_seg0[0]), rowreg[0]);
+                store_row(0, rowreg[0]);
+                if (nseg > 1)
+                    load_row(__builtin_amdgcn_readfirstlane(s_seg0[1]), rowreg[1]);
                 __syncthreads();
-                buf ^= 1;
+            }
+            for (int sg = 0; sg < nseg; sg += 2) {
+                // even segment: LDS buffer 0; its successor's row waits in rowreg[1]
+                if (sg + 2 < nseg)
+                    load_row(__builtin_amdgcn_readfirstlane(s_seg0[sg + 2]), rowreg[0]);
+                walk(sg, 0);
+                if (sg + 1 < nseg)
+                    store_row(1, rowreg[1]);
+                __syncthreads();
+                if (sg + 1 >= nseg)
+                    break;
+                // odd segment: LDS buffer 1; rowreg[0] holds segment sg+2
+                if (sg + 3 < nseg)
+                    load_row(__builtin_amdgcn_readfirstlane(s_seg0[sg + 3]), rowreg[1]);
+                walk(sg + 1, 1);
+                if (sg + 2 < nseg)
+                    store_row(0, rowreg[0]);
+                __syncthreads();
             }
         }
     }
@@ -1115,7 +1131,8 @@ struct pb_lbl {
     int32_t *rec_i32 = nullptr;      // 5 arrays of max_layers*ngroups
     int rowcap = 0;
     int gather_mode = 0;     // 0 = choose, 1 = global gather, 2 = LDS-staged
-    double stage_threshold = 40.0;   // groups per (2048-sample tile, phase) to go staged
+    int last_gather = 0;     // kernel used by the last call: 1 global, 2 staged, 3 linterp
+    double stage_threshold = 8.0;   // groups per (2048-sample tile, phase) to go staged
     // optional per-launch timing of the gather kernel (bench.py's roofline figure)
     std::vector<hipEvent_t> ev;      // start/stop pairs
     int ev_used = 0;
@@ -1421,6 +1438,20 @@ int pb_lbl_set_isoiext(pb_lbl *p, const int32_t *isoiext_h)
     return PB_OK;
 }
 
+int pb_lbl_set_gather_mode(pb_lbl *p, int mode)
+{
+    PB_REQUIRE(p && mode >= 0 && mode <= 2, "pb_lbl_set_gather_mode: mode must be 0, 1 or 2");
+    p->gather_mode = mode;
+    return PB_OK;
+}
+
+int pb_lbl_last_gather_mode(const pb_lbl *p, int *mode)
+{
+    PB_REQUIRE(p && mode, "pb_lbl_last_gather_mode: null pointer");
+    *mode = p->last_gather;
+    return PB_OK;
+}
+
 int pb_lbl_set_ethresh(pb_lbl *p, double ethresh)
 {
     PB_REQUIRE(p, "pb_lbl_set_ethresh: null handle");
@@ -1574,6 +1605,7 @@ int pb_lbl_extinction(pb_lbl *p, double *ext_d, int64_t wbegin, int64_t wcount,
     const bool timed = p->ev_used + 2 <= (int)p->ev.size();
     if (timed)
         PB_HIP(hipEventRecord(p->ev[p->ev_used], s));
+    p->last_gather = p->resolution ? 3 : staged ? 2 : 1;
     if (p->resolution) {
         a.ntiles = pb::div_up(wcount, kBlock);
         dim3 grid((unsigned)(8 * a.ntiles * layer_groups), a.nrows);

@@ -168,6 +168,18 @@ class LBL:
     def set_ethresh(self, ethresh):
         call('pb_lbl_set_ethresh', self._h, float(ethresh))
 
+    GATHER = {'auto': 0, 'global': 1, 'staged': 2}
+
+    def set_gather_mode(self, mode):
+        """'auto' | 'global' | 'staged' (see pbhip.h: pb_lbl_set_gather_mode)."""
+        call('pb_lbl_set_gather_mode', self._h, self.GATHER[mode])
+
+    @property
+    def last_gather_kernel(self):
+        m = C.c_int(0)
+        call('pb_lbl_last_gather_mode', self._h, C.byref(m))
+        return {0: None, 1: 'k_ext_resample', 2: 'k_ext_staged', 3: 'k_ext_linterp'}[m.value]
+
     def extinction(self, temp, dens, isoz, add=True, out=None, wbegin=0, wcount=None):
         """temp[L], dens[L,nmol], isoz[niso,L] device tensors -> ec[L,rows,wcount]."""
         nlayers = temp.shape[0]

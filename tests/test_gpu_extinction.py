@@ -44,9 +44,9 @@ def build(eng, c, resolution, table_from_oracle, orc, ethresh=1e-30, cutoff=None
     return vt, ll, lbl
 
 
-@pytest.mark.parametrize('mode', ['step', 'res'])
+@pytest.mark.parametrize('mode,gather', [('step', 'global'), ('step', 'staged'), ('res', 'auto')])
 @pytest.mark.parametrize('own_table', [False, True])
-def test_g2_extinction_golden(eng, golden, orc, mode, own_table):
+def test_g2_extinction_golden(eng, golden, orc, mode, own_table, gather):
     g = golden('g2_extinction')
     c = cases.extinction_inputs(resolution=(mode == 'res'))
     atm, iso = c['atm'], c['iso']
@@ -62,6 +62,7 @@ def test_g2_extinction_golden(eng, golden, orc, mode, own_table):
             plans[key] = build(eng, c, mode == 'res', not own_table, orc,
                                cutoff=c['cutoff'] if cut else 0.0)
         vt, ll, lbl = plans[key]
+        lbl.set_gather_mode(gather)
         isoiext = iso['isoiext'].copy()
         if skip:
             isoiext[1] = -1
@@ -75,8 +76,11 @@ def test_g2_extinction_golden(eng, golden, orc, mode, own_table):
         if nz.any():
             worst = max(worst, np.max(np.abs(got[nz] / want[nz] - 1)))
         np.testing.assert_allclose(got, want, rtol=RTOL, err_msg=f'variant {k}')
-    print(f'{mode} own_table={own_table}: max rel err vs reference = {worst:.2e}')
+    print(f'{mode}/{gather} own_table={own_table}: max rel err vs reference = {worst:.2e}')
     assert ll.nadd > 0
+    want_kernel = {'global': 'k_ext_resample', 'staged': 'k_ext_staged',
+                   'auto': 'k_ext_linterp'}[gather]
+    assert lbl.last_gather_kernel == want_kernel
 
 
 def test_groups_match_oracle_counters(eng, orc):
@@ -112,9 +116,10 @@ def test_groups_match_oracle_counters(eng, orc):
     assert np.all(kmax > 0)
 
 
+@pytest.mark.parametrize('gather', ['global', 'staged'])
 @pytest.mark.parametrize('nwave,nlines,niso', [(2, 1, 1), (65, 40, 1), (1025, 3000, 2),
-                                               (4097, 20000, 4)])
-def test_synthetic_cases_vs_oracle(eng, orc, nwave, nlines, niso):
+                                               (4097, 20000, 4), (9001, 60000, 2)])
+def test_synthetic_cases_vs_oracle(eng, orc, nwave, nlines, niso, gather):
     """Ragged grid sizes (tile edges), several isotopes, every layer; own table."""
     from pyratbay_amd import synth
     case = synth.lbl_case(nwave, 6, nlines, wnosamp=24, nlor=18, ndop=9, extent=80.0,
@@ -125,6 +130,7 @@ def test_synthetic_cases_vs_oracle(eng, orc, nwave, nlines, niso):
     lbl = eng.LBL(vt, ll, g['wn'], g['divisors'], atm['mol_radius'], atm['mol_mass'],
                   iso['isoimol'], iso['isomass'], iso['isoratio'], iso['isoiext'],
                   vg['cutoff'], 1e-30, max_layers=6)
+    lbl.set_gather_mode(gather)
     ext = host(lbl.extinction(eng.dev(atm['temp']), eng.dev(atm['dens']),
                               eng.dev(iso['isoz']), add=True))
     profile = vt.flat()
@@ -143,10 +149,11 @@ def test_synthetic_cases_vs_oracle(eng, orc, nwave, nlines, niso):
         if nz.any():
             worst = max(worst, np.max(np.abs(got[nz] / want[nz] - 1)))
         np.testing.assert_allclose(got, want, rtol=RTOL)
-    print(f'W={nwave} N={nlines}: max rel err vs oracle (same table) = {worst:.2e}')
+    print(f'W={nwave} N={nlines} {gather}: max rel err vs oracle (same table) = {worst:.2e}')
 
 
-def test_wavenumber_shards_concatenate(eng, orc):
+@pytest.mark.parametrize('gather', ['global', 'staged'])
+def test_wavenumber_shards_concatenate(eng, orc, gather):
     """Shards [wbegin, wbegin+wcount) of the global grid reproduce the full spectrum
     bit for bit (no exchange between shards)."""
     from pyratbay_amd import synth
@@ -158,6 +165,7 @@ def test_wavenumber_shards_concatenate(eng, orc):
     lbl = eng.LBL(vt, ll, g['wn'], g['divisors'], atm['mol_radius'], atm['mol_mass'],
                   iso['isoimol'], iso['isomass'], iso['isoratio'], iso['isoiext'],
                   vg['cutoff'], 1e-30, max_layers=5)
+    lbl.set_gather_mode(gather)
     t, d, z = eng.dev(atm['temp']), eng.dev(atm['dens']), eng.dev(iso['isoz'])
     full = host(lbl.extinction(t, d, z))
     bounds = [0, 377, 1024, 1025, 2500, 3001]
