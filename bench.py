@@ -33,11 +33,14 @@ WORKLOADS = {
                    label='1e5 wavenumbers x 80 layers, 1e6 synthetic lines, transit'),
     'small': dict(nwave=10001, nlayers=20, nlines=10000, wnstep=0.05, niso=1,
                   label='1e4 wavenumbers x 20 layers, 1e4 synthetic lines, transit'),
+    'c3': dict(nwave=1000001, nlayers=80, nlines=1000000, wnstep=0.005, niso=4,
+               rt_path='emission',
+               label='1e6 wavenumbers x 80 layers, 1e6-line 4-isotope list, emission'),
 }
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 
 
-def cpu_baseline(case, voigt, budget_layers=8):
+def cpu_baseline(case, voigt, budget_layers=8, gpu_ec=None, gpu_spectrum=None):
     """Reference CPU path on a bounded sample: `budget_layers` of the layers through the
     unmodified reference _extcoeff.extinction (oracle/_ref; falls back to the oracle's
     C restatement), extrapolated to all layers, plus the full optical-depth and
@@ -95,7 +98,18 @@ def cpu_baseline(case, voigt, budget_layers=8):
         spec = orc.transmission(depth, atm['radius'], atm['rstar'], ideep, 0)
     t_rest = time.perf_counter() - t0
     seconds = t_ext * nlayers / len(layers) + t_rest
-    return dict(value=1.0 / seconds, unit='spectra/s', cores=1, kind=kind,
+    # full-size parity evidence: the GPU's ec rows (and, when every layer was computed on
+    # the CPU, the final spectrum) against the CPU reference on the same inputs
+    parity = None
+    if gpu_ec is not None:
+        got, want = gpu_ec[layers], ec[layers]
+        nz = want != 0
+        parity = {'ec_max_rel_err': float(np.max(np.abs(got[nz] / want[nz] - 1))),
+                  'ec_zero_pattern_equal': bool(np.array_equal(got == 0, want == 0)),
+                  'layers_compared': int(len(layers))}
+        if gpu_spectrum is not None and len(layers) == nlayers:
+            parity['spectrum_max_rel_err'] = float(np.max(np.abs(gpu_spectrum / spec - 1)))
+    return dict(value=1.0 / seconds, unit='spectra/s', cores=1, kind=kind, parity=parity,
                 sample=(f'{len(layers)} of {nlayers} layers through extinction '
                         f'({t_ext:.2f} s), extrapolated x{nlayers / len(layers):.1f}; full '
                         f'optical depth + transmission ({t_rest:.2f} s); '
@@ -136,7 +150,8 @@ def main():
     gather = SpectrumGather(nwave, world, rank, 'cuda')
     wbegin, wcount = gather.wbegin, gather.wcount
     t0 = time.perf_counter()
-    model = engine.LBLSpectrum(case, rt_path='transit', wbegin=wbegin, wcount=wcount)
+    model = engine.LBLSpectrum(case, rt_path=w.get('rt_path', 'transit'), wbegin=wbegin,
+                               wcount=wcount)
     torch.cuda.synchronize()
     t_init = time.perf_counter() - t0
 
@@ -203,7 +218,9 @@ def main():
                          'path_GBps': path_bytes * value / 1e9},
         }
         if world == 1 and not args.no_cpu_baseline:
-            out['cpu_baseline'] = cpu_baseline(case, model.voigt, args.cpu_layers)
+            out['cpu_baseline'] = cpu_baseline(
+                case, model.voigt, args.cpu_layers, gpu_ec=model.ec.cpu().numpy()[:, 0],
+                gpu_spectrum=model.spectrum.cpu().numpy())
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

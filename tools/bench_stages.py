@@ -12,7 +12,7 @@ steps = int(sys.argv[2]) if len(sys.argv) > 2 else 10
 w = bench.WORKLOADS[name]
 case = synth.lbl_case(w['nwave'], w['nlayers'], w['nlines'], wnstep=w['wnstep'],
                       niso=w['niso'], seed=42)
-model = engine.LBLSpectrum(case, rt_path='transit')
+model = engine.LBLSpectrum(case, rt_path=w.get('rt_path', 'transit'))
 for _ in range(2):
     model.run()
 torch.cuda.synchronize()
