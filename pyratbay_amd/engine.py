@@ -438,3 +438,52 @@ class LBLSpectrum:
         self.extinction()
         self.optical_depth()
         return self.rt()
+
+
+class TableSpectrum:
+    """Retrieval inner loop on sampled cross sections (Line_Sample path,
+    pyratbay/opacity/line_sampling.py:394-463 -> _extcoeff.interp_ec): the table
+    etable[nspec, ntemp, nlayers, nwave] stays resident; each eval() interpolates it to the
+    layer temperatures, weights by the species densities, and runs optical depth + RT."""
+
+    def __init__(self, etable, ttable, wn, radius, rstar, rt_path='transit', itop=0,
+                 maxdepth=10.0, quadrature_mu=None, quadrature_weights=None):
+        require_gpu()
+        self.etable = etable if isinstance(etable, torch.Tensor) else dev(etable)
+        self.nspec, self.ntemp, self.nlayers, self.nwave = self.etable.shape
+        self.ttable = dev(ttable)
+        self.tmin, self.tmax = float(np.min(ttable)), float(np.max(ttable))
+        self.wn = dev(wn)
+        self.rt_path, self.itop, self.maxdepth = rt_path, itop, maxdepth
+        self.rstar = float(rstar)
+        self.set_radius(radius)
+        if rt_path != 'transit':
+            self.mu = dev(quadrature_mu)
+            self.weights = dev(quadrature_weights)
+        self.ec = torch.zeros((self.nlayers, self.nwave), dtype=torch.float64, device='cuda')
+
+    def set_radius(self, radius):
+        self.radius = dev(radius)
+        if self.rt_path == 'transit':
+            self.raypath = dev(pack_raypath(transit_path(radius, self.itop), self.itop))
+        else:
+            self.intervals = dev(-np.diff(np.asarray(radius, float)))
+
+    def eval(self, temp, dens):
+        """temp[L] (K, inside the table's range -- the caller rejects the rest like
+        line_sampling.py:426-427), dens[L, nspec] (molecules cm-3) -> spectrum[W]."""
+        self.temp = temp if isinstance(temp, torch.Tensor) else dev(temp)
+        dens = dens if isinstance(dens, torch.Tensor) else dev(dens)
+        self.ec.zero_()
+        interp_ec(self.ec, self.etable, self.ttable, self.temp, dens, 0, self.nlayers)
+        if self.rt_path == 'transit':
+            self.depth, self.ideep = optical_depth_transit(
+                self.ec, self.raypath, self.itop, self.nlayers, self.maxdepth)
+            self.spectrum = transmission(self.depth, self.ideep, self.radius, self.itop,
+                                         self.rstar)
+        else:
+            self.depth, self.ideep = plane_parallel_optical_depth(
+                self.ec, self.intervals, self.itop, self.nlayers, self.maxdepth)
+            self.spectrum = emission_flux(self.depth, self.ideep, self.wn, self.temp, self.mu,
+                                          self.weights, self.itop)
+        return self.spectrum

@@ -1,0 +1,140 @@
+"""TLI (transition line information) files: the reference's binary line-list format.
+
+Writer layout: pyratbay/opacity/lread.py:277-314; reader semantics:
+pyratbay/pyrat/line_by_line.py:298-482 (+ Database header :485-540).  Native endianness,
+version 6.5.0:
+
+    1s endian ('l'|'b') . 3h version . 2d wn_min wn_max . h n_databases
+    per database: h+name . h+molecule . hh ntemp niso . ntemp d temperatures
+                  per isotope: h+name . d mass . d ratio . ntemp d partition function
+    i n_lines . i n_iso_total . n_iso_total i lines-per-isotope
+    four contiguous column blocks over all lines, sorted by (isotope, wavenumber):
+        n_lines d wavenumber . n_lines h isotope index . n_lines d Elow . n_lines d gf
+
+The four column blocks are read with one `np.fromfile` each per isotope range, which is
+also the layout the device wants (SoA), so ingestion is a straight copy.
+"""
+import struct
+import sys
+
+import numpy as np
+
+VERSION = (6, 5, 0)
+
+
+def _pack_str(f, s):
+    b = s.encode('utf-8')
+    f.write(struct.pack(f'h{len(b)}s', len(b), b))
+
+
+def _read_str(f):
+    n, = struct.unpack('h', f.read(2))
+    return f.read(n).decode('utf-8')
+
+
+def write_tli(path, databases, wn_min=None, wn_max=None):
+    """databases: list of dicts with keys name, molecule, temperatures[ntemp],
+    isotopes (names), iso_mass, iso_ratio, partition[niso, ntemp], and the line arrays
+    wn, iso_id (index into the concatenated isotope list), elow, gf sorted by
+    (isotope, wavenumber) within the database."""
+    all_wn = np.concatenate([np.asarray(d['wn'], float) for d in databases])
+    wn_min = float(all_wn.min()) if wn_min is None else wn_min
+    wn_max = float(all_wn.max()) if wn_max is None else wn_max
+    with open(path, 'wb') as f:
+        f.write(struct.pack('s', sys.byteorder[0].encode()))
+        f.write(struct.pack('3h', *VERSION))
+        f.write(struct.pack('2d', wn_min, wn_max))
+        f.write(struct.pack('h', len(databases)))
+        n_iso_lines = []
+        iso_offset = 0
+        for d in databases:
+            _pack_str(f, d['name'])
+            _pack_str(f, d['molecule'])
+            temps = np.asarray(d['temperatures'], float)
+            niso = len(d['isotopes'])
+            f.write(struct.pack('hh', len(temps), niso))
+            f.write(temps.tobytes())
+            pf = np.asarray(d['partition'], float)
+            for j in range(niso):
+                _pack_str(f, str(d['isotopes'][j]))
+                f.write(struct.pack('d', float(d['iso_mass'][j])))
+                f.write(struct.pack('d', float(d['iso_ratio'][j])))
+                f.write(pf[j].tobytes())
+            ids = np.asarray(d['iso_id'])
+            for j in range(niso):
+                n_iso_lines.append(int(np.sum(ids == iso_offset + j)))
+            iso_offset += niso
+        f.write(struct.pack('i', len(all_wn)))
+        f.write(struct.pack('i', len(n_iso_lines)))
+        f.write(np.asarray(n_iso_lines, np.int32).tobytes())
+        f.write(all_wn.tobytes())
+        f.write(np.concatenate([np.asarray(d['iso_id'], np.int16) for d in databases]).tobytes())
+        f.write(np.concatenate([np.asarray(d['elow'], float) for d in databases]).tobytes())
+        f.write(np.concatenate([np.asarray(d['gf'], float) for d in databases]).tobytes())
+
+
+def read_tli(path, wn_low=-np.inf, wn_high=np.inf):
+    """Returns (databases, wn, gf, elow, iso_id) restricted per isotope to
+    wn_low <= wn <= wn_high, like read_tli_file (line_by_line.py:298-482)."""
+    with open(path, 'rb') as f:
+        endian = f.read(1).decode()
+        if endian != sys.byteorder[0]:
+            raise ValueError(f'Incompatible endianness between TLI file ({endian}) and '
+                             f'this machine ({sys.byteorder[0]})')
+        ver = struct.unpack('3h', f.read(6))
+        if ver[0] != 6 or ver[1] not in (1, 2, 3, 4, 5):
+            raise ValueError('Incompatible TLI version.  The TLI file must be created '
+                             'with Lineread version 6.1-6.5.')
+        file_wn_min, file_wn_max = struct.unpack('2d', f.read(16))
+        ndb, = struct.unpack('h', f.read(2))
+        databases = []
+        for _ in range(ndb):
+            name = _read_str(f)
+            molecule = _read_str(f)
+            ntemp, niso = struct.unpack('hh', f.read(4))
+            temps = np.frombuffer(f.read(8 * ntemp), float).copy()
+            isotopes, mass, ratio, pf = [], [], [], []
+            for _ in range(niso):
+                isotopes.append(_read_str(f))
+                m, r = struct.unpack('2d', f.read(16))
+                mass.append(m)
+                ratio.append(r)
+                pf.append(np.frombuffer(f.read(8 * ntemp), float).copy())
+            databases.append(dict(name=name, molecule=molecule, temperatures=temps,
+                                  isotopes=isotopes, iso_mass=np.array(mass),
+                                  iso_ratio=np.array(ratio), partition=np.array(pf)))
+        n_lines, = struct.unpack('i', f.read(4))
+        n_iso, = struct.unpack('i', f.read(4))
+        per_iso = np.frombuffer(f.read(4 * n_iso), np.int32).copy()
+        start = f.tell()
+        f.seek(0, 2)
+        if (f.tell() - start) != n_lines * 26:
+            raise ValueError('The remaining data file size does not correspond to the '
+                             f'number of transitions ({n_lines})')
+    off_wn = start
+    off_iso = off_wn + 8 * n_lines
+    off_el = off_iso + 2 * n_lines
+    off_gf = off_el + 8 * n_lines
+    wn_all = np.memmap(path, np.float64, 'r', off_wn, (n_lines,))
+    pieces = []
+    lo = 0
+    for n in per_iso:
+        seg = wn_all[lo:lo + n]
+        a = lo + int(np.searchsorted(seg, wn_low, 'left'))
+        b = lo + int(np.searchsorted(seg, wn_high, 'right'))
+        if b > a:
+            pieces.append((a, b))
+        lo += int(n)
+
+    def gather(offset, dtype):
+        col = np.memmap(path, dtype, 'r', offset, (n_lines,))
+        if not pieces:
+            return np.zeros(0, dtype)
+        return np.concatenate([np.asarray(col[a:b]) for a, b in pieces])
+
+    wn = gather(off_wn, np.float64)
+    iso_id = gather(off_iso, np.int16)
+    elow = gather(off_el, np.float64)
+    gf = gather(off_gf, np.float64)
+    meta = dict(wn_min=file_wn_min, wn_max=file_wn_max, version=ver, n_lines=n_lines)
+    return databases, wn, gf, elow, iso_id, meta
