@@ -160,6 +160,14 @@ int pb_optdepth(double *tau_d, const double *data_d, int64_t row_stride,
 int pb_optical_depth_transit(double *depth_d, int32_t *ideep_d, const double *ec_d,
                              const double *raypath_d, int itop, int ibottom,
                              double maxdepth, int nlayers, int nwave, void *stream);
+/* Same loop fused with radiative_transfer.transmission (no cloud deck,
+ * pyratbay/spectrum/radiative_transfer.py:57-71): depth_d and ideep_d as above, plus
+ * spectrum_d[nwave] = (r_top^2 + 2*integral)/rstar^2 computed in the pass that resolves
+ * the early exit. */
+int pb_transit_spectrum(double *spectrum_d, double *depth_d, int32_t *ideep_d,
+                        const double *ec_d, const double *raypath_d, const double *radius_d,
+                        double rstar, int itop, int ibottom, double maxdepth, int nlayers,
+                        int nwave, void *stream);
 /* _trapezoid.plane_parallel_optical_depth (src_c/_trapezoid.c:175-213); rows below
  * the stopping layer are left as passed in, like the reference. */
 int pb_plane_parallel_optical_depth(double *depth_d, int32_t *ideep_d,

@@ -51,6 +51,7 @@ _PROTOS = {
     'pb_interp_ec': [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp],
     'pb_optdepth': [vp, vp, i64, vp, i32, f64, vp, i32, i32, vp],
     'pb_optical_depth_transit': [vp, vp, vp, vp, i32, i32, f64, i32, i32, vp],
+    'pb_transit_spectrum': [vp, vp, vp, vp, vp, vp, f64, i32, i32, f64, i32, i32, vp],
     'pb_plane_parallel_optical_depth': [vp, vp, vp, vp, f64, i32, i32, i32, i32, vp],
     'pb_trapezoid2D': [vp, vp, vp, vp, i32, i32, vp],
     'pb_transmission': [vp, vp, vp, vp, i32, f64, i32, i32, vp],

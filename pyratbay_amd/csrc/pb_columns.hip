@@ -50,75 +50,116 @@ __global__ void k_optdepth(double *tau, const double *data, int64_t row_stride,
 }
 
 // ---------------------------------------------------------------------------
-// Transit optical depth for all impact parameters (optic_depth.py:103-112).
-// One workgroup = 64 columns x 4 waves.  The ec tile [nlayers][64] and the packed
-// ray-path triangle are staged in LDS; wave q computes rows itop+q, itop+q+4, ...
-// (row r costs r-itop FMAs, so the interleave balances the waves).  The per-column
-// first crossing of maxdepth is an LDS min; rows below it are then zeroed, which
-// reproduces the sequential early exit of the reference.
+// Transit optical depth for all impact parameters (optic_depth.py:103-112), two kernels.
+//
+// k_transit_tau: thread = (column, block of kRowsPerThread impact parameters).  The
+// column of ec is streamed once per row block (coalesced over columns, served by L2 after
+// the first block), the kRowsPerThread running sums stay in registers and the ray-path
+// segments are wave-uniform scalar loads.  tau_r = sum_{i<r} path_r[i]*(ec[i+1]+ec[i])
+// is accumulated in the reference's order (same products, same additions), for EVERY row.
+//
+// k_transit_finish: thread = column.  Walks the rows once: finds the first crossing of
+// maxdepth (the reference's early exit), zeroes the rows below it, writes ideep
+// (including the final `ideep[ideep<0] = r`) and, when asked, integrates the
+// transmission spectrum exp(-tau)*r over the rows down to ideep
+// (radiative_transfer.py:57-71) in the same pass.
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(kBlock) void k_transit_depth(
-    double *depth, int32_t *ideep, const double *ec, const double *raypath, int itop,
-    int ibottom, double maxdepth, int nlayers, int nwave)
+constexpr int kRowsPerThread = 16;
+
+__global__ __launch_bounds__(kBlock) void k_transit_tau(double *depth, const double *ec,
+                                                        const double *raypath, int itop,
+                                                        int ibottom, int nlayers, int nwave)
 {
-    extern __shared__ __align__(16) unsigned char smem[];
-    const int nrow = nlayers - itop;            // rows held in LDS (layers itop..L-1)
-    double *s_ec = reinterpret_cast<double *>(smem);            // [nrow][64]
-    double *s_path = s_ec + (size_t)nrow * 64;                  // packed triangle
-    int *s_first = reinterpret_cast<int *>(s_path + (size_t)nrow * (nrow - 1) / 2);  // [64]
-
-    const int lane = threadIdx.x & 63;
-    const int q = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int col = blockIdx.x * 64 + lane;
-    const bool live = col < nwave;
-    const int ntri = nrow * (nrow - 1) / 2;
-
-    for (int r = q; r < nrow; r += 4)
-        s_ec[r * 64 + lane] = live ? ec[(int64_t)(itop + r) * nwave + col] : 0.0;
-    for (int i = threadIdx.x; i < ntri; i += kBlock)
-        s_path[i] = raypath[i];
-    if (threadIdx.x < 64)
-        s_first[threadIdx.x] = 0x7fffffff;
+    // ray-path segments of this block's rows, [segment i][row k], zero where i >= r:
+    // adding 0 * s leaves a sum unchanged, so one predicate-free loop serves all rows
+    extern __shared__ __align__(16) double s_path[];
+    const int col = blockIdx.x * kBlock + threadIdx.x;
+    const int nrow = nlayers - itop;
+    const int nimpact = min(ibottom, nlayers) - itop;     // rows 0..nimpact-1 are evaluated
+    const int rb = blockIdx.y * kRowsPerThread;
+    const int rlast = min(rb + kRowsPerThread, nimpact) - 1;       // last evaluated row here
+    const int nseg = max(rlast, 0);                                 // segments i < rlast
+    for (int e = threadIdx.x; e < nseg * kRowsPerThread; e += kBlock) {
+        const int i = e / kRowsPerThread, k = e % kRowsPerThread;
+        const int r = rb + k;
+        s_path[e] = (r <= rlast && i < r) ? raypath[(r * (r - 1)) / 2 + i] : 0.0;
+    }
     __syncthreads();
-
-    const int nimpact = ibottom - itop;         // rows itop..ibottom-1 are evaluated
-    // pass 1: tau for every evaluated row, remember the first crossing
-    int first = 0x7fffffff;
-    for (int r = q; r < nrow; r += 4) {
-        double acc = 0.0;
-        if (r < nimpact) {
-            const double *path = s_path + (r * (r - 1)) / 2;
-            double prev = s_ec[lane];
-            for (int i = 0; i < r; i++) {
-                double next = s_ec[(i + 1) * 64 + lane];
-                acc += path[i] * (next + prev);
-                prev = next;
-            }
-            if (acc > maxdepth && r < first)
-                first = r;
+    if (col >= nwave)
+        return;
+    double tau[kRowsPerThread];
+#pragma unroll
+    for (int k = 0; k < kRowsPerThread; k++)
+        tau[k] = 0.0;
+    if (nseg > 0) {
+        const double *src = ec + (int64_t)itop * nwave + col;
+        double prev = src[0];
+#pragma unroll 4
+        for (int i = 0; i < nseg; i++) {
+            const double next = src[(int64_t)(i + 1) * nwave];
+            const double s = next + prev;
+            prev = next;
+            const double *pk = s_path + i * kRowsPerThread;          // LDS broadcast reads
+#pragma unroll
+            for (int k = 0; k < kRowsPerThread; k++)
+                tau[k] += pk[k] * s;
         }
-        if (live)
-            depth[(int64_t)(itop + r) * nwave + col] = acc;
     }
-    if (first != 0x7fffffff)
-        atomicMin(&s_first[lane], first);
-    // rows above itop are never touched by the reference loop (depth starts at zero)
-    for (int r = q; r < itop; r += 4)
-        if (live)
+#pragma unroll
+    for (int k = 0; k < kRowsPerThread; k++) {
+        const int r = rb + k;
+        if (r < nrow)
+            depth[(int64_t)(itop + r) * nwave + col] = tau[k];     // 0 for r >= nimpact
+    }
+    if (blockIdx.y == 0)
+        for (int r = 0; r < itop; r++)
             depth[(int64_t)r * nwave + col] = 0.0;
-    __syncthreads();
+}
 
-    // pass 2: rows below the first crossing stay zero in the reference
-    const int stop = s_first[lane];
-    if (stop != 0x7fffffff) {
-        for (int r = q; r < nimpact; r += 4)
-            if (r > stop && live)
-                depth[(int64_t)(itop + r) * nwave + col] = 0.0;
+__global__ __launch_bounds__(kBlock) void k_transit_finish(
+    double *depth, int32_t *ideep, double *spectrum, const double *radius, double rstar,
+    int itop, int ibottom, double maxdepth, int nlayers, int nwave)
+{
+    const int col = blockIdx.x * kBlock + threadIdx.x;
+    if (col >= nwave)
+        return;
+    const int nimpact = min(ibottom, nlayers) - itop;
+    int stop = -1;
+    double acc = 0.0, fprev = 0.0, rprev = 0.0;
+    // rows are fetched eight at a time (independent loads in flight), then examined in order
+    constexpr int kFetch = 8;
+    for (int r0 = 0; r0 < nimpact; r0 += kFetch) {
+        double t[kFetch];
+#pragma unroll
+        for (int k = 0; k < kFetch; k++)
+            t[k] = (r0 + k < nimpact) ? depth[(int64_t)(itop + r0 + k) * nwave + col] : 0.0;
+#pragma unroll
+        for (int k = 0; k < kFetch; k++) {
+            const int r = r0 + k;
+            if (r >= nimpact)
+                break;
+            if (stop < 0) {
+                if (spectrum) {
+                    const double rad = radius[itop + r];
+                    const double f = exp(-t[k]) * rad;
+                    if (r > 0)
+                        acc += (rad - rprev) * (fprev + f);
+                    fprev = f;
+                    rprev = rad;
+                }
+                if (t[k] > maxdepth)
+                    stop = r;
+            } else if (t[k] != 0.0) {
+                depth[(int64_t)(itop + r) * nwave + col] = 0.0;   // below the first crossing
+            }
+        }
     }
-    if (q == 0 && live) {
-        // ideep[ideep<0] = r with r the last loop value (itop if the loop is empty)
-        int last = nimpact > 0 ? ibottom - 1 : itop;
-        ideep[col] = stop != 0x7fffffff ? itop + stop : last;
+    // ideep[ideep<0] = r with r the last loop value (itop if the loop is empty)
+    const int last = nimpact > 0 ? itop + nimpact - 1 : itop;
+    ideep[col] = stop >= 0 ? itop + stop : last;
+    if (spectrum) {
+        const double rtop = radius[itop];
+        spectrum[col] = (rtop * rtop + 2 * (acc * 0.5)) / (rstar * rstar);
     }
 }
 
@@ -447,30 +488,53 @@ int pb_optdepth(double *tau_d, const double *data_d, int64_t row_stride,
     return PB_OK;
 }
 
+static int transit_launch(double *depth_d, int32_t *ideep_d, double *spectrum_d,
+                          const double *ec_d, const double *raypath_d, const double *radius_d,
+                          double rstar, int itop, int ibottom, double maxdepth, int nlayers,
+                          int nwave, void *stream, const char *who)
+{
+    PB_REQUIRE(nlayers > 0 && nwave >= 0, "%s: bad shape", who);
+    PB_REQUIRE(itop >= 0 && itop < nlayers, "%s: itop out of range", who);
+    PB_REQUIRE(ibottom <= nlayers, "%s: ibottom > nlayers", who);
+    if (nwave == 0)
+        return PB_OK;
+    PB_REQUIRE(depth_d && ideep_d && ec_d, "%s: null pointer", who);
+    const int nrow = nlayers - itop;
+    PB_REQUIRE(nrow == 1 || raypath_d, "%s: null raypath", who);
+    PB_REQUIRE(!spectrum_d || radius_d, "%s: null radius", who);
+    dim3 grid(pb::div_up(nwave, kBlock), pb::div_up(nrow, kRowsPerThread));
+    const size_t lds = (size_t)nrow * kRowsPerThread * sizeof(double);
+    if (lds > 64 * 1024) {
+        pb::set_error("%s: %d layers need %zu B of LDS", who, nrow, lds);
+        return PB_ERR_UNSUPPORTED;
+    }
+    k_transit_tau<<<grid, kBlock, lds, pb::as_stream(stream)>>>(depth_d, ec_d, raypath_d, itop,
+                                                              ibottom, nlayers, nwave);
+    PB_LAUNCH_CHECK();
+    k_transit_finish<<<pb::div_up(nwave, kBlock), kBlock, 0, pb::as_stream(stream)>>>(
+        depth_d, ideep_d, spectrum_d, radius_d, rstar, itop, ibottom, maxdepth, nlayers,
+        nwave);
+    PB_LAUNCH_CHECK();
+    return PB_OK;
+}
+
 int pb_optical_depth_transit(double *depth_d, int32_t *ideep_d, const double *ec_d,
                              const double *raypath_d, int itop, int ibottom,
                              double maxdepth, int nlayers, int nwave, void *stream)
 {
-    PB_REQUIRE(nlayers > 0 && nwave >= 0, "pb_optical_depth_transit: bad shape");
-    PB_REQUIRE(itop >= 0 && itop < nlayers, "pb_optical_depth_transit: itop out of range");
-    PB_REQUIRE(ibottom <= nlayers, "pb_optical_depth_transit: ibottom > nlayers");
-    if (nwave == 0)
-        return PB_OK;
-    PB_REQUIRE(depth_d && ideep_d && ec_d, "pb_optical_depth_transit: null pointer");
-    const int nrow = nlayers - itop;
-    PB_REQUIRE(nrow == 1 || raypath_d, "pb_optical_depth_transit: null raypath");
-    size_t lds = (size_t)nrow * 64 * 8 + (size_t)nrow * (nrow - 1) / 2 * 8 + 64 * 4;
-    if (lds > 160 * 1024) {
-        pb::set_error("pb_optical_depth_transit: %d layers need %zu B of LDS (>160 KiB)",
-                      nrow, lds);
-        return PB_ERR_UNSUPPORTED;
-    }
-    PB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_transit_depth),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    k_transit_depth<<<pb::div_up(nwave, 64), kBlock, lds, pb::as_stream(stream)>>>(
-        depth_d, ideep_d, ec_d, raypath_d, itop, ibottom, maxdepth, nlayers, nwave);
-    PB_LAUNCH_CHECK();
-    return PB_OK;
+    return transit_launch(depth_d, ideep_d, nullptr, ec_d, raypath_d, nullptr, 1.0, itop,
+                          ibottom, maxdepth, nlayers, nwave, stream,
+                          "pb_optical_depth_transit");
+}
+
+int pb_transit_spectrum(double *spectrum_d, double *depth_d, int32_t *ideep_d,
+                        const double *ec_d, const double *raypath_d, const double *radius_d,
+                        double rstar, int itop, int ibottom, double maxdepth, int nlayers,
+                        int nwave, void *stream)
+{
+    PB_REQUIRE(spectrum_d, "pb_transit_spectrum: null spectrum");
+    return transit_launch(depth_d, ideep_d, spectrum_d, ec_d, raypath_d, radius_d, rstar, itop,
+                          ibottom, maxdepth, nlayers, nwave, stream, "pb_transit_spectrum");
 }
 
 int pb_plane_parallel_optical_depth(double *depth_d, int32_t *ideep_d,

@@ -260,6 +260,19 @@ def optical_depth_transit(ec, raypath_packed, itop, ibottom, maxdepth):
     return depth, ideep
 
 
+def transit_spectrum(ec, raypath_packed, radius, rstar, itop, ibottom, maxdepth):
+    """optic_depth.py:103-112 + radiative_transfer.py:57-71 in one call:
+    ec[L,W] -> spectrum[W], depth[L,W], ideep[W]."""
+    nlayers, nwave = ec.shape
+    depth = torch.empty_like(ec)
+    ideep = torch.empty(nwave, dtype=torch.int32, device=ec.device)
+    spectrum = torch.empty(nwave, dtype=torch.float64, device=ec.device)
+    call('pb_transit_spectrum', _ptr(spectrum), _ptr(depth), _ptr(ideep), _ptr(ec),
+         _ptr(raypath_packed), _ptr(radius), float(rstar), int(itop), int(ibottom),
+         float(maxdepth), nlayers, nwave, _stream())
+    return spectrum, depth, ideep
+
+
 def plane_parallel_optical_depth(ec, intervals, itop, ibottom, maxdepth, depth=None):
     """optic_depth.py:122-130.  Rows below the stopping layer stay zero."""
     nlayers, nwave = ec.shape
@@ -434,8 +447,14 @@ class LBLSpectrum:
         return self.spectrum
 
     def run(self):
-        """One spectrum: the 'extinction', 'odepth' and 'spectrum' stages."""
+        """One spectrum: the 'extinction', 'odepth' and 'spectrum' stages (the last two
+        fused for the transit geometry)."""
         self.extinction()
+        if self.rt_path == 'transit':
+            self.spectrum, self.depth, self.ideep = transit_spectrum(
+                self.ec.view(self.nlayers, self.wcount), self.raypath, self.radius,
+                self.rstar, self.itop, self.nlayers, self.maxdepth)
+            return self.spectrum
         self.optical_depth()
         return self.rt()
 
@@ -477,10 +496,9 @@ class TableSpectrum:
         self.ec.zero_()
         interp_ec(self.ec, self.etable, self.ttable, self.temp, dens, 0, self.nlayers)
         if self.rt_path == 'transit':
-            self.depth, self.ideep = optical_depth_transit(
-                self.ec, self.raypath, self.itop, self.nlayers, self.maxdepth)
-            self.spectrum = transmission(self.depth, self.ideep, self.radius, self.itop,
-                                         self.rstar)
+            self.spectrum, self.depth, self.ideep = transit_spectrum(
+                self.ec, self.raypath, self.radius, self.rstar, self.itop, self.nlayers,
+                self.maxdepth)
         else:
             self.depth, self.ideep = plane_parallel_optical_depth(
                 self.ec, self.intervals, self.itop, self.nlayers, self.maxdepth)

@@ -36,6 +36,12 @@ def test_transit_depth_and_transmission_golden(eng, golden, tag):
     np.testing.assert_allclose(host(depth), g4[f'transit_depth_{tag}'], rtol=RTOL)
     spec = eng.transmission(depth, ideep, eng.dev(g4['radius']), itop, float(g5['rstar']))
     np.testing.assert_allclose(host(spec), g5[f'transmission_{tag}'], rtol=RTOL)
+    # fused entry: same depth / ideep / spectrum from one call
+    spec2, depth2, ideep2 = eng.transit_spectrum(ec, path, eng.dev(g4['radius']),
+                                                 float(g5['rstar']), itop, ibottom, maxdepth)
+    assert np.array_equal(host(ideep2), host(ideep))
+    assert np.array_equal(host(depth2), host(depth))
+    assert np.array_equal(host(spec2), host(spec))
 
 
 @pytest.mark.parametrize('tag', ['a', 'b', 'c'])
