@@ -123,13 +123,15 @@ def main():
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--workload', default='c2', choices=sorted(WORKLOADS))
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--shard', default='layers', choices=['layers', 'wavenumber'],
+                    help='multi-GPU decomposition (see pyratbay_amd/dist.py)')
     ap.add_argument("--cpu-layers", type=int, default=80)
     args = ap.parse_args()
 
     import torch
     import torch.distributed as dist
     from pyratbay_amd import engine, synth
-    from pyratbay_amd.dist import SpectrumGather
+    from pyratbay_amd.dist import SpectrumGather, LayerShardedTransit
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
@@ -137,28 +139,46 @@ def main():
     if world != args.gpus:
         raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with '
                          'python -m torch.distributed.run --nproc-per-node N bench.py --gpus N')
+    # PB_REHEARSE=1: every rank on GPU 0 with gloo (collectives staged through the host) --
+    # only to rehearse the N>1 code path on a one-GPU box; never a benchmark setting
+    rehearse = os.environ.get('PB_REHEARSE') == '1'
+    if rehearse:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', rank=rank, world_size=world,
-                                device_id=torch.device('cuda', local_rank))
+        if rehearse:
+            dist.init_process_group('gloo', rank=rank, world_size=world)
+        else:
+            dist.init_process_group('nccl', rank=rank, world_size=world,
+                                    device_id=torch.device('cuda', local_rank))
 
     w = WORKLOADS[args.workload]
     case = synth.lbl_case(w['nwave'], w['nlayers'], w['nlines'], wnstep=w['wnstep'],
                           niso=w['niso'], seed=42)
     nwave, nlayers = case['grid']['nwave'], case['atm']['nlayers']
-    gather = SpectrumGather(nwave, world, rank, 'cuda')
-    wbegin, wcount = gather.wbegin, gather.wcount
+    rt_path = w.get('rt_path', 'transit')
+    layer_mode = world > 1 and args.shard == 'layers' and rt_path == 'transit'
     t0 = time.perf_counter()
-    model = engine.LBLSpectrum(case, rt_path=w.get('rt_path', 'transit'), wbegin=wbegin,
-                               wcount=wcount)
+    if layer_mode:
+        # layer-sharded extinction -> all-to-all -> wavenumber-sharded depth/RT -> all-gather
+        sharded = LayerShardedTransit(case, world, rank)
+        model = sharded.model
+        wcount = nwave                      # the gather kernel covers the full grid ...
+        nlayers_rank = len(sharded.layers)  # ... for this rank's layers
+        step = sharded.step
+    else:
+        gather = SpectrumGather(nwave, world, rank, 'cuda')
+        wbegin, wcount = gather.wbegin, gather.wcount
+        nlayers_rank = nlayers
+        model = engine.LBLSpectrum(case, rt_path=rt_path, wbegin=wbegin, wcount=wcount)
+
+        def step():
+            # every rank computes its wavenumber shard, then the shards are re-assembled
+            # on every rank (RCCL all-gather over xGMI when world > 1)
+            return gather(model.run())
     torch.cuda.synchronize()
     t_init = time.perf_counter() - t0
-
-    def step():
-        # one spectrum: every rank computes its wavenumber shard, then the shards are
-        # re-assembled on every rank (RCCL all-gather over xGMI when world > 1)
-        return gather(model.run())
 
     for _ in range(args.warmup):
         step()
@@ -175,9 +195,11 @@ def main():
     elapsed = time.perf_counter() - t0
     gather_ms, launches = model.lbl.timing_end()
     if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
+        tt = torch.tensor([elapsed], dtype=torch.float64, device='cpu' if rehearse else 'cuda')
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
+    if os.environ.get('PB_DUMP_SPECTRUM'):
+        np.save(f"{os.environ['PB_DUMP_SPECTRUM']}.rank{rank}.npy", step().cpu().numpy())
 
     if rank == 0:
         ms_per_step = 1e3 * elapsed / args.steps
@@ -187,7 +209,7 @@ def main():
         # SURVEY 8(d)'s per-spectrum figure that this kernel moves: read the line list
         # once (26 B/line), write ec once (8 B per layer x sample of the shard).
         n_lines = model.lines.nlines
-        kernel_bytes = 26.0 * n_lines + 8.0 * nlayers * wcount
+        kernel_bytes = 26.0 * n_lines + 8.0 * nlayers_rank * wcount
         path_bytes = 26.0 * n_lines + 32.0 * nlayers * nwave + 8.0 * nwave
         kernel_ms = gather_ms / max(launches, 1)
         achieved = kernel_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
@@ -207,7 +229,10 @@ def main():
                        'nlines': n_lines, 'wnosamp': case['grid']['wnosamp'],
                        'voigt_grid': 'nlor=100 ndop=50 extent=300 cutoff=25',
                        'voigt_table_bytes': int(model.voigt.device_bytes),
-                       'parallelism': f'wavenumber shards x{world}' if world > 1 else 'single GPU',
+                       'parallelism': ('single GPU' if world == 1 else
+                                       f'layer-sharded extinction x{world} + all-to-all + '
+                                       'wavenumber-sharded RT + all-gather' if layer_mode
+                                       else f'wavenumber shards x{world} + all-gather'),
                        'init_seconds': round(t_init, 3)},
             'roofline': {'bound': 'hbm', 'kernel': model.lbl.last_gather_kernel,
                          'achieved': achieved,
@@ -220,7 +245,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(
                 case, model.voigt, args.cpu_layers, gpu_ec=model.ec.cpu().numpy()[:, 0],
-                gpu_spectrum=model.spectrum.cpu().numpy())
+                gpu_spectrum=model.spectrum.cpu().numpy() if rt_path == 'transit' else None)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -1,14 +1,54 @@
-"""Wavenumber sharding across the GPUs of one node (one process per GPU).
+"""Sharding of one spectrum across the GPUs of one node (one process per GPU).
 
-Every stage after line broadening is column-independent, and the
-line list is replicated, so rank r computes the output samples [bounds[r], bounds[r+1])
-of the GLOBAL grid with no exchange in the middle of the path.  Two collectives close a
-step: an all-gather of the spectrum shards (RCCL over xGMI on GPUs, gloo in the CPU tests)
-and an all-reduce(SUM) of the per-band partial trapezoids.
+Two decompositions are provided:
+
+* wavenumber shards: every stage after line broadening is
+  column-independent and the line list is replicated, so rank r computes the output
+  samples [bounds[r], bounds[r+1]) of the GLOBAL grid with no exchange in the middle of
+  the path (`SpectrumGather` closes the step with an all-gather).  Each shard still walks
+  all layers, re-derives the per-line records and carries a +-cutoff halo of lines, so
+  the fixed part of a step does not shrink with the number of ranks.
+
+* layer-sharded extinction (`LayerShardedTransit`): the extinction of different layers is
+  independent -- it is the axis the reference itself parallelises over with fork
+  (pyratbay/pyrat/line_by_line.py:232-246).  Rank r computes ec for the layers
+  r, r+N, r+2N, ... over the FULL grid (deep and shallow layers interleave, so the load
+  balances), one all-to-all turns [my layers, all columns] into [all layers, my columns],
+  the column stages (optical depth, spectrum) run on the wavenumber shard, and the
+  all-gather re-assembles the spectrum.  Per-rank work is 1/N of the single-GPU work with
+  the same tile geometry and no halo; the result is bit-identical to the single-GPU
+  spectrum because every ec row and every column is computed by the same arithmetic.
+
+Band fluxes: all-reduce(SUM) of per-shard partial trapezoids (`allreduce_bandflux`).
+RCCL over xGMI on GPUs, gloo in the CPU tests.
 """
 import numpy as np
 import torch
 import torch.distributed as dist
+
+
+def _via_host(group=None):
+    """True when the process group cannot move device tensors (gloo): used only to
+    rehearse the multi-rank path on a box with fewer GPUs than ranks."""
+    return dist.is_initialized() and dist.get_backend(group) == 'gloo'
+
+
+def all_gather_flat(recv, send, group=None):
+    if _via_host(group) and send.is_cuda:
+        r, s_ = recv.cpu(), send.cpu()
+        dist.all_gather_into_tensor(r, s_, group=group)
+        recv.copy_(r)
+    else:
+        dist.all_gather_into_tensor(recv, send, group=group)
+
+
+def all_to_all_flat(recv, send, group=None):
+    if _via_host(group) and send.is_cuda:
+        r, s_ = recv.cpu(), send.cpu()
+        dist.all_to_all_single(r, s_, group=group)
+        recv.copy_(r)
+    else:
+        dist.all_to_all_single(recv, send, group=group)
 
 
 def shard_bounds(nwave, world):
@@ -46,7 +86,7 @@ class SpectrumGather:
             self.full.copy_(local)
             return self.full
         self.send[:self.wcount].copy_(local)
-        dist.all_gather_into_tensor(self.recv, self.send, group=self.group)
+        all_gather_flat(self.recv, self.send, self.group)
         blocks = self.recv.view(self.world, self.pad)
         for r in range(self.world):
             n = int(self.bounds[r + 1] - self.bounds[r])
@@ -60,3 +100,68 @@ def allreduce_bandflux(partial, heights=None, group=None):
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
         dist.all_reduce(partial, op=dist.ReduceOp.SUM, group=group)
     return partial * heights if heights is not None else partial
+
+
+def layer_exchange(ec_mine, nlayers, nwave, world, rank, group=None, buffers=None):
+    """[my layers (r, r+N, ...), all columns] -> [all layers, my columns].
+
+    ec_mine: tensor [Lp, nwave] with Lp = ceil(nlayers/world) rows (rows beyond this
+    rank's share are padding).  Returns (ec_cols[nlayers, wcount], bounds).  One
+    all_to_all_single of equal blocks; layer l = src + world*j lands in row j*world + src,
+    i.e. the natural layer order."""
+    lp = -(-nlayers // world)
+    bounds = shard_bounds(nwave, world)
+    wp = int(np.max(np.diff(bounds)))
+    assert ec_mine.shape == (lp, nwave)
+    if buffers is None:
+        buffers = (torch.zeros((world, lp, wp), dtype=ec_mine.dtype, device=ec_mine.device),
+                   torch.empty((world, lp, wp), dtype=ec_mine.dtype, device=ec_mine.device))
+    send, recv = buffers
+    for dest in range(world):
+        a, b = int(bounds[dest]), int(bounds[dest + 1])
+        send[dest, :, :b - a].copy_(ec_mine[:, a:b])
+    if world > 1:
+        all_to_all_flat(recv.view(-1), send.view(-1), group)
+    else:
+        recv.copy_(send)
+    wcount = int(bounds[rank + 1] - bounds[rank])
+    # recv[src, j, :] is layer src + world*j
+    ec_cols = recv.permute(1, 0, 2).reshape(lp * world, wp)[:nlayers, :wcount]
+    return ec_cols.contiguous(), bounds
+
+
+class LayerShardedTransit:
+    """One transit spectrum per step on `world` GPUs: layer-sharded LBL extinction, one
+    all-to-all, wavenumber-sharded optical depth + transmission, one all-gather."""
+
+    def __init__(self, case, world, rank, group=None):
+        from . import engine
+        self.engine = engine
+        self.world, self.rank, self.group = world, rank, group
+        g, atm, iso = case['grid'], case['atm'], case['iso']
+        self.nwave, self.nlayers = g['nwave'], atm['nlayers']
+        self.layers = np.arange(rank, self.nlayers, world)
+        self.lp = -(-self.nlayers // world)
+        self.model = engine.LBLSpectrum(case, rt_path='transit')      # full grid, full plan
+        idx = torch.as_tensor(self.layers, device='cuda')
+        self.temp = self.model.temp[idx].contiguous()
+        self.dens = self.model.dens[idx].contiguous()
+        self.isoz = self.model.isoz[:, idx].contiguous()
+        self.ec = torch.zeros((self.lp, 1, self.nwave), dtype=torch.float64, device='cuda')
+        self.gather = SpectrumGather(self.nwave, world, rank, 'cuda', group)
+        wp = self.gather.pad
+        self.buffers = (torch.zeros((world, self.lp, wp), dtype=torch.float64, device='cuda'),
+                        torch.empty((world, self.lp, wp), dtype=torch.float64, device='cuda'))
+        self.lbl = self.model.lbl
+
+    def step(self):
+        m, e = self.model, self.engine
+        n = len(self.layers)
+        if n:
+            m.lbl.extinction(self.temp, self.dens, self.isoz, add=True, out=self.ec[:n])
+        ec_cols, _ = layer_exchange(self.ec.view(self.lp, self.nwave), self.nlayers,
+                                    self.nwave, self.world, self.rank, self.group,
+                                    self.buffers)
+        spec, self.depth, self.ideep = e.transit_spectrum(
+            ec_cols, m.raypath, m.radius, m.rstar, m.itop, self.nlayers, m.maxdepth)
+        return self.gather(spec)

@@ -101,3 +101,33 @@ def test_shard_bounds_properties():
             assert b[0] == 0 and b[-1] == nwave and len(b) == world + 1
             sizes = np.diff(b)
             assert sizes.min() >= 0 and sizes.max() - sizes.min() <= 1
+
+
+def _worker_layers(rank, world, port, nlayers, nwave, tmp):
+    sys.path.insert(0, ROOT)
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from pyratbay_amd import dist as pbd
+    full = np.arange(nlayers * nwave, dtype=float).reshape(nlayers, nwave)   # "ec"
+    lp = -(-nlayers // world)
+    mine = np.zeros((lp, nwave))
+    rows = np.arange(rank, nlayers, world)
+    mine[:len(rows)] = full[rows]
+    cols, bounds = pbd.layer_exchange(torch.from_numpy(mine), nlayers, nwave, world, rank)
+    a, b = int(bounds[rank]), int(bounds[rank + 1])
+    ok = np.array_equal(cols.numpy(), full[:, a:b])
+    np.save(os.path.join(tmp, f'ok{rank}.npy'), np.array([ok, cols.shape[0], cols.shape[1]]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('nlayers,nwave', [(7, 101), (8, 64)])
+def test_layer_exchange_two_ranks(tmp_path, nlayers, nwave):
+    """[my layers, all columns] -> [all layers, my columns] through all_to_all_single."""
+    world = 2
+    mp.spawn(_worker_layers, args=(world, _free_port(), nlayers, nwave, str(tmp_path)),
+             nprocs=world, join=True)
+    for rank in range(world):
+        ok, nl, nw = np.load(tmp_path / f'ok{rank}.npy')
+        assert ok == 1 and nl == nlayers

@@ -133,3 +133,27 @@ def test_set_atmosphere_changes_result(eng, case):
     assert np.max(np.abs(hot / base - 1)) > 1e-6
     model.set_atmosphere(atm['temp'], atm['dens'], iso['isoz'])
     assert np.array_equal(model.run().cpu().numpy(), base)
+
+
+@pytest.mark.parametrize('world', [2, 8])
+def test_layer_sharded_extinction_equals_single(eng, case, world):
+    """Layer-sharded mode (dist.LayerShardedTransit): rank r computes the layers
+    r, r+N, ...; interleaving the rows reproduces the single-GPU ec bit for bit, and the
+    world=1 pipeline reproduces the single-GPU spectrum."""
+    import torch
+    from pyratbay_amd.dist import LayerShardedTransit
+    single = eng.LBLSpectrum(case, rt_path='transit')
+    want = single.run().cpu().numpy()
+    ec_full = single.ec.cpu().numpy()[:, 0]
+    nl = single.nlayers
+    got = np.zeros_like(ec_full)
+    for r in range(world):
+        idx = torch.arange(r, nl, world, device='cuda')
+        if len(idx) == 0:
+            continue
+        ec = single.lbl.extinction(single.temp[idx].contiguous(), single.dens[idx].contiguous(),
+                                   single.isoz[:, idx].contiguous(), add=True)
+        got[r::world] = ec.cpu().numpy()[:, 0]
+    assert np.array_equal(got, ec_full)
+    one = LayerShardedTransit(case, 1, 0)
+    assert np.array_equal(one.step().cpu().numpy(), want)

@@ -12,7 +12,12 @@ steps = int(sys.argv[2]) if len(sys.argv) > 2 else 10
 w = bench.WORKLOADS[name]
 case = synth.lbl_case(w['nwave'], w['nlayers'], w['nlines'], wnstep=w['wnstep'],
                       niso=w['niso'], seed=42)
-model = engine.LBLSpectrum(case, rt_path=w.get('rt_path', 'transit'))
+nshard = int(sys.argv[3]) if len(sys.argv) > 3 else 1
+from pyratbay_amd.dist import shard_bounds
+b = shard_bounds(case['grid']['nwave'], nshard)
+r = nshard // 2
+model = engine.LBLSpectrum(case, rt_path=w.get('rt_path', 'transit'), wbegin=int(b[r]),
+                           wcount=int(b[r + 1] - b[r]))
 for _ in range(2):
     model.run()
 torch.cuda.synchronize()
@@ -26,6 +31,6 @@ for _ in range(steps):
     torch.cuda.synchronize()
     for i in range(3):
         tot[i] += ev[i].elapsed_time(ev[i + 1])
-print(f'{name}: extinction {tot[0]/steps:.3f} ms  odepth {tot[1]/steps:.3f} ms  '
+print(f'{name} shard 1/{nshard}: extinction {tot[0]/steps:.3f} ms  odepth {tot[1]/steps:.3f} ms  '
       f'spectrum {tot[2]/steps:.3f} ms  total {sum(tot)/steps:.3f} ms '
       f'({steps/sum(tot)*1e3:.1f} spectra/s)')
