@@ -71,6 +71,11 @@ struct LblArgs {
     const int64_t *ph_start;          // [niso*(osamp+1)+1]
     int rowcap;                       // longest phase row of the table (samples)
     const int32_t *ph_iso;            // isotope of every phase-sorted group
+    const int32_t *giso;              // isotope of every position-sorted group
+    // group list that k_records walks (phase-sorted or position-sorted) and whether the
+    // gather kernel reads records (1) or derives them itself (0: resolution mode)
+    const int32_t *rk_first, *rk_count, *rk_iown, *rk_iso;
+    int use_records;
     int64_t ngroups;
     // per (layer, phase-sorted group) records written by k_records [nlayers][ngroups]
     double *rec_k;                    // co-added strength (before threshold / density)
@@ -307,8 +312,14 @@ __device__ inline void decode_block(const LblArgs &a, int &tile, int &layer)
 // fully inside (fma with the scalar k), partial (k or 0 selected per sample) or outside
 // (skipped) is decided by scalar compares.
 // ---------------------------------------------------------------------------
+// RS wavefronts share one 256-sample range and split its records between them (each walks
+// the records of every RS-th 64-record round); their partial sums are added in wavefront
+// order through LDS.  RS > 1 shortens the critical path of a workgroup RS-fold -- used
+// when the launch has too few workgroups to fill the chip (multi-GPU shards).
+template <int RS>
 __global__ __launch_bounds__(kBlock) void k_ext_resample(LblArgs a)
 {
+    constexpr int kTileRS = kTile / RS;          // output samples per workgroup
     __shared__ double s_k[kBlock];
     __shared__ unsigned s_off[kBlock];
     __shared__ unsigned s_win[kBlock];           // lo | hi << 16
@@ -321,16 +332,14 @@ __global__ __launch_bounds__(kBlock) void k_ext_resample(LblArgs a)
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 
-    const int64_t t0 = a.wbegin + (int64_t)tile * kTile;           // global sample index
-    const int64_t tend = min(t0 + kTile, a.wbegin + a.wcount);
-    const int rlo = wave * kWaveSpan;                              // tile coordinates
+    const int64_t t0 = a.wbegin + (int64_t)tile * kTileRS;         // global sample index
+    const int64_t tend = min(t0 + kTileRS, a.wbegin + a.wcount);
+    const int part = wave % RS;                                    // my share of the records
+    const int rlo = (wave / RS) * kWaveSpan;                       // tile coordinates
+    const int64_t recbase = (int64_t)layer * a.ngroups;
     const int rhi = (int)min((int64_t)rlo + kWaveSpan, tend - t0);
 
     const int ofactor = a.ls_ofactor[layer];
-    const int scale = a.ls_scale[layer];
-    const int64_t dnwn = a.ls_dnwn[layer];
-    const double dwnstep = a.ls_dwnstep[layer];
-    const double temp = a.temp[layer];
     const double kthresh =
         a.ethresh * __longlong_as_double((long long)a.kmax_bits[(int64_t)layer * a.nrows + row]);
     const int osamp = a.osamp;
@@ -347,8 +356,6 @@ __global__ __launch_bounds__(kBlock) void k_ext_resample(LblArgs a)
         const int64_t li = (int64_t)layer * a.niso + iso;
         const int ilor = a.li_ilor[li];
         const double alphad = a.li_alphad[li];
-        const double ratio = a.isoratio[iso];
-        const double z = a.li_z[li];
         const double dens = a.li_dens[li];
         int64_t reach = a.li_hmax[li];
         if (a.cutoff > 0.0)
@@ -364,56 +371,38 @@ __global__ __launch_bounds__(kBlock) void k_ext_resample(LblArgs a)
         // monotonic in the line position, so it is bracketed by the images of the first
         // and last candidate positions (a leader lies within one fine step of own[iown]).
         const double vmin = a.own0 + ((double)a.giown[g0] - 1.0) * a.ownstep;
-        const double vmax = a.own0 + ((double)a.giown[g1 - 1] + 1.0) * a.ownstep;
+        // lowest Doppler column the candidates can use (their cells lie at or after it in
+        // the table, so 32-bit offsets from its start are non-negative)
         const int idop_lo = pb::nearest_index(a.doppler, alphad * vmin, 0, a.ndop - 1);
-        const int idop_hi = pb::nearest_index(a.doppler, alphad * vmax, 0, a.ndop - 1);
         const int64_t cell_lo = (int64_t)ilor * a.ndop + idop_lo;
         const int64_t base_idx = a.pm_base[cell_lo] - kTile;       // inside the front pad
         const double *base = a.pm + base_idx;
 
         for (int64_t gb = g0; gb < g1; gb += kBlock) {
             __syncthreads();
-            // ---- one record per lane ----
+            // ---- one record per lane: (layer, group) records from k_records ----
             {
                 const int64_t g = gb + threadIdx.x;
                 double k = 0.0;
                 unsigned off = 0, win = 0;
-                if (g < g1 && a.experiment == 3) {
-                    const int iown = a.giown[g];
-                    int c = (int)(iown / osamp - t0);
-                    int l3 = max(c - 104, 0), h3 = min(c + 104, (int)(tend - t0));
-                    if (l3 < h3) {
-                        k = 1e-30;
-                        win = (unsigned)l3 | ((unsigned)h3 << 16);
-                        off = (unsigned)(kTile + l3);
-                    }
-                } else if (g < g1) {
-                    const int first = a.gfirst[g];
-                    const int iown = a.giown[g];
-                    k = group_strength(a, first, a.gcount[g], ratio, temp, z);
-                    if (!(k < kthresh)) {
+                if (g < g1) {
+                    const int64_t idx = recbase + g;
+                    k = a.rec_k[idx];
+                    const int64_t lo = max((int64_t)a.rec_ulo[idx], t0);
+                    const int64_t hi = min((int64_t)a.rec_uhi[idx], tend);
+                    if (!(k < kthresh) && lo < hi) {
                         if (a.add)
                             k *= dens;
-                        const Window w = group_window(a, a.lwn[first], iown, ilor, alphad,
-                                                      ofactor, dwnstep, dnwn, idop_lo, idop_hi);
-                        // kept samples: minj <= scale*jo < maxj, inside the profile
-                        int64_t lo = (w.minj + scale - 1) / scale;
-                        int64_t hi = (w.maxj + scale - 1) / scale;
-                        lo = max(lo, pb::ceil_div((int64_t)iown - w.half, osamp));
-                        hi = min(hi, pb::floor_div((int64_t)iown + w.half, osamp) + 1);
-                        lo = max(lo, t0);
-                        hi = min(hi, tend);
-                        if (lo < hi) {
-                            win = (unsigned)(lo - t0) | ((unsigned)(hi - t0) << 16);
-                            const int64_t f0 = (int64_t)w.half - iown;
-                            const int64_t q = pb::floor_div(f0, osamp);
-                            const int64_t phi = f0 - q * osamp;
-                            // tile sample j reads base[off + j]
-                            off = (unsigned)(a.pm_base[w.cell] + phi * a.pm_stride[w.cell] + q +
-                                             t0 - base_idx);
-                            if (a.experiment == 1)
-                                off = (unsigned)(kTile + (lo - t0));
-                        }
+                        const int cell = a.rec_cell[idx];
+                        win = (unsigned)(lo - t0) | ((unsigned)(hi - t0) << 16);
+                        // tile sample j reads base[off + j]
+                        off = (unsigned)(a.pm_base[cell] +
+                                         (int64_t)a.rec_phi[idx] * a.pm_stride[cell] +
+                                         a.rec_q[idx] + t0 - base_idx);
+                        if (a.experiment == 1)
+                            off = (unsigned)(kTile + (lo - t0));
+                    } else {
+                        k = 0.0;
                     }
                 }
                 s_k[threadIdx.x] = k;
@@ -426,7 +415,10 @@ __global__ __launch_bounds__(kBlock) void k_ext_resample(LblArgs a)
             for (int b = 0; b < nrec; b += 64) {
                 const int e = (b + lane) & (kBlock - 1);
                 const unsigned my_win = s_win[e];
-                const bool hit = b + lane < nrec && (int)(my_win & 0xffff) < rhi &&
+                // record g belongs to wavefront share (g / 64) % RS: a property of the
+                // group, not of the tiling, so any tiling adds the same partial sums
+                const bool mine = RS == 1 || (int)(((gb + b + lane) >> 6) & (RS - 1)) == part;
+                const bool hit = mine && b + lane < nrec && (int)(my_win & 0xffff) < rhi &&
                                  (int)(my_win >> 16) > rlo;
                 unsigned long long mask = __ballot(hit);
                 const double my_k = s_k[e];
@@ -480,6 +472,27 @@ __global__ __launch_bounds__(kBlock) void k_ext_resample(LblArgs a)
         }
     }
 
+    if (RS > 1) {
+        // partial sums of the wavefronts that share a range, added in wavefront order
+        __shared__ double s_acc[kBlock * kChunks * kLaneSamples];
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < kChunks; s++) {
+            s_acc[(threadIdx.x * kChunks + s) * kLaneSamples + 0] = acc[s][0];
+            s_acc[(threadIdx.x * kChunks + s) * kLaneSamples + 1] = acc[s][1];
+        }
+        __syncthreads();
+        if (part != 0)
+            return;
+#pragma unroll
+        for (int s = 0; s < kChunks; s++) {
+            for (int q = 1; q < RS; q++) {
+                const int t = threadIdx.x + q * 64;
+                acc[s][0] += s_acc[(t * kChunks + s) * kLaneSamples + 0];
+                acc[s][1] += s_acc[(t * kChunks + s) * kLaneSamples + 1];
+            }
+        }
+    }
     double *dst = a.ext + ((int64_t)layer * a.nrows + row) * a.wcount + (t0 - a.wbegin);
 #pragma unroll
     for (int s = 0; s < kChunks; s++) {
@@ -492,7 +505,7 @@ __global__ __launch_bounds__(kBlock) void k_ext_resample(LblArgs a)
 }
 
 // ---------------------------------------------------------------------------
-// 2'. Records for the staged gather: everything about a (layer, group) pair that does
+// 2'. Records for the gather kernels: everything about a (layer, group) pair that does
 // not depend on the output tile -- co-added strength, table cell and phase row, window on
 // the global grid -- is computed ONCE here (coalesced, no workgroup synchronisation) and
 // streamed by the gather kernel; the per-row maximum strength (k_kmax) is fused in.
@@ -515,7 +528,7 @@ __global__ __launch_bounds__(kBlock) void k_records(LblArgs a)
     double k = 0.0, lmax = 0.0;
     int ulo = 0, uhi = 0, q = 0, cell = 0, phi = 0, row = -1;
     if (g < a.ngroups) {
-        const int iso = a.ph_iso[g];
+        const int iso = a.rk_iso[g];
         row = a.isoiext[iso];
         if (row >= 0 && a.add)
             row = 0;
@@ -524,9 +537,9 @@ __global__ __launch_bounds__(kBlock) void k_records(LblArgs a)
             const double temp = a.temp[layer];
             const double ratio = a.isoratio[iso];
             const double z = a.li_z[li];
-            const int first = a.ph_first[g];
-            const int count = a.ph_count[g];
-            const int iown = a.ph_iown[g];
+            const int first = a.rk_first[g];
+            const int count = a.rk_count[g];
+            const int iown = a.rk_iown[g];
             k = line_strength(ratio, a.gf[first], a.elow[first], a.lwn[first], temp, z);
             lmax = k;
             for (int m = 1; m < count; m++) {
@@ -1234,6 +1247,12 @@ int pb_lines_create(pb_lines **out, const double *lwn_h, const double *elow_h,
     if (rc == PB_OK) rc = upload(&l->d_gfirst, gfirst.data(), gfirst.size());
     if (rc == PB_OK) rc = upload(&l->d_gcount, gcount.data(), gcount.size());
     if (rc == PB_OK) rc = upload(&l->d_giown, giown.data(), giown.size());
+    {
+        std::vector<int32_t> giso(groups.size());
+        for (size_t k = 0; k < groups.size(); k++)
+            giso[k] = groups[k].iso;
+        if (rc == PB_OK) rc = upload(&l->d_giso, giso.data(), giso.size());
+    }
     if (rc == PB_OK) rc = upload(&l->d_iso_gstart, l->iso_gstart.data(), l->iso_gstart.size());
     if (rc != PB_OK) {
         pb_lines_destroy(l);
@@ -1263,6 +1282,7 @@ void pb_lines_destroy(pb_lines *l)
     (void)hipFree(l->d_gfirst);
     (void)hipFree(l->d_gcount);
     (void)hipFree(l->d_giown);
+    (void)hipFree(l->d_giso);
     (void)hipFree(l->d_iso_gstart);
     delete l;
 }
@@ -1302,6 +1322,10 @@ int pb_lbl_create(pb_lbl **out, pb_voigt *voigt, pb_lines *lines, const double *
                 return PB_ERR_UNSUPPORTED;
             }
         }
+    }
+    if (!resolution && lines->onwn >= (1LL << 30)) {
+        pb::set_error("pb_lbl_create: fine grid of %lld samples exceeds 2^30", (long long)lines->onwn);
+        return PB_ERR_UNSUPPORTED;
     }
     // the gather kernel addresses one Lorentz row of the table with 32-bit offsets
     for (int m = 0; m < voigt->nlor; m++) {
@@ -1508,6 +1532,7 @@ int pb_lbl_extinction(pb_lbl *p, double *ext_d, int64_t wbegin, int64_t wcount,
     a.ph_start = p->ph_start;
     a.rowcap = p->rowcap;
     a.ph_iso = p->ph_iso;
+    a.giso = l->d_giso;
     a.ngroups = l->ngroups;
     a.inv_osamp = 1.0 / (double)v->osamp;
     a.molrad = p->d_molrad;
@@ -1568,10 +1593,16 @@ int pb_lbl_extinction(pb_lbl *p, double *ext_d, int64_t wbegin, int64_t wcount,
     const size_t lds = 4 * rowlen_h * 8 + lds_fixed;
     const double per_phase = (double)l->ngroups / std::max(1, p->nwave) * 2048.0 / v->osamp;
     const bool can_stage = !p->resolution && a.rowcap <= kStageRowMax && lds <= 160 * 1024 &&
-                           l->onwn < (1LL << 30) && l->ngroups > 0;
+                           l->ngroups > 0;
+    // the staged kernel needs enough workgroups to hide its per-segment latency; small
+    // launches (multi-GPU shards) go to the global gather with record splitting
+    const bool enough_blocks =
+        pb::div_up(wcount, 2 * kStagedWaves * kStageSpan) * (int64_t)nlayers >= 1500;
     const bool staged = can_stage && (p->gather_mode == 2 ||
-                                      (p->gather_mode == 0 && per_phase >= p->stage_threshold));
-    if (staged && !p->rec_k) {
+                                      (p->gather_mode == 0 && enough_blocks &&
+                                       per_phase >= p->stage_threshold));
+    const bool use_records = !p->resolution && l->ngroups > 0;
+    if (use_records && !p->rec_k) {
         const size_t n = (size_t)p->max_layers * (size_t)l->ngroups;
         if (hipMalloc(&p->rec_k, n * 8) != hipSuccess ||
             hipMalloc(&p->rec_i32, n * 4 * 5) != hipSuccess) {
@@ -1579,7 +1610,7 @@ int pb_lbl_extinction(pb_lbl *p, double *ext_d, int64_t wbegin, int64_t wcount,
             return PB_ERR_NOMEM;
         }
     }
-    if (staged) {
+    if (use_records) {
         const size_t n = (size_t)p->max_layers * (size_t)l->ngroups;
         a.rec_k = p->rec_k;
         a.rec_ulo = p->rec_i32;
@@ -1587,11 +1618,17 @@ int pb_lbl_extinction(pb_lbl *p, double *ext_d, int64_t wbegin, int64_t wcount,
         a.rec_q = p->rec_i32 + 2 * n;
         a.rec_cell = p->rec_i32 + 3 * n;
         a.rec_phi = p->rec_i32 + 4 * n;
+        // records are laid out in the order the chosen gather kernel walks the groups
+        a.rk_first = staged ? p->ph_first : l->d_gfirst;
+        a.rk_count = staged ? p->ph_count : l->d_gcount;
+        a.rk_iown = staged ? p->ph_iown : l->d_giown;
+        a.rk_iso = staged ? p->ph_iso : l->d_giso;
     }
+    a.use_records = use_records ? 1 : 0;
 
     k_layer_state<<<nlayers, 64, 0, s>>>(a);
     PB_LAUNCH_CHECK();
-    if (staged) {
+    if (use_records) {
         dim3 grid(pb::div_up(l->ngroups, kBlock), nlayers);
         k_records<<<grid, kBlock, (size_t)a.nrows * 8, s>>>(a);
         PB_LAUNCH_CHECK();
@@ -1628,9 +1665,20 @@ int pb_lbl_extinction(pb_lbl *p, double *ext_d, int64_t wbegin, int64_t wcount,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         kern<<<grid, kStagedThreads, lds, s>>>(a);
     } else {
-        a.ntiles = pb::div_up(wcount, kTile);
+        // record splitting when the launch would not fill the chip
+        // (measured at C2: RS=2 beats RS=1 until the launch has ~16k workgroups)
+        const int64_t tiles1 = pb::div_up(wcount, kTile) * (int64_t)nlayers * a.nrows;
+        int RS = tiles1 >= 16000 ? 1 : tiles1 >= 1500 ? 2 : 4;
+        if (const char *e = getenv("PB_RSPLIT"))
+            RS = atoi(e) >= 4 ? 4 : atoi(e) >= 2 ? 2 : 1;
+        a.ntiles = pb::div_up(wcount, kTile / RS);
         dim3 grid((unsigned)(8 * a.ntiles * layer_groups), a.nrows);
-        k_ext_resample<<<grid, kBlock, 0, s>>>(a);
+        if (RS == 4)
+            k_ext_resample<4><<<grid, kBlock, 0, s>>>(a);
+        else if (RS == 2)
+            k_ext_resample<2><<<grid, kBlock, 0, s>>>(a);
+        else
+            k_ext_resample<1><<<grid, kBlock, 0, s>>>(a);
     }
     PB_LAUNCH_CHECK();
     if (timed) {

@@ -45,6 +45,6 @@ struct pb_lines {
     double *d_lwn = nullptr, *d_elow = nullptr, *d_gf = nullptr;
     int32_t *d_lid = nullptr;
     // device: co-add groups, sorted by (isotope, iown)
-    int32_t *d_gfirst = nullptr, *d_gcount = nullptr, *d_giown = nullptr;
+    int32_t *d_gfirst = nullptr, *d_gcount = nullptr, *d_giown = nullptr, *d_giso = nullptr;
     int64_t *d_iso_gstart = nullptr;
 };
