@@ -604,7 +604,7 @@ constexpr int kStageRowMax = 1024;   // longest phase row the kernel stages
 // NW wavefronts per workgroup, S sub-tiles of NW*256 samples each (tile = S*NW*256); one
 // record per thread per batch.
 template <int NW, int S>
-__global__ __launch_bounds__(NW * 64) void k_ext_staged(LblArgs a)
+__global__ __launch_bounds__(NW * 64, 8) void k_ext_staged(LblArgs a)
 {
     constexpr int kThreads = NW * 64;
     constexpr int kSub = NW * kStageSpan;         // samples per sub-tile
@@ -613,25 +613,21 @@ __global__ __launch_bounds__(NW * 64) void k_ext_staged(LblArgs a)
     static_assert(kT < 65536, "window coordinates are packed in 16 bits");
     extern __shared__ __align__(16) unsigned char smem[];
     const int osamp = a.osamp;
-    const int rowlen = (a.rowcap + 2 * kStagePad + 1) & ~1;    // even: 16-byte aligned copies
-    // row buffers: [2 buffers][2 copies][rowlen]; copy 1 holds the row shifted by one
-    // sample, so that every record finds its samples 16-byte aligned in one of the two
+    // row buffers: [pad][row 0][pad][row 1][pad], pads of kStagePad zero samples shared
     double *s_row = reinterpret_cast<double *>(smem);
     struct __align__(16) Rec {
         double k;
-        int qoff;                 // byte offset of tile sample 0 in the right row copy
+        int qoff;                 // byte offset of tile sample 0 from the row buffer start
         unsigned win;             // lo | hi << 16 (tile coordinates)
     };
-    Rec *s_rec = reinterpret_cast<Rec *>(s_row + 4 * rowlen);            // [kThreads]
+    const int rowspan = a.rowcap + kStagePad;                            // buffer pitch
+    Rec *s_rec = reinterpret_cast<Rec *>(s_row + 2 * rowspan + kStagePad);   // [kThreads]
+    long long *s_src = reinterpret_cast<long long *>(s_rec + kThreads);  // row start, -1 empty
     unsigned long long *s_segmask =
-        reinterpret_cast<unsigned long long *>(s_rec + kThreads);        // [NW]
-    int *s_cell = reinterpret_cast<int *>(s_segmask + NW);               // -1 = empty record
-    int *s_phi = s_cell + kThreads;
-    int *s_mlo = s_phi + kThreads;
-    int *s_mhi = s_mlo + kThreads;
-    int *s_seg0 = s_mhi + kThreads;                                      // live segments
-    int *s_seg1 = s_seg0 + kThreads;
-    int *s_part = s_seg1 + kThreads;                                     // [NW] scan scratch
+        reinterpret_cast<unsigned long long *>(s_src + kThreads);        // [NW]
+    unsigned *s_m = reinterpret_cast<unsigned *>(s_segmask + NW);        // mlo | mhi << 16
+    unsigned *s_seg = s_m + kThreads;                                    // i0 | i1 << 16
+    int *s_part = reinterpret_cast<int *>(s_seg + kThreads);             // [NW] scan scratch
     int *s_cum = s_part + NW;                                            // [osamp+1]
     int *s_phs = s_cum + (osamp + 1);                                    // [osamp]
 
@@ -657,32 +653,29 @@ __global__ __launch_bounds__(NW * 64) void k_ext_staged(LblArgs a)
 #pragma unroll
     for (int u = 0; u < S; u++)
         acc[u][0] = acc[u][1] = acc[u][2] = acc[u][3] = 0.0;
-    for (int i = tid; i < 4 * rowlen; i += kThreads)
+    for (int i = tid; i < 2 * rowspan + kStagePad; i += kThreads)
         s_row[i] = 0.0;                            // the pads stay zero for good
 
     // Row of one segment -> registers (issued early), registers -> LDS (after the walk).
     double rowreg[2][kRowRegs];
-    auto load_row = [&](int i0, double (&reg)[kRowRegs]) {
-        const int cell = __builtin_amdgcn_readfirstlane(s_cell[i0]);
-        const int phi = __builtin_amdgcn_readfirstlane(s_phi[i0]);
-        const int mlo = __builtin_amdgcn_readfirstlane(s_mlo[i0]);
-        const int mhi = __builtin_amdgcn_readfirstlane(s_mhi[i0]);
-        const double *src = a.pm + a.pm_base[cell] + (int64_t)phi * a.pm_stride[cell];
+    auto load_row = [&](int sg, double (&reg)[kRowRegs]) {
+        const int i0 = __builtin_amdgcn_readfirstlane((int)(s_seg[sg] & 0xffff));
+        const unsigned m = (unsigned)__builtin_amdgcn_readfirstlane((int)s_m[i0]);
+        const int mlo = (int)(m & 0xffff), mhi = (int)(m >> 16);
+        const double *src = a.pm + s_src[i0];
 #pragma unroll
         for (int r = 0; r < kRowRegs; r++) {
-            const int m = tid + r * kThreads;
-            reg[r] = (m >= mlo && m < mhi) ? src[m] : 0.0;
+            const int mm = tid + r * kThreads;
+            reg[r] = (mm >= mlo && mm < mhi) ? src[mm] : 0.0;
         }
     };
     auto store_row = [&](int buf, const double (&reg)[kRowRegs]) {
-        double *dst = s_row + (2 * buf) * rowlen + kStagePad;
+        double *dst = s_row + kStagePad + buf * rowspan;
 #pragma unroll
         for (int r = 0; r < kRowRegs; r++) {
-            const int m = tid + r * kThreads;
-            if (m < a.rowcap) {
-                dst[m] = reg[r];
-                dst[rowlen + m - 1] = reg[r];          // copy 1: shifted by one sample
-            }
+            const int mm = tid + r * kThreads;
+            if (mm < a.rowcap)
+                dst[mm] = reg[r];
         }
     };
 
@@ -751,8 +744,9 @@ __global__ __launch_bounds__(NW * 64) void k_ext_staged(LblArgs a)
             // ---- one record per lane, in (phase, iown) order, from k_records ----
             {
                 double k = 0.0;
-                unsigned win = 0;
-                int qoff = 0, cell = -1, phi = 0, mlo = 0, mhi = 0;
+                unsigned win = 0, mwin = 0;
+                int qoff = 0;
+                long long src = -1;
                 const int x = x0 + tid;
                 if (x < total) {
                     int plo = 0, pup = osamp;           // largest p with s_cum[p] <= x
@@ -772,15 +766,11 @@ __global__ __launch_bounds__(NW * 64) void k_ext_staged(LblArgs a)
                         if (a.add)
                             k *= dens;
                         const int q = a.rec_q[idx];
+                        const int cell = a.rec_cell[idx];
                         win = (unsigned)lo | ((unsigned)hi << 16);
-                        // tile sample j reads row[j + q + t0]; a lane reads the pair that
-                        // starts at an even j, so the parity of q + t0 picks the copy
-                        const int qq = (int)(q + t0);
-                        qoff = (qq & 1) ? (qq - 1 + rowlen) * 8 : qq * 8;   // copy1[i] = row[i+1]
-                        cell = a.rec_cell[idx];
-                        phi = a.rec_phi[idx];
-                        mlo = ulo + q;
-                        mhi = uhi + q;
+                        qoff = (int)(q + t0) * 8;       // tile sample j reads row[j + q + t0]
+                        src = a.pm_base[cell] + (long long)a.rec_phi[idx] * a.pm_stride[cell];
+                        mwin = (unsigned)(ulo + q) | ((unsigned)(uhi + q) << 16);
                     } else {
                         k = 0.0;
                     }
@@ -788,24 +778,20 @@ __global__ __launch_bounds__(NW * 64) void k_ext_staged(LblArgs a)
                 s_rec[tid].k = k;
                 s_rec[tid].qoff = qoff;
                 s_rec[tid].win = win;
-                s_cell[tid] = cell;
-                s_phi[tid] = phi;
-                s_mlo[tid] = mlo;
-                s_mhi[tid] = mhi;
+                s_src[tid] = src;
+                s_m[tid] = mwin;
             }
             __syncthreads();
             // ---- segments: runs of equal (cell, phase, row window); live ones are listed ----
             bool start = false;
             {
                 if (tid < nrec)
-                    start = tid == 0 || s_cell[tid] != s_cell[tid - 1] ||
-                            s_phi[tid] != s_phi[tid - 1] || s_mlo[tid] != s_mlo[tid - 1] ||
-                            s_mhi[tid] != s_mhi[tid - 1];
+                    start = tid == 0 || s_src[tid] != s_src[tid - 1] || s_m[tid] != s_m[tid - 1];
                 const unsigned long long m = __ballot(start);
                 if (lane == 0)
                     s_segmask[wave] = m;
             }
-            const bool live = start && s_cell[tid] >= 0;
+            const bool live = start && s_src[tid] >= 0;
             const unsigned long long livemask = __ballot(live);
             if (lane == 0)
                 s_part[wave] = __builtin_popcountll(livemask);
@@ -834,8 +820,7 @@ __global__ __launch_bounds__(NW * 64) void k_ext_staged(LblArgs a)
                         m = s_segmask[w];
                     }
                     const int pos = before + __builtin_popcountll(livemask & ((1ull << lane) - 1ull));
-                    s_seg0[pos] = tid;
-                    s_seg1[pos] = end;
+                    s_seg[pos] = (unsigned)tid | ((unsigned)end << 16);
                 }
             }
             __syncthreads();
@@ -845,11 +830,11 @@ __global__ __launch_bounds__(NW * 64) void k_ext_staged(LblArgs a)
             // sg+2's row is already in flight (in registers) while sg is walked, and is
             // written to the free LDS buffer one segment later ----
             auto walk = [&](int sg, int buf) {
-                const int i0 = __builtin_amdgcn_readfirstlane(s_seg0[sg]);
-                const int i1 = __builtin_amdgcn_readfirstlane(s_seg1[sg]);
-                // byte address of this lane's first sample pair in copy 0 of the row
+                const unsigned sd = (unsigned)__builtin_amdgcn_readfirstlane((int)s_seg[sg]);
+                const int i0 = (int)(sd & 0xffff), i1 = (int)(sd >> 16);
+                // byte address of this lane's first sample in the staged row
                 const char *rowp = reinterpret_cast<const char *>(
-                    s_row + (2 * buf) * rowlen + kStagePad + rlo + 2 * lane);
+                    s_row + kStagePad + buf * rowspan + rlo + lane);
                 // The records of a segment have equal window lengths and ascending
                 // positions, so the ones that reach a sub-tile range are consecutive.
                 for (int b = i0; b < i1; b += 64) {
@@ -869,37 +854,34 @@ __global__ __launch_bounds__(NW * 64) void k_ext_staged(LblArgs a)
                             b + __builtin_amdgcn_readfirstlane(__builtin_ctzll(mask));
                         const int last =
                             first + __builtin_amdgcn_readfirstlane(__builtin_popcountll(mask));
-                        // per record: one 16-byte broadcast read of {k, offset}, two
-                        // aligned 16-byte row reads (2 x 128 samples), four fma
+                        // per record: one broadcast read of {k, offset}, four 64-sample row
+                        // reads, four fma
                         const char *rs = rowp + (size_t)u * kSub * 8;
                         int r = first;
                         for (; r + 1 < last; r += 2) {
                             const Rec r0 = s_rec[r];
                             const Rec r1 = s_rec[r + 1];
-                            const double2 a0 = *reinterpret_cast<const double2 *>(rs + r0.qoff);
-                            const double2 a1 =
-                                *reinterpret_cast<const double2 *>(rs + r0.qoff + 128 * 8);
-                            const double2 b0 = *reinterpret_cast<const double2 *>(rs + r1.qoff);
-                            const double2 b1 =
-                                *reinterpret_cast<const double2 *>(rs + r1.qoff + 128 * 8);
-                            acc[u][0] = fma(r0.k, a0.x, acc[u][0]);
-                            acc[u][1] = fma(r0.k, a0.y, acc[u][1]);
-                            acc[u][2] = fma(r0.k, a1.x, acc[u][2]);
-                            acc[u][3] = fma(r0.k, a1.y, acc[u][3]);
-                            acc[u][0] = fma(r1.k, b0.x, acc[u][0]);
-                            acc[u][1] = fma(r1.k, b0.y, acc[u][1]);
-                            acc[u][2] = fma(r1.k, b1.x, acc[u][2]);
-                            acc[u][3] = fma(r1.k, b1.y, acc[u][3]);
+                            const double *p0 = reinterpret_cast<const double *>(rs + r0.qoff);
+                            const double *p1 = reinterpret_cast<const double *>(rs + r1.qoff);
+                            const double a0 = p0[0], a1 = p0[64], a2 = p0[128], a3 = p0[192];
+                            const double b0 = p1[0], b1 = p1[64], b2 = p1[128], b3 = p1[192];
+                            acc[u][0] = fma(r0.k, a0, acc[u][0]);
+                            acc[u][1] = fma(r0.k, a1, acc[u][1]);
+                            acc[u][2] = fma(r0.k, a2, acc[u][2]);
+                            acc[u][3] = fma(r0.k, a3, acc[u][3]);
+                            acc[u][0] = fma(r1.k, b0, acc[u][0]);
+                            acc[u][1] = fma(r1.k, b1, acc[u][1]);
+                            acc[u][2] = fma(r1.k, b2, acc[u][2]);
+                            acc[u][3] = fma(r1.k, b3, acc[u][3]);
                         }
                         if (r < last) {
                             const Rec r0 = s_rec[r];
-                            const double2 a0 = *reinterpret_cast<const double2 *>(rs + r0.qoff);
-                            const double2 a1 =
-                                *reinterpret_cast<const double2 *>(rs + r0.qoff + 128 * 8);
-                            acc[u][0] = fma(r0.k, a0.x, acc[u][0]);
-                            acc[u][1] = fma(r0.k, a0.y, acc[u][1]);
-                            acc[u][2] = fma(r0.k, a1.x, acc[u][2]);
-                            acc[u][3] = fma(r0.k, a1.y, acc[u][3]);
+                            const double *p0 = reinterpret_cast<const double *>(rs + r0.qoff);
+                            const double a0 = p0[0], a1 = p0[64], a2 = p0[128], a3 = p0[192];
+                            acc[u][0] = fma(r0.k, a0, acc[u][0]);
+                            acc[u][1] = fma(r0.k, a1, acc[u][1]);
+                            acc[u][2] = fma(r0.k, a2, acc[u][2]);
+                            acc[u][3] = fma(r0.k, a3, acc[u][3]);
                         }
                     }
                 }
@@ -907,16 +889,16 @@ __global__ __launch_bounds__(NW * 64) void k_ext_staged(LblArgs a)
             if (a.experiment == 5)
                 nseg = 0;
             if (nseg > 0) {
-                load_row(__builtin_amdgcn_readfirstlane(s_seg0[0]), rowreg[0]);
+                load_row(0, rowreg[0]);
                 store_row(0, rowreg[0]);
                 if (nseg > 1)
-                    load_row(__builtin_amdgcn_readfirstlane(s_seg0[1]), rowreg[1]);
+                    load_row(1, rowreg[1]);
                 __syncthreads();
             }
             for (int sg = 0; sg < nseg; sg += 2) {
                 // even segment: LDS buffer 0; its successor's row waits in rowreg[1]
                 if (sg + 2 < nseg)
-                    load_row(__builtin_amdgcn_readfirstlane(s_seg0[sg + 2]), rowreg[0]);
+                    load_row(sg + 2, rowreg[0]);
                 walk(sg, 0);
                 if (sg + 1 < nseg)
                     store_row(1, rowreg[1]);
@@ -925,7 +907,7 @@ __global__ __launch_bounds__(NW * 64) void k_ext_staged(LblArgs a)
                     break;
                 // odd segment: LDS buffer 1; rowreg[0] holds segment sg+2
                 if (sg + 3 < nseg)
-                    load_row(__builtin_amdgcn_readfirstlane(s_seg0[sg + 3]), rowreg[1]);
+                    load_row(sg + 3, rowreg[1]);
                 walk(sg + 1, 1);
                 if (sg + 2 < nseg)
                     store_row(0, rowreg[0]);
@@ -939,8 +921,7 @@ __global__ __launch_bounds__(NW * 64) void k_ext_staged(LblArgs a)
     for (int u = 0; u < S; u++) {
 #pragma unroll
         for (int c = 0; c < 4; c++) {
-            // acc[u][2h + e] = sample rlo + u*kSub + 128*h + 2*lane + e
-            const int j = rlo + u * kSub + (c >> 1) * 128 + 2 * lane + (c & 1);
+            const int j = rlo + u * kSub + c * 64 + lane;
             if (j < tlen)
                 dst[j] = acc[u][c];
         }
@@ -1586,11 +1567,9 @@ int pb_lbl_extinction(pb_lbl *p, double *ext_d, int64_t wbegin, int64_t wcount,
     // properties (never on the shard), so shards and the full grid run the same arithmetic.
     constexpr int kStagedWaves = 8;
     constexpr int kStagedThreads = kStagedWaves * 64;
-    const size_t lds_fixed = (size_t)kStagedThreads * 16 + kStagedWaves * 8 +
-                             (size_t)kStagedThreads * 4 * 6 + kStagedWaves * 4 +
+    const size_t lds_fixed = (size_t)kStagedThreads * (16 + 8 + 4 + 4) + kStagedWaves * 12 +
                              (size_t)(2 * v->osamp + 1) * 4 + 64;
-    const size_t rowlen_h = ((size_t)a.rowcap + 2 * kStagePad + 1) & ~(size_t)1;
-    const size_t lds = 4 * rowlen_h * 8 + lds_fixed;
+    const size_t lds = (2 * ((size_t)a.rowcap + kStagePad) + kStagePad) * 8 + lds_fixed;
     const double per_phase = (double)l->ngroups / std::max(1, p->nwave) * 2048.0 / v->osamp;
     const bool can_stage = !p->resolution && a.rowcap <= kStageRowMax && lds <= 160 * 1024 &&
                            l->ngroups > 0;
