@@ -248,15 +248,18 @@ struct Window {
 
 __device__ inline Window group_window(const LblArgs &a, double wavn, int iown, int ilor,
                                       double alphad, int ofactor, double dwnstep,
-                                      int64_t dnwn, int idop_lo, int idop_hi)
+                                      int64_t dnwn, int idop_lo, int idop_hi,
+                                      const double *doppler = nullptr)
 {
     // [idop_lo, idop_hi] brackets the answer (nearest index is monotonic in wavn), which
-    // turns the bisection over the whole Doppler grid into 0-2 steps
+    // turns the bisection over the whole Doppler grid into 0-2 steps; `doppler` may point
+    // to an LDS copy of the grid
     Window w;
     const int idwn = (int)((wavn - a.own0) / dwnstep);
     const int idop = idop_lo == idop_hi
                          ? idop_lo
-                         : pb::nearest_index(a.doppler, alphad * wavn, idop_lo, idop_hi);
+                         : pb::nearest_index(doppler ? doppler : a.doppler, alphad * wavn,
+                                             idop_lo, idop_hi);
     w.cell = ilor * a.ndop + idop;
     w.half = a.psize[w.cell];
     const int subw = iown - idwn * ofactor;
@@ -267,8 +270,9 @@ __device__ inline Window group_window(const LblArgs &a, double wavn, int iown, i
     if (w.maxj > dnwn)
         w.maxj = dnwn;
     if (a.cutoff > 0.0) {
-        const int mincut = (int)(idwn - a.cutoff / dwnstep);
-        const int maxcut = (int)(idwn + a.cutoff / dwnstep);
+        const double cutsteps = a.cutoff / dwnstep;      // wave-uniform
+        const int mincut = (int)(idwn - cutsteps);
+        const int maxcut = (int)(idwn + cutsteps);
         if (mincut > w.minj)
             w.minj = mincut;
         if (maxcut < w.maxj)
@@ -519,11 +523,14 @@ __device__ inline int floor_div_inv(int a, double inv)
 
 __global__ __launch_bounds__(kBlock) void k_records(LblArgs a)
 {
-    extern __shared__ unsigned long long s_max[];
+    extern __shared__ unsigned long long s_max[];                 // [nrows]
+    double *s_dop = reinterpret_cast<double *>(s_max + a.nrows); // [ndop] Doppler grid
     const int layer = blockIdx.y;
     const int64_t g = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     for (int r = threadIdx.x; r < a.nrows; r += kBlock)
         s_max[r] = 0ull;
+    for (int d = threadIdx.x; d < a.ndop; d += kBlock)
+        s_dop[d] = a.doppler[d];
     __syncthreads();
     double k = 0.0, lmax = 0.0;
     int ulo = 0, uhi = 0, q = 0, cell = 0, phi = 0, row = -1;
@@ -552,7 +559,7 @@ __global__ __launch_bounds__(kBlock) void k_records(LblArgs a)
             const int scale = a.ls_scale[layer];
             const Window w = group_window(a, a.lwn[first], iown, a.li_ilor[li], a.li_alphad[li],
                                           ofactor, a.ls_dwnstep[layer], a.ls_dnwn[layer], 0,
-                                          a.ndop - 1);
+                                          a.ndop - 1, s_dop);
             // kept samples: minj <= scale*jo < maxj, inside the profile and the grid
             const double inv_scale = 1.0 / (double)scale;
             ulo = -floor_div_inv(-(int)w.minj, inv_scale);
@@ -854,35 +861,31 @@ __global__ __launch_bounds__(NW * 64, 8) void k_ext_staged(LblArgs a)
                             b + __builtin_amdgcn_readfirstlane(__builtin_ctzll(mask));
                         const int last =
                             first + __builtin_amdgcn_readfirstlane(__builtin_popcountll(mask));
-                        // per record: one broadcast read of {k, offset}, four 64-sample row
-                        // reads, four fma
+                        // per record: ONE 16-byte broadcast read of {k, offset, window}, four
+                        // 64-sample row reads, four fma; four records per trip
                         const char *rs = rowp + (size_t)u * kSub * 8;
+                        const double2 *recs = reinterpret_cast<const double2 *>(s_rec);
+                        auto visit = [&](const double2 raw) {
+                            const double k = raw.x;
+                            const int qoff = __double2loint(raw.y);
+                            const double *p0 = reinterpret_cast<const double *>(rs + qoff);
+                            const double a0 = p0[0], a1 = p0[64], a2 = p0[128], a3 = p0[192];
+                            acc[u][0] = fma(k, a0, acc[u][0]);
+                            acc[u][1] = fma(k, a1, acc[u][1]);
+                            acc[u][2] = fma(k, a2, acc[u][2]);
+                            acc[u][3] = fma(k, a3, acc[u][3]);
+                        };
                         int r = first;
-                        for (; r + 1 < last; r += 2) {
-                            const Rec r0 = s_rec[r];
-                            const Rec r1 = s_rec[r + 1];
-                            const double *p0 = reinterpret_cast<const double *>(rs + r0.qoff);
-                            const double *p1 = reinterpret_cast<const double *>(rs + r1.qoff);
-                            const double a0 = p0[0], a1 = p0[64], a2 = p0[128], a3 = p0[192];
-                            const double b0 = p1[0], b1 = p1[64], b2 = p1[128], b3 = p1[192];
-                            acc[u][0] = fma(r0.k, a0, acc[u][0]);
-                            acc[u][1] = fma(r0.k, a1, acc[u][1]);
-                            acc[u][2] = fma(r0.k, a2, acc[u][2]);
-                            acc[u][3] = fma(r0.k, a3, acc[u][3]);
-                            acc[u][0] = fma(r1.k, b0, acc[u][0]);
-                            acc[u][1] = fma(r1.k, b1, acc[u][1]);
-                            acc[u][2] = fma(r1.k, b2, acc[u][2]);
-                            acc[u][3] = fma(r1.k, b3, acc[u][3]);
+                        for (; r + 3 < last; r += 4) {
+                            const double2 w0 = recs[r], w1 = recs[r + 1], w2 = recs[r + 2],
+                                          w3 = recs[r + 3];
+                            visit(w0);
+                            visit(w1);
+                            visit(w2);
+                            visit(w3);
                         }
-                        if (r < last) {
-                            const Rec r0 = s_rec[r];
-                            const double *p0 = reinterpret_cast<const double *>(rs + r0.qoff);
-                            const double a0 = p0[0], a1 = p0[64], a2 = p0[128], a3 = p0[192];
-                            acc[u][0] = fma(r0.k, a0, acc[u][0]);
-                            acc[u][1] = fma(r0.k, a1, acc[u][1]);
-                            acc[u][2] = fma(r0.k, a2, acc[u][2]);
-                            acc[u][3] = fma(r0.k, a3, acc[u][3]);
-                        }
+                        for (; r < last; r++)
+                            visit(recs[r]);
                     }
                 }
             };
@@ -1609,7 +1612,7 @@ int pb_lbl_extinction(pb_lbl *p, double *ext_d, int64_t wbegin, int64_t wcount,
     PB_LAUNCH_CHECK();
     if (use_records) {
         dim3 grid(pb::div_up(l->ngroups, kBlock), nlayers);
-        k_records<<<grid, kBlock, (size_t)a.nrows * 8, s>>>(a);
+        k_records<<<grid, kBlock, (size_t)a.nrows * 8 + (size_t)a.ndop * 8, s>>>(a);
         PB_LAUNCH_CHECK();
     } else if (l->nlines > 0) {
         const int lines_per_block = 4096;
