@@ -75,6 +75,7 @@ struct LblArgs {
     // group list that k_records walks (phase-sorted or position-sorted) and whether the
     // gather kernel reads records (1) or derives them itself (0: resolution mode)
     const int32_t *rk_first, *rk_count, *rk_iown, *rk_iso;
+    const double *rk_lwn, *rk_elow, *rk_gf;   // the leader line of every group, same order
     int use_records;
     int64_t ngroups;
     // per (layer, phase-sorted group) records written by k_records [nlayers][ngroups]
@@ -547,7 +548,8 @@ __global__ __launch_bounds__(kBlock) void k_records(LblArgs a)
             const int first = a.rk_first[g];
             const int count = a.rk_count[g];
             const int iown = a.rk_iown[g];
-            k = line_strength(ratio, a.gf[first], a.elow[first], a.lwn[first], temp, z);
+            const double wavn = a.rk_lwn[g];          // leader's record, in walk order
+            k = line_strength(ratio, a.rk_gf[g], a.rk_elow[g], wavn, temp, z);
             lmax = k;
             for (int m = 1; m < count; m++) {
                 const double kp = line_strength(ratio, a.gf[first + m], a.elow[first + m],
@@ -557,7 +559,7 @@ __global__ __launch_bounds__(kBlock) void k_records(LblArgs a)
             }
             const int ofactor = a.ls_ofactor[layer];
             const int scale = a.ls_scale[layer];
-            const Window w = group_window(a, a.lwn[first], iown, a.li_ilor[li], a.li_alphad[li],
+            const Window w = group_window(a, wavn, iown, a.li_ilor[li], a.li_alphad[li],
                                           ofactor, a.ls_dwnstep[layer], a.ls_dnwn[layer], 0,
                                           a.ndop - 1, s_dop);
             // kept samples: minj <= scale*jo < maxj, inside the profile and the grid
@@ -1124,6 +1126,8 @@ struct pb_lbl {
     int32_t *ph_first = nullptr, *ph_count = nullptr, *ph_iown = nullptr;
     int64_t *ph_start = nullptr;
     int32_t *ph_iso = nullptr;
+    double *ph_lead = nullptr;       // leader lwn, elow, gf of the phase-sorted groups [3][G]
+    double *g_lead = nullptr;        // same for the position-sorted groups
     double *rec_k = nullptr;
     int32_t *rec_i32 = nullptr;      // 5 arrays of max_layers*ngroups
     int rowcap = 0;
@@ -1223,6 +1227,9 @@ int pb_lines_create(pb_lines **out, const double *lwn_h, const double *elow_h,
         gcount[k] = groups[k].count;
         giown[k] = groups[k].iown;
     }
+    l->h_lwn.assign(lwn_h, lwn_h + nlines);
+    l->h_elow.assign(elow_h, elow_h + nlines);
+    l->h_gf.assign(gf_h, gf_h + nlines);
     int rc = PB_OK;
     if (rc == PB_OK) rc = upload(&l->d_lwn, lwn_h, (size_t)nlines);
     if (rc == PB_OK) rc = upload(&l->d_elow, elow_h, (size_t)nlines);
@@ -1409,6 +1416,23 @@ int pb_lbl_create(pb_lbl **out, pb_voigt *voigt, pb_lines *lines, const double *
                 for (int64_t k = lines->iso_gstart[i]; k < lines->iso_gstart[i + 1]; k++)
                     iso_of[(size_t)k] = i;
             if (rc == PB_OK) rc = upload(&p->ph_iso, iso_of.data(), ng);
+        }
+        {
+            // leader line of every group in both walk orders (coalesced reads in k_records)
+            const std::vector<double> &lwn_all = lines->h_lwn, &elow_all = lines->h_elow,
+                                      &gf_all = lines->h_gf;
+            std::vector<double> lead(3 * ng), glead(3 * ng);
+            for (size_t k = 0; k < ng; k++) {
+                const int32_t lf = f[k], gf_ = lines->h_gfirst[k];
+                lead[k] = lwn_all[lf];
+                lead[ng + k] = elow_all[lf];
+                lead[2 * ng + k] = gf_all[lf];
+                glead[k] = lwn_all[gf_];
+                glead[ng + k] = elow_all[gf_];
+                glead[2 * ng + k] = gf_all[gf_];
+            }
+            if (rc == PB_OK) rc = upload(&p->ph_lead, lead.data(), lead.size());
+            if (rc == PB_OK) rc = upload(&p->g_lead, glead.data(), glead.size());
         }
         // per (layer, group) records of k_records: allocated on first use
         int cap = 0;
@@ -1605,6 +1629,10 @@ int pb_lbl_extinction(pb_lbl *p, double *ext_d, int64_t wbegin, int64_t wcount,
         a.rk_count = staged ? p->ph_count : l->d_gcount;
         a.rk_iown = staged ? p->ph_iown : l->d_giown;
         a.rk_iso = staged ? p->ph_iso : l->d_giso;
+        const double *lead = staged ? p->ph_lead : p->g_lead;
+        a.rk_lwn = lead;
+        a.rk_elow = lead + l->ngroups;
+        a.rk_gf = lead + 2 * l->ngroups;
     }
     a.use_records = use_records ? 1 : 0;
 
@@ -1747,6 +1775,8 @@ void pb_lbl_destroy(pb_lbl *p)
     (void)hipFree(p->ph_iown);
     (void)hipFree(p->ph_start);
     (void)hipFree(p->ph_iso);
+    (void)hipFree(p->ph_lead);
+    (void)hipFree(p->g_lead);
     (void)hipFree(p->rec_k);
     (void)hipFree(p->rec_i32);
     for (hipEvent_t e : p->ev)

@@ -41,6 +41,7 @@ struct pb_lines {
     double own0 = 0.0, own_last = 0.0, ownstep = 0.0;   // from the own[] array
     std::vector<int64_t> iso_gstart;                    // [niso+1] group segments
     std::vector<int32_t> h_gfirst, h_gcount, h_giown;   // host copies of the groups
+    std::vector<double> h_lwn, h_elow, h_gf;            // host copies of the line records
     // device: line records
     double *d_lwn = nullptr, *d_elow = nullptr, *d_gf = nullptr;
     int32_t *d_lid = nullptr;
