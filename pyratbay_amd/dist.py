@@ -165,3 +165,26 @@ class LayerShardedTransit:
         spec, self.depth, self.ideep = e.transit_spectrum(
             ec_cols, m.raypath, m.radius, m.rstar, m.itop, self.nlayers, m.maxdepth)
         return self.gather(spec)
+
+
+def walker_slice(nwalkers, world, rank):
+    """Replica parallelism for retrieval: every GPU holds the
+    full cross-section table and evaluates a contiguous slice of the walker batch."""
+    b = shard_bounds(nwalkers, world)
+    return int(b[rank]), int(b[rank + 1])
+
+
+def gather_walkers(local, nwalkers, world, rank, group=None):
+    """local[n_r, nbands] -> bandflux[nwalkers, nbands] on every rank (one all-gather of
+    equal padded blocks)."""
+    b = shard_bounds(nwalkers, world)
+    pad = int(np.max(np.diff(b)))
+    nb = local.shape[1]
+    send = torch.zeros((pad, nb), dtype=local.dtype, device=local.device)
+    send[:local.shape[0]] = local
+    if world == 1:
+        return local.clone()
+    recv = torch.empty((world * pad, nb), dtype=local.dtype, device=local.device)
+    all_gather_flat(recv.view(-1), send.view(-1), group)
+    blocks = recv.view(world, pad, nb)
+    return torch.cat([blocks[r, :int(b[r + 1] - b[r])] for r in range(world)], dim=0)

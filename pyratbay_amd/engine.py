@@ -505,3 +505,20 @@ class TableSpectrum:
             self.spectrum = emission_flux(self.depth, self.ideep, self.wn, self.temp, self.mu,
                                           self.weights, self.itop)
         return self.spectrum
+
+    def eval_bands(self, temps, dens, bands):
+        """Batched-walker evaluation (the inner loop of a retrieval, pyrat_obj.py:225-385
+        without the parameter mapping): temps[nw, L], dens[nw, L, nspec] device tensors,
+        bands: PassBands on this model's grid -> bandflux[nw, nbands].  Walkers whose
+        temperatures leave the table's range get inf, like eval()'s reject path
+        (pyrat_obj.py:302-320, 378-380)."""
+        nw = temps.shape[0]
+        out = torch.empty((nw, bands.nbands), dtype=torch.float64, device='cuda')
+        ok = ((temps >= self.tmin) & (temps <= self.tmax)).all(dim=1).cpu().numpy()
+        for w in range(nw):
+            if not ok[w]:
+                out[w] = float('inf')
+                continue
+            spec = self.eval(temps[w], dens[w])
+            out[w] = bands.partial_integrate(spec) * bands.heights
+        return out

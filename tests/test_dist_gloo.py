@@ -131,3 +131,26 @@ def test_layer_exchange_two_ranks(tmp_path, nlayers, nwave):
     for rank in range(world):
         ok, nl, nw = np.load(tmp_path / f'ok{rank}.npy')
         assert ok == 1 and nl == nlayers
+
+
+def _worker_walkers(rank, world, port, nwalkers, tmp):
+    sys.path.insert(0, ROOT)
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from pyratbay_amd import dist as pbd
+    full = np.arange(nwalkers * 3, dtype=float).reshape(nwalkers, 3)
+    a, b = pbd.walker_slice(nwalkers, world, rank)
+    out = pbd.gather_walkers(torch.from_numpy(full[a:b].copy()), nwalkers, world, rank)
+    np.save(os.path.join(tmp, f'w{rank}.npy'), out.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_walker_replicas_gather(tmp_path):
+    nwalkers, world = 11, 2
+    mp.spawn(_worker_walkers, args=(world, _free_port(), nwalkers, str(tmp_path)),
+             nprocs=world, join=True)
+    want = np.arange(nwalkers * 3, dtype=float).reshape(nwalkers, 3)
+    for rank in range(world):
+        assert np.array_equal(np.load(tmp_path / f'w{rank}.npy'), want)

@@ -89,3 +89,34 @@ def test_table_eval_vs_oracle_between_nodes(setup, orc):
     depth, ideep = orc.optical_depth_transit(ec, atm['radius'], 0, L, 10.0)
     want = orc.transmission(depth, atm['radius'], atm['rstar'], ideep, 0)
     np.testing.assert_allclose(spec, want, rtol=1e-12)
+
+
+def test_batched_walkers_bandflux(setup, orc):
+    """C5 shape in miniature: several (T, abundance) vectors -> band fluxes; one walker
+    outside the table's temperature range is rejected with inf."""
+    engine, synth, case, vt, ll, lbl = setup
+    g, atm = case['grid'], case['atm']
+    rng = np.random.default_rng(12)
+    nspec, ntemp, L, W = 2, 5, 6, g['nwave']
+    ttable = np.linspace(600, 2600, ntemp)
+    etable = 10.0**rng.uniform(-26, -21, (nspec, ntemp, L, W))
+    model = engine.TableSpectrum(etable, ttable, g['wn'], atm['radius'], atm['rstar'])
+    bands = []
+    for lo, hi in ((20, 500), (450, 1100)):
+        resp = np.exp(-np.linspace(-1, 1, hi - lo)**2)
+        bands.append((lo, resp, 1.0 / np.trapezoid(resp, g['wn'][lo:hi])))
+    pb = engine.PassBands(g['wn'], bands)
+    nw = 4
+    temps = rng.uniform(700, 2500, (nw, L))
+    temps[2, 3] = 2700.0                                   # out of range -> rejected
+    dens = 10.0**rng.uniform(9, 15, (nw, L, nspec))
+    got = model.eval_bands(engine.dev(temps), engine.dev(dens), pb).cpu().numpy()
+    assert np.all(np.isinf(got[2]))
+    for w in (0, 1, 3):
+        ec = np.zeros((L, W))
+        orc.interp_ec(ec, etable, ttable, temps[w], dens[w], 0, L)
+        depth, ideep = orc.optical_depth_transit(ec, atm['radius'], 0, L, 10.0)
+        spec = orc.transmission(depth, atm['radius'], atm['rstar'], ideep, 0)
+        want = [np.trapezoid(spec[s:s + len(r)] * r, g['wn'][s:s + len(r)]) * h
+                for s, r, h in bands]
+        np.testing.assert_allclose(got[w], want, rtol=1e-12)
