@@ -321,13 +321,15 @@ __device__ inline void decode_block(const LblArgs &a, int &tile, int &layer)
 // the records of every RS-th 64-record round); their partial sums are added in wavefront
 // order through LDS.  RS > 1 shortens the critical path of a workgroup RS-fold -- used
 // when the launch has too few workgroups to fill the chip (multi-GPU shards).
-template <int RS>
-__global__ __launch_bounds__(kBlock) void k_ext_resample(LblArgs a)
+template <int RS, int NW>
+__global__ __launch_bounds__(NW * 64) void k_ext_resample(LblArgs a)
 {
-    constexpr int kTileRS = kTile / RS;          // output samples per workgroup
-    __shared__ double s_k[kBlock];
-    __shared__ unsigned s_off[kBlock];
-    __shared__ unsigned s_win[kBlock];           // lo | hi << 16
+    constexpr int NT = NW * 64;                  // threads = records per batch
+    constexpr int kTileRS = (NW / RS) * kWaveSpan;   // output samples per workgroup
+    static_assert(NW % RS == 0, "wavefronts must divide evenly into record shares");
+    __shared__ double s_k[NT];
+    __shared__ unsigned s_off[NT];
+    __shared__ unsigned s_win[NT];               // lo | hi << 16
 
     int tile, layer;
     decode_block(a, tile, layer);
@@ -383,7 +385,7 @@ __global__ __launch_bounds__(kBlock) void k_ext_resample(LblArgs a)
         const int64_t base_idx = a.pm_base[cell_lo] - kTile;       // inside the front pad
         const double *base = a.pm + base_idx;
 
-        for (int64_t gb = g0; gb < g1; gb += kBlock) {
+        for (int64_t gb = g0; gb < g1; gb += NT) {
             __syncthreads();
             // ---- one record per lane: (layer, group) records from k_records ----
             {
@@ -416,9 +418,9 @@ __global__ __launch_bounds__(kBlock) void k_ext_resample(LblArgs a)
             }
             __syncthreads();
             // ---- every wavefront walks the records that reach its samples ----
-            const int nrec = a.experiment == 2 ? 0 : (int)min((int64_t)kBlock, g1 - gb);
+            const int nrec = a.experiment == 2 ? 0 : (int)min((int64_t)NT, g1 - gb);
             for (int b = 0; b < nrec; b += 64) {
-                const int e = (b + lane) & (kBlock - 1);
+                const int e = (b + lane) & (NT - 1);
                 const unsigned my_win = s_win[e];
                 // record g belongs to wavefront share (g / 64) % RS: a property of the
                 // group, not of the tiling, so any tiling adds the same partial sums
@@ -479,7 +481,7 @@ __global__ __launch_bounds__(kBlock) void k_ext_resample(LblArgs a)
 
     if (RS > 1) {
         // partial sums of the wavefronts that share a range, added in wavefront order
-        __shared__ double s_acc[kBlock * kChunks * kLaneSamples];
+        __shared__ double s_acc[NT * kChunks * kLaneSamples];
         __syncthreads();
 #pragma unroll
         for (int s = 0; s < kChunks; s++) {
@@ -1676,19 +1678,26 @@ int pb_lbl_extinction(pb_lbl *p, double *ext_d, int64_t wbegin, int64_t wcount,
         kern<<<grid, kStagedThreads, lds, s>>>(a);
     } else {
         // record splitting when the launch would not fill the chip
-        // (measured at C2: RS=2 beats RS=1 until the launch has ~16k workgroups)
+        // (measured at C2: RS=2 beats RS=1 until the launch has ~16k workgroups; a 16-wave
+        // workgroup with a 16-way split, selectable with PB_RSPLIT=16, measured slower than
+        // RS=4: every wavefront still scans every 64-record round for its share)
         const int64_t tiles1 = pb::div_up(wcount, kTile) * (int64_t)nlayers * a.nrows;
         int RS = tiles1 >= 16000 ? 1 : tiles1 >= 1500 ? 2 : 4;
-        if (const char *e = getenv("PB_RSPLIT"))
-            RS = atoi(e) >= 4 ? 4 : atoi(e) >= 2 ? 2 : 1;
-        a.ntiles = pb::div_up(wcount, kTile / RS);
+        if (const char *e = getenv("PB_RSPLIT")) {
+            const int v_ = atoi(e);
+            RS = v_ >= 16 ? 16 : v_ >= 4 ? 4 : v_ >= 2 ? 2 : 1;
+        }
+        const int tile = RS == 16 ? kWaveSpan : kTile / RS;
+        a.ntiles = pb::div_up(wcount, tile);
         dim3 grid((unsigned)(8 * a.ntiles * layer_groups), a.nrows);
-        if (RS == 4)
-            k_ext_resample<4><<<grid, kBlock, 0, s>>>(a);
+        if (RS == 16)
+            k_ext_resample<16, 16><<<grid, 1024, 0, s>>>(a);
+        else if (RS == 4)
+            k_ext_resample<4, 4><<<grid, kBlock, 0, s>>>(a);
         else if (RS == 2)
-            k_ext_resample<2><<<grid, kBlock, 0, s>>>(a);
+            k_ext_resample<2, 4><<<grid, kBlock, 0, s>>>(a);
         else
-            k_ext_resample<1><<<grid, kBlock, 0, s>>>(a);
+            k_ext_resample<1, 4><<<grid, kBlock, 0, s>>>(a);
     }
     PB_LAUNCH_CHECK();
     if (timed) {
