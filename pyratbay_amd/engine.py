@@ -446,6 +446,30 @@ class LBLSpectrum:
                                           self.mu, self.weights, self.itop)
         return self.spectrum
 
+    def capture(self):
+        """Capture one run() into a HIP graph (torch.cuda.CUDAGraph on a side stream) and
+        return a replay function: the whole step -- layer state, records, gather, optical
+        depth, spectrum -- is then ONE graph launch, with inputs read from and outputs
+        written to the same device buffers (update the atmosphere with set_atmosphere()).
+        The first call allocates workspaces, so it runs once eagerly before the capture."""
+        self.run()
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            self.run()                         # warm-up on the capture stream
+            side.synchronize()
+            with torch.cuda.graph(graph, stream=side):
+                out = self.run()
+        torch.cuda.current_stream().wait_stream(side)
+        self._graph = graph
+
+        def replay():
+            graph.replay()
+            return out
+        return replay
+
     def run(self):
         """One spectrum: the 'extinction', 'odepth' and 'spectrum' stages (the last two
         fused for the transit geometry)."""

@@ -157,3 +157,21 @@ def test_layer_sharded_extinction_equals_single(eng, case, world):
     assert np.array_equal(got, ec_full)
     one = LayerShardedTransit(case, 1, 0)
     assert np.array_equal(one.step().cpu().numpy(), want)
+
+
+def test_hip_graph_replay(eng, case):
+    """The step captured as one HIP graph reproduces the eager spectrum, also after the
+    atmosphere buffers were updated in place."""
+    from pyratbay_amd import synth
+    model = eng.LBLSpectrum(case, rt_path='transit')
+    eager = model.run().cpu().numpy().copy()
+    replay = model.capture()
+    assert np.array_equal(replay().cpu().numpy(), eager)
+    atm, iso = case['atm'], case['iso']
+    temp = atm['temp'] * 1.05
+    isoz = synth.partition_function(temp)[None, :].repeat(len(iso['isomass']), 0)
+    model.set_atmosphere(temp, atm['dens'], isoz)
+    hot = replay().cpu().numpy().copy()
+    fresh = eng.LBLSpectrum(case, rt_path='transit', voigt=model.voigt, lines=model.lines)
+    fresh.set_atmosphere(temp, atm['dens'], isoz)
+    assert np.array_equal(hot, fresh.run().cpu().numpy())

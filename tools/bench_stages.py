@@ -34,3 +34,21 @@ for _ in range(steps):
 print(f'{name} shard 1/{nshard}: extinction {tot[0]/steps:.3f} ms  odepth {tot[1]/steps:.3f} ms  '
       f'spectrum {tot[2]/steps:.3f} ms  total {sum(tot)/steps:.3f} ms '
       f'({steps/sum(tot)*1e3:.1f} spectra/s)')
+
+if os.environ.get('PB_GRAPH') == '1':
+    replay = model.capture()
+    for _ in range(3):
+        replay()
+    torch.cuda.synchronize()
+    import time
+    t0 = time.perf_counter()
+    for _ in range(steps * 5):
+        replay()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / (steps * 5)
+    t0 = time.perf_counter()
+    for _ in range(steps * 5):
+        model.run()
+    torch.cuda.synchronize()
+    de = (time.perf_counter() - t0) / (steps * 5)
+    print(f'{name}: eager {de*1e3:.3f} ms/step, HIP graph replay {dt*1e3:.3f} ms/step')
