@@ -102,11 +102,16 @@ int pb_lbl_create(pb_lbl **out, pb_voigt *voigt, pb_lines *lines,
 /* Change the species-selection flags (isoiext < 0 = neglect; extinction.py:164-167) */
 int pb_lbl_set_isoiext(pb_lbl *p, const int32_t *isoiext_h);
 int pb_lbl_set_ethresh(pb_lbl *p, double ethresh);
-/* Gather-kernel selection for constant-step grids: 0 = automatic (LDS-staged kernel when
- * several lines share a phase row of a tile, else the global gather), 1 = global gather,
- * 2 = LDS-staged (falls back to 1 when a phase row does not fit in LDS).  Both sum the
- * same terms; only the order differs (global: isotope, position; staged: isotope, phase,
- * position).  last_gather_mode reports what the last call ran (3 = resolution mode). */
+/* Gather-kernel selection for constant-step grids.
+ *   0 = automatic: layers whose phase-major profile blocks fit in LDS (narrow profiles) run
+ *       the resident-profile kernel; the others run the LDS-staged kernel when several lines
+ *       share a phase row of a tile, else the global gather;
+ *   1 = global gather only, 2 = LDS-staged only (falls back to 1 when a phase row does not
+ *       fit in LDS), 3 = resident-profile kernel where it applies + global gather.
+ * All sum the same terms; only the order differs (global, resident: isotope, position;
+ * staged: isotope, phase, position).  The choice never depends on the wavenumber shard.
+ * last_gather_mode reports what the last call ran: 1 global, 2 staged, 3 resolution mode,
+ * plus 8 when the resident-profile kernel ran as well. */
 int pb_lbl_set_gather_mode(pb_lbl *p, int mode);
 int pb_lbl_last_gather_mode(const pb_lbl *p, int *mode);
 /* ext_d[nlayers, nrows, wcount] with nrows = 1 if add else (max isoiext)+1, for the
@@ -123,6 +128,11 @@ int pb_lbl_extinction(pb_lbl *p, double *ext_d, int64_t wbegin, int64_t wcount,
  * kmax_h[nlayers*nrows] (per-species maximum line strength, :225). */
 int pb_lbl_last_state(pb_lbl *p, int32_t *ofactor_h, double *kmax_h, int nlayers,
                       int nrows, void *stream);
+/* Which layers of the last call the resident-profile kernel computed (resident_h[nlayers],
+ * 0/1; all 0 when that kernel was off) and the size in doubles of the largest phase-major
+ * profile block each layer can select (block_h[nlayers]).  Synchronises the stream. */
+int pb_lbl_last_layer_kinds(pb_lbl *p, int32_t *resident_h, int32_t *block_h, int nlayers,
+                            void *stream);
 /* Per-launch timing of the gather kernel with HIP events on the call's stream:
  * begin() arms up to max_launches start/stop pairs, every following
  * pb_lbl_extinction records one pair around its gather launch, end() returns the summed

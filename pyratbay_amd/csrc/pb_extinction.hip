@@ -30,6 +30,7 @@
 // table a layer touches -- one Lorentz row, a few Doppler columns -- then stays in
 // that XCD's 4 MiB L2), heaviest (deepest) layers first.
 #include <algorithm>
+#include <climits>
 #include <cmath>
 #include <cstdlib>
 #include <new>
@@ -69,6 +70,10 @@ struct LblArgs {
     // the same groups sorted by (isotope, iown mod osamp, iown) for the staged kernel
     const int32_t *ph_first, *ph_count, *ph_iown;
     const int64_t *ph_start;          // [niso*(osamp+1)+1]
+    // coarse position index of the phase-sorted list: ph_bin[(iso*osamp + p)*(nbins+1) + b] =
+    // first entry of (iso, p) at or after fine position b * kBinSamples * osamp
+    const int32_t *ph_bin;
+    int ph_nbins;
     int rowcap;                       // longest phase row of the table (samples)
     const int32_t *ph_iso;            // isotope of every phase-sorted group
     const int32_t *giso;              // isotope of every position-sorted group
@@ -76,8 +81,15 @@ struct LblArgs {
     // gather kernel reads records (1) or derives them itself (0: resolution mode)
     const int32_t *rk_first, *rk_count, *rk_iown, *rk_iso;
     const double *rk_lwn, *rk_elow, *rk_gf;   // the leader line of every group, same order
+    const double *g_lead;             // leader lines in position order [3][ngroups]
     int use_records;
     int64_t ngroups;
+    // resident-profile kernel: which layers it computes, its LDS capacity (doubles, 0 = off)
+    // and, per isotope, the first position-sorted group at or after every output sample
+    int32_t *ls_resident;
+    int32_t *ls_block;                // largest phase-major profile block of the layer (doubles)
+    int res_cap;
+    const int32_t *gs_start;          // [niso][nwave+1]
     // per (layer, phase-sorted group) records written by k_records [nlayers][ngroups]
     double *rec_k;                    // co-added strength (before threshold / density)
     int32_t *rec_ulo, *rec_uhi;       // window on the global output grid
@@ -127,12 +139,15 @@ __device__ inline double line_strength(double ratio, double gf, double elow, dou
 __global__ __launch_bounds__(64) void k_layer_state(LblArgs a)
 {
     __shared__ unsigned long long s_minwidth;
+    __shared__ int s_block;          // largest phase-major profile block any isotope can use
     const int layer = blockIdx.x;
     const double temp = a.temp[layer];
     const double fdop = sqrt(2 * pb::kKB * temp / pb::kAMU) * pb::kSqrtLn2 / pb::kLS;
     const double flor = sqrt(2 * pb::kKB * temp / pb::kPi / pb::kAMU) / pb::kLS;
-    if (threadIdx.x == 0)
+    if (threadIdx.x == 0) {
         s_minwidth = __double_as_longlong(1e5);
+        s_block = 0;
+    }
     for (int r = threadIdx.x; r < a.nrows; r += 64)
         a.kmax_bits[(int64_t)layer * a.nrows + r] = 0ull;
     __syncthreads();
@@ -153,6 +168,17 @@ __global__ __launch_bounds__(64) void k_layer_state(LblArgs a)
         int hmax = 0;
         for (int d = 0; d < a.ndop; d++)
             hmax = max(hmax, a.psize[ilor * a.ndop + d]);
+        // the resident kernel stages whole cells: only the Doppler columns that lines on
+        // this grid can select matter (one column of margin on both sides)
+        {
+            const int dlo = max(0, pb::nearest_index(a.doppler, alphad * a.own0, 0, a.ndop - 1) - 1);
+            const int dhi = min(a.ndop - 1,
+                                pb::nearest_index(a.doppler, alphad * a.own_last, 0, a.ndop - 1) + 1);
+            int used = 0;
+            for (int d = dlo; d <= dhi; d++)
+                used = max(used, a.pm_stride[ilor * a.ndop + d]);
+            atomicMax(&s_block, used * a.osamp);
+        }
         const int64_t k = (int64_t)layer * a.niso + i;
         a.li_alphad[k] = alphad;
         a.li_ilor[k] = ilor;
@@ -172,6 +198,8 @@ __global__ __launch_bounds__(64) void k_layer_state(LblArgs a)
         a.ls_dwnstep[layer] = a.ownstep * ofactor;
         a.ls_dnwn[layer] = 1 + (a.onwn - 1) / ofactor;
         a.ls_scale[layer] = (int)round(a.wnstep / a.ownstep / ofactor);
+        a.ls_resident[layer] = a.res_cap > 0 && s_block <= a.res_cap;
+        a.ls_block[layer] = s_block;
     }
 }
 
@@ -333,7 +361,7 @@ __global__ __launch_bounds__(NW * 64) void k_ext_resample(LblArgs a)
 
     int tile, layer;
     decode_block(a, tile, layer);
-    if (layer < 0)
+    if (layer < 0 || (a.res_cap > 0 && a.ls_resident[layer]))
         return;
     const int row = blockIdx.y;
     const int lane = threadIdx.x & 63;
@@ -537,8 +565,17 @@ __global__ __launch_bounds__(kBlock) void k_records(LblArgs a)
     __syncthreads();
     double k = 0.0, lmax = 0.0;
     int ulo = 0, uhi = 0, q = 0, cell = 0, phi = 0, row = -1;
+    // layers of the resident-profile kernel are walked in position order
+    const bool pos = a.res_cap > 0 && a.ls_resident[layer];
+    const int32_t *rk_iso = pos ? a.giso : a.rk_iso;
+    const int32_t *rk_first = pos ? a.gfirst : a.rk_first;
+    const int32_t *rk_count = pos ? a.gcount : a.rk_count;
+    const int32_t *rk_iown = pos ? a.giown : a.rk_iown;
+    const double *rk_lwn = pos ? a.g_lead : a.rk_lwn;
+    const double *rk_elow = pos ? a.g_lead + a.ngroups : a.rk_elow;
+    const double *rk_gf = pos ? a.g_lead + 2 * a.ngroups : a.rk_gf;
     if (g < a.ngroups) {
-        const int iso = a.rk_iso[g];
+        const int iso = rk_iso[g];
         row = a.isoiext[iso];
         if (row >= 0 && a.add)
             row = 0;
@@ -547,11 +584,11 @@ __global__ __launch_bounds__(kBlock) void k_records(LblArgs a)
             const double temp = a.temp[layer];
             const double ratio = a.isoratio[iso];
             const double z = a.li_z[li];
-            const int first = a.rk_first[g];
-            const int count = a.rk_count[g];
-            const int iown = a.rk_iown[g];
-            const double wavn = a.rk_lwn[g];          // leader's record, in walk order
-            k = line_strength(ratio, a.rk_gf[g], a.rk_elow[g], wavn, temp, z);
+            const int first = rk_first[g];
+            const int count = rk_count[g];
+            const int iown = rk_iown[g];
+            const double wavn = rk_lwn[g];            // leader's record, in walk order
+            k = line_strength(ratio, rk_gf[g], rk_elow[g], wavn, temp, z);
             lmax = k;
             for (int m = 1; m < count; m++) {
                 const double kp = line_strength(ratio, a.gf[first + m], a.elow[first + m],
@@ -608,6 +645,7 @@ __global__ __launch_bounds__(kBlock) void k_records(LblArgs a)
 // A lane owns the samples rlo + 64*c + lane (c < 4*G); a wavefront tests a record's
 // window against groups of 4 chunks with scalar compares.
 // ---------------------------------------------------------------------------
+constexpr int kBinSamples = 256;     // output samples per bin of the phase-list position index
 constexpr int kStagePad = 256;       // zero samples on either side of a staged row
 constexpr int kStageSpan = 256;      // samples per wavefront and sub-tile (4 chunks of 64)
 constexpr int kStageRowMax = 1024;   // longest phase row the kernel stages
@@ -644,7 +682,7 @@ __global__ __launch_bounds__(NW * 64, 8) void k_ext_staged(LblArgs a)
 
     int tile, layer;
     decode_block(a, tile, layer);
-    if (layer < 0)
+    if (layer < 0 || (a.res_cap > 0 && a.ls_resident[layer]))
         return;
     const int row = blockIdx.y;
     const int tid = threadIdx.x;
@@ -669,15 +707,22 @@ __global__ __launch_bounds__(NW * 64, 8) void k_ext_staged(LblArgs a)
 
     // Row of one segment -> registers (issued early), registers -> LDS (after the walk).
     double rowreg[2][kRowRegs];
+    // out-of-window lanes fall outside the buffer descriptor and read 0 (no predicate)
     auto load_row = [&](int sg, double (&reg)[kRowRegs]) {
         const int i0 = __builtin_amdgcn_readfirstlane((int)(s_seg[sg] & 0xffff));
         const unsigned m = (unsigned)__builtin_amdgcn_readfirstlane((int)s_m[i0]);
         const int mlo = (int)(m & 0xffff), mhi = (int)(m >> 16);
-        const double *src = a.pm + s_src[i0];
+        const long long so = s_src[i0];
+        const long long so_u = ((long long)__builtin_amdgcn_readfirstlane((int)(so >> 32)) << 32) |
+                               (unsigned)__builtin_amdgcn_readfirstlane((int)so);
+        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+            (void *)(a.pm + so_u + mlo), 0, (mhi - mlo) * 8, 0x00020000);
+        typedef int v2i __attribute__((ext_vector_type(2)));
 #pragma unroll
         for (int r = 0; r < kRowRegs; r++) {
-            const int mm = tid + r * kThreads;
-            reg[r] = (mm >= mlo && mm < mhi) ? src[mm] : 0.0;
+            const v2i v = __builtin_amdgcn_raw_buffer_load_b64(
+                rsrc, (tid + r * kThreads - mlo) * 8, 0, 0);
+            reg[r] = __hiloint2double(v.y, v.x);
         }
     };
     auto store_row = [&](int buf, const double (&reg)[kRowRegs]) {
@@ -710,10 +755,14 @@ __global__ __launch_bounds__(NW * 64, 8) void k_ext_staged(LblArgs a)
         for (int r = 0; r < per; r++) {
             const int p = tid * per + r;
             if (p < osamp) {
-                const int64_t seg0 = a.ph_start[(int64_t)iso * (osamp + 1) + p];
-                const int64_t seg1 = a.ph_start[(int64_t)iso * (osamp + 1) + p + 1];
-                const int64_t s0 = lower_bound_i32(a.ph_iown, seg0, seg1, flo);
-                const int64_t s1 = lower_bound_i32(a.ph_iown, seg0, seg1, fhi + 1);
+                // two table lookups bracket each bound to within one bin (a fraction of a
+                // record per phase), then a short bisection makes it exact
+                const int32_t *bin = a.ph_bin + ((int64_t)iso * osamp + p) * (a.ph_nbins + 1);
+                const int64_t binw = (int64_t)kBinSamples * osamp;
+                const int b0 = (int)min((int64_t)a.ph_nbins - 1, max((int64_t)0, flo) / binw);
+                const int b1 = (int)min((int64_t)a.ph_nbins - 1, max((int64_t)0, fhi + 1) / binw);
+                const int64_t s0 = lower_bound_i32(a.ph_iown, bin[b0], bin[b0 + 1], flo);
+                const int64_t s1 = lower_bound_i32(a.ph_iown, bin[b1], bin[b1 + 1], fhi + 1);
                 s_phs[p] = (int)s0;
                 s_cum[p] = (int)(s1 - s0);
                 mine += (int)(s1 - s0);
@@ -840,57 +889,76 @@ __global__ __launch_bounds__(NW * 64, 8) void k_ext_staged(LblArgs a)
             // ---- rows are double-buffered in LDS and fetched two segments ahead: segment
             // sg+2's row is already in flight (in registers) while sg is walked, and is
             // written to the free LDS buffer one segment later ----
-            auto walk = [&](int sg, int buf) {
-                const unsigned sd = (unsigned)__builtin_amdgcn_readfirstlane((int)s_seg[sg]);
+            // Lane l of every wavefront keeps, for segment (sg & ~63) + l, the records that
+            // reach each of the wavefront's sub-tiles: first | count << 16.  The records of a
+            // segment have equal window lengths and ascending positions, so those are
+            // consecutive and two bisections find them; 64 segments are done at once.
+            unsigned hits[S];
+            auto find_hits = [&](int sg0) {
+                const int sgl = sg0 + lane;
+                const unsigned sd = sgl < nseg ? s_seg[sgl] : 0u;
                 const int i0 = (int)(sd & 0xffff), i1 = (int)(sd >> 16);
+#pragma unroll
+                for (int u = 0; u < S; u++) {
+                    const int slo = rlo + u * kSub;
+                    int lo = i0, hi = i1;              // first record with window end > slo
+                    while (lo < hi) {
+                        const int mid = (lo + hi) >> 1;
+                        if ((int)(s_rec[mid].win >> 16) > slo)
+                            hi = mid;
+                        else
+                            lo = mid + 1;
+                    }
+                    const int first = lo;
+                    hi = i1;                           // first record starting at or after the end
+                    while (lo < hi) {
+                        const int mid = (lo + hi) >> 1;
+                        if ((int)(s_rec[mid].win & 0xffff) >= slo + kStageSpan)
+                            hi = mid;
+                        else
+                            lo = mid + 1;
+                    }
+                    hits[u] = slo < tlen ? (unsigned)first | ((unsigned)(lo - first) << 16) : 0u;
+                }
+            };
+            auto walk = [&](int sg, int buf) {
+                if ((sg & 63) == 0)
+                    find_hits(sg);
                 // byte address of this lane's first sample in the staged row
                 const char *rowp = reinterpret_cast<const char *>(
                     s_row + kStagePad + buf * rowspan + rlo + lane);
-                // The records of a segment have equal window lengths and ascending
-                // positions, so the ones that reach a sub-tile range are consecutive.
-                for (int b = i0; b < i1; b += 64) {
-                    const int e = b + lane;
-                    const unsigned my_win = e < i1 ? s_rec[e].win : 0u;
-                    const int my_lo = (int)(my_win & 0xffff), my_hi = (int)(my_win >> 16);
 #pragma unroll
-                    for (int u = 0; u < S; u++) {
-                        const int ulo_ = rlo + u * kSub;
-                        if (ulo_ >= tlen)
-                            continue;
-                        const unsigned long long mask =
-                            __ballot(my_lo < ulo_ + kStageSpan && my_hi > ulo_);
-                        if (!mask || a.experiment == 2)
-                            continue;
-                        const int first =
-                            b + __builtin_amdgcn_readfirstlane(__builtin_ctzll(mask));
-                        const int last =
-                            first + __builtin_amdgcn_readfirstlane(__builtin_popcountll(mask));
-                        // per record: ONE 16-byte broadcast read of {k, offset, window}, four
-                        // 64-sample row reads, four fma; four records per trip
-                        const char *rs = rowp + (size_t)u * kSub * 8;
-                        const double2 *recs = reinterpret_cast<const double2 *>(s_rec);
-                        auto visit = [&](const double2 raw) {
-                            const double k = raw.x;
-                            const int qoff = __double2loint(raw.y);
-                            const double *p0 = reinterpret_cast<const double *>(rs + qoff);
-                            const double a0 = p0[0], a1 = p0[64], a2 = p0[128], a3 = p0[192];
-                            acc[u][0] = fma(k, a0, acc[u][0]);
-                            acc[u][1] = fma(k, a1, acc[u][1]);
-                            acc[u][2] = fma(k, a2, acc[u][2]);
-                            acc[u][3] = fma(k, a3, acc[u][3]);
-                        };
-                        int r = first;
-                        for (; r + 3 < last; r += 4) {
-                            const double2 w0 = recs[r], w1 = recs[r + 1], w2 = recs[r + 2],
-                                          w3 = recs[r + 3];
-                            visit(w0);
-                            visit(w1);
-                            visit(w2);
-                            visit(w3);
-                        }
-                        for (; r < last; r++)
-                            visit(recs[r]);
+                for (int u = 0; u < S; u++) {
+                    const unsigned h = (unsigned)__builtin_amdgcn_readlane((int)hits[u], sg & 63);
+                    if (h < 0x10000u || a.experiment == 2)
+                        continue;
+                    const int first = (int)(h & 0xffff);
+                    const int last = first + (int)(h >> 16);
+                    // per record: ONE 16-byte broadcast read of {k, offset, window}, four
+                    // 64-sample row reads, four fma; four records per trip
+                    const char *rs = rowp + (size_t)u * kSub * 8;
+                    const double2 *recs = reinterpret_cast<const double2 *>(s_rec);
+                    auto visit = [&](const double2 raw) {
+                        const double k = raw.x;
+                        const int qoff = __double2loint(raw.y);
+                        const double *p0 = reinterpret_cast<const double *>(rs + qoff);
+                        const double a0 = p0[0], a1 = p0[64], a2 = p0[128], a3 = p0[192];
+                        acc[u][0] = fma(k, a0, acc[u][0]);
+                        acc[u][1] = fma(k, a1, acc[u][1]);
+                        acc[u][2] = fma(k, a2, acc[u][2]);
+                        acc[u][3] = fma(k, a3, acc[u][3]);
+                    };
+                    int r = first;
+                    for (; r + 3 < last; r += 4) {
+                        const double2 w0 = recs[r], w1 = recs[r + 1], w2 = recs[r + 2],
+                                      w3 = recs[r + 3];
+                        visit(w0);
+                        visit(w1);
+                        visit(w2);
+                        visit(w3);
                     }
+                    for (; r < last; r++)
+                        visit(recs[r]);
                 }
             };
             if (a.experiment == 5)
@@ -932,6 +1000,189 @@ __global__ __launch_bounds__(NW * 64, 8) void k_ext_staged(LblArgs a)
             if (j < tlen)
                 dst[j] = acc[u][c];
         }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// 3a''. Resident-profile gather (constant-step grid), for layers whose profiles are narrow:
+// the WHOLE phase-major block of a table cell (osamp rows of a few tens of samples,
+// <= res_cap doubles) is copied into LDS once per (workgroup, isotope, cell), and then
+// every lane owns ONE output sample and walks, in position order, the records whose window
+// reaches its wavefront's 64 samples: one 16-byte broadcast read of the record, one
+// `ds_read_b64` of row[phi][sample + q] and one fma per (record, 64 samples), with a
+// per-lane window predicate that redirects outside lanes to a zero slot.
+// With ~20-sample rows a record costs 64 lanes of work instead of the 256 (staged) or 512
+// (global) of the kernels above, and there are no per-phase segments to synchronise on.
+// The terms of a sample are added in (isotope, position) order -- the order of the global
+// gather -- whatever the tiling.
+// ---------------------------------------------------------------------------
+constexpr int kResWaves = 8;
+constexpr int kResThreads = kResWaves * 64;
+constexpr int kResStrips = 2;                              // 64-sample strips per wavefront
+constexpr int kResTile = kResThreads * kResStrips;         // output samples per workgroup
+constexpr int kResCapDefault = 8192;                       // doubles of LDS for one profile block
+static_assert(kResTile < 65536, "window coordinates are packed in 16 bits");
+
+__global__ __launch_bounds__(kResThreads) void k_ext_resident(LblArgs a)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    struct __align__(16) Rec {
+        double k;
+        int off;                  // LDS byte offset of tile sample 0 in the record's phase row
+        unsigned win;             // lo | length << 16 (tile coordinates)
+    };
+    double *s_prof = reinterpret_cast<double *>(smem);                   // [res_cap] + zero slot
+    const int zslot = a.res_cap;
+    Rec *s_rec = reinterpret_cast<Rec *>(s_prof + a.res_cap + 2);        // [kResThreads]
+    int *s_cell = reinterpret_cast<int *>(s_rec + kResThreads);          // [kResThreads]
+    int *s_part = s_cell + kResThreads;                                  // [kResWaves]
+
+    int tile, layer;
+    decode_block(a, tile, layer);
+    if (layer < 0 || !a.ls_resident[layer])
+        return;
+    const int row = blockIdx.y;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    const int64_t t0 = a.wbegin + (int64_t)tile * kResTile;
+    const int64_t tend = min(t0 + kResTile, a.wbegin + a.wcount);
+    const int tlen = (int)(tend - t0);
+    const double kthresh =
+        a.ethresh * __longlong_as_double((long long)a.kmax_bits[(int64_t)layer * a.nrows + row]);
+    const int64_t recbase = (int64_t)layer * a.ngroups;
+    const int osamp = a.osamp;
+    const int ofactor = a.ls_ofactor[layer];
+
+    double acc[kResStrips];
+#pragma unroll
+    for (int u = 0; u < kResStrips; u++)
+        acc[u] = 0.0;
+    if (tid == 0)
+        s_prof[zslot] = 0.0;
+
+    for (int iso = 0; iso < a.niso; iso++) {
+        const int iext = a.isoiext[iso];
+        if (iext < 0 || (a.add ? 0 : iext) != row)
+            continue;
+        const int64_t li = (int64_t)layer * a.niso + iso;
+        const double dens = a.li_dens[li];
+        int64_t reach = a.li_hmax[li];
+        if (a.cutoff > 0.0)
+            reach = min(reach, (int64_t)(a.cutoff / a.ownstep) + 2 * (int64_t)ofactor + 2);
+        reach += osamp + ofactor;
+        // candidates: groups at fine positions [t0*osamp - reach, (tend-1)*osamp + reach],
+        // bracketed through the per-sample index of the position-sorted list
+        const int64_t rs = reach / osamp + 1;
+        const int32_t *gs = a.gs_start + (int64_t)iso * (a.nwave + 1);
+        const int64_t g0 = gs[max((int64_t)0, t0 - rs)];
+        const int64_t g1 = gs[min((int64_t)a.nwave, tend + rs)];
+
+        for (int64_t gb = g0; gb < g1; gb += kResThreads) {
+            const int nrec = (int)min((int64_t)kResThreads, g1 - gb);
+            __syncthreads();               // the previous walk has finished with s_rec / s_prof
+            {
+                double k = 0.0;
+                unsigned win = 0;
+                int off = 0, cell = -1;
+                if (tid < nrec) {
+                    const int64_t idx = recbase + gb + tid;
+                    k = a.rec_k[idx];
+                    const int ulo = a.rec_ulo[idx], uhi = a.rec_uhi[idx];
+                    const int lo = (int)(max((int64_t)ulo, t0) - t0);
+                    const int hi = (int)(min((int64_t)uhi, tend) - t0);
+                    if (!(k < kthresh) && lo < hi) {
+                        if (a.add)
+                            k *= dens;
+                        cell = a.rec_cell[idx];
+                        win = (unsigned)lo | ((unsigned)(hi - lo) << 16);
+                        // tile sample j reads s_prof[phi*stride + (j + t0 + q)]
+                        off = 8 * (a.rec_phi[idx] * a.pm_stride[cell] + (int)(a.rec_q[idx] + t0));
+                    } else {
+                        k = 0.0;
+                    }
+                }
+                s_rec[tid].k = k;
+                s_rec[tid].off = off;
+                s_rec[tid].win = win;
+                s_cell[tid] = cell;
+            }
+            // the cells of a batch, in ascending order (the Doppler index grows with position)
+            int cur = -1;
+            for (;;) {
+                __syncthreads();
+                int c = s_cell[tid];
+                c = c > cur ? c : INT_MAX;
+#pragma unroll
+                for (int d = 32; d >= 1; d >>= 1)
+                    c = min(c, __shfl_xor(c, d));
+                if (lane == 0)
+                    s_part[wave] = c;
+                __syncthreads();
+                c = INT_MAX;
+                for (int w = 0; w < kResWaves; w++)
+                    c = min(c, s_part[w]);
+                if (c == INT_MAX)
+                    break;
+                cur = c;
+                // ---- the cell's phase-major block -> LDS ----
+                {
+                    const int n = a.pm_stride[cur] * osamp;
+                    const double *src = a.pm + a.pm_base[cur];
+                    for (int i = tid; i < n; i += kResThreads)
+                        s_prof[i] = src[i];
+                }
+                __syncthreads();
+                // ---- every wavefront walks the records that reach its strips ----
+                const double2 *recs = reinterpret_cast<const double2 *>(s_rec);
+#pragma unroll
+                for (int u = 0; u < kResStrips; u++) {
+                    const int slo = (wave + u * kResWaves) * 64;
+                    if (slo >= tlen)
+                        continue;
+                    int first = INT_MAX, last = -1;
+                    for (int b = 0; b < nrec; b += 64) {
+                        const int e = b + lane;            // < kResThreads
+                        const unsigned w = s_rec[e].win;
+                        const int wlo = (int)(w & 0xffff);
+                        const bool hit = s_cell[e] == cur && wlo < slo + 64 &&
+                                         wlo + (int)(w >> 16) > slo;
+                        const unsigned long long m = __ballot(hit);
+                        if (m) {
+                            first = min(first, b + (int)__builtin_ctzll(m));
+                            last = max(last, b + 63 - (int)__builtin_clzll(m));
+                        }
+                    }
+                    first = __builtin_amdgcn_readfirstlane(first);
+                    last = __builtin_amdgcn_readfirstlane(last);
+                    const unsigned j = (unsigned)(slo + lane);
+                    typedef __attribute__((address_space(3))) const double lds_double;
+                    // LDS byte addresses: the lane's sample in row 0, and the zero slot
+                    const unsigned prof0 = (unsigned)(uintptr_t)(
+                        (__attribute__((address_space(3))) const char *)s_prof);
+                    const unsigned j8 = prof0 + j * 8u, z8 = prof0 + (unsigned)zslot * 8u;
+                    double sum = acc[u];
+#pragma unroll 4
+                    for (int r = first; r <= last; r++) {
+                        const double2 raw = recs[r];
+                        const unsigned w = (unsigned)__double2hiint(raw.y);
+                        const bool in = j - (w & 0xffffu) < (w >> 16);
+                        const unsigned at = in ? j8 + (unsigned)__double2loint(raw.y) : z8;
+                        sum = fma(raw.x, *(lds_double *)(uintptr_t)at, sum);
+                    }
+                    acc[u] = sum;
+                }
+            }
+        }
+    }
+
+    double *dst = a.ext + ((int64_t)layer * a.nrows + row) * a.wcount + (t0 - a.wbegin);
+#pragma unroll
+    for (int u = 0; u < kResStrips; u++) {
+        const int j = (wave + u * kResWaves) * 64 + lane;
+        if (j < tlen)
+            dst[j] = acc[u];
     }
 }
 
@@ -1128,13 +1379,19 @@ struct pb_lbl {
     int32_t *ph_first = nullptr, *ph_count = nullptr, *ph_iown = nullptr;
     int64_t *ph_start = nullptr;
     int32_t *ph_iso = nullptr;
+    int32_t *ph_bin = nullptr;
+    int ph_nbins = 0;
     double *ph_lead = nullptr;       // leader lwn, elow, gf of the phase-sorted groups [3][G]
     double *g_lead = nullptr;        // same for the position-sorted groups
     double *rec_k = nullptr;
     int32_t *rec_i32 = nullptr;      // 5 arrays of max_layers*ngroups
     int rowcap = 0;
-    int gather_mode = 0;     // 0 = choose, 1 = global gather, 2 = LDS-staged
-    int last_gather = 0;     // kernel used by the last call: 1 global, 2 staged, 3 linterp
+    int32_t *ls_resident = nullptr;   // [max_layers]
+    int32_t *ls_block = nullptr;      // [max_layers]
+    int32_t *gs_start = nullptr;      // [niso][nwave+1]
+    int res_cap = 0;                  // LDS doubles of one resident profile block (0 = none fits)
+    int gather_mode = 0;     // 0 = choose, 1 = global gather, 2 = LDS-staged, 3 = resident+global
+    int last_gather = 0;     // last call: 1 global, 2 staged, 3 linterp; +8 = resident kernel too
     double stage_threshold = 8.0;   // groups per (2048-sample tile, phase) to go staged
     // optional per-launch timing of the gather kernel (bench.py's roofline figure)
     std::vector<hipEvent_t> ev;      // start/stop pairs
@@ -1378,6 +1635,8 @@ int pb_lbl_create(pb_lbl **out, pb_voigt *voigt, pb_lines *lines, const double *
     alloc((void **)&p->li_ilor, LI * 4);
     alloc((void **)&p->li_hmax, LI * 4);
     alloc((void **)&p->kmax_bits, L * (size_t)rows * 8);
+    alloc((void **)&p->ls_resident, L * 4);
+    alloc((void **)&p->ls_block, L * 4);
     if (rc == PB_OK && !resolution) {
         // groups re-sorted by (isotope, iown mod osamp, iown): all lines that read the same
         // phase row of a profile become neighbours (k_ext_staged)
@@ -1413,6 +1672,26 @@ int pb_lbl_create(pb_lbl **out, pb_voigt *voigt, pb_lines *lines, const double *
         if (rc == PB_OK) rc = upload(&p->ph_iown, w.data(), ng);
         if (rc == PB_OK) rc = upload(&p->ph_start, start.data(), start.size());
         {
+            // position index of every (isotope, phase) run, one entry per kBinSamples samples
+            const int nbins = (int)pb::div_up((int64_t)nwave, (int64_t)kBinSamples) + 1;
+            const int64_t binw = (int64_t)kBinSamples * osamp;
+            std::vector<int32_t> bins((size_t)niso * osamp * ((size_t)nbins + 1));
+            for (int i = 0; i < niso; i++)
+                for (int ph = 0; ph < osamp; ph++) {
+                    int64_t k = start[(size_t)i * (osamp + 1) + ph];
+                    const int64_t kend = start[(size_t)i * (osamp + 1) + ph + 1];
+                    int32_t *row = bins.data() + ((size_t)i * osamp + ph) * ((size_t)nbins + 1);
+                    for (int b = 0; b < nbins; b++) {
+                        while (k < kend && (int64_t)w[(size_t)k] < b * binw)
+                            k++;
+                        row[b] = (int32_t)k;
+                    }
+                    row[nbins] = (int32_t)kend;
+                }
+            p->ph_nbins = nbins;
+            if (rc == PB_OK) rc = upload(&p->ph_bin, bins.data(), bins.size());
+        }
+        {
             std::vector<int32_t> iso_of(ng);
             for (int i = 0; i < niso; i++)
                 for (int64_t k = lines->iso_gstart[i]; k < lines->iso_gstart[i + 1]; k++)
@@ -1437,10 +1716,31 @@ int pb_lbl_create(pb_lbl **out, pb_voigt *voigt, pb_lines *lines, const double *
             if (rc == PB_OK) rc = upload(&p->g_lead, glead.data(), glead.size());
         }
         // per (layer, group) records of k_records: allocated on first use
-        int cap = 0;
-        for (int32_t st : voigt->pm_stride)
+        int cap = 0, smallest = INT_MAX;
+        for (int32_t st : voigt->pm_stride) {
             cap = std::max(cap, st);
+            smallest = std::min(smallest, st);
+        }
         p->rowcap = cap;
+        // resident-profile kernel: 64 KiB of LDS for one cell's phase-major block
+        if (ng > 0 && (int64_t)smallest * osamp <= kResCapDefault)
+            p->res_cap = kResCapDefault;
+        if (const char *e = getenv("PB_RESIDENT_CAP"))
+            p->res_cap = std::max(0, std::min(atoi(e), 19000));
+        if (p->res_cap > 0) {
+            // first position-sorted group of every isotope at or after each output sample
+            std::vector<int32_t> gs((size_t)niso * ((size_t)nwave + 1));
+            for (int i = 0; i < niso; i++) {
+                int64_t g = lines->iso_gstart[i];
+                const int64_t gend = lines->iso_gstart[i + 1];
+                for (int64_t w = 0; w <= nwave; w++) {
+                    while (g < gend && (int64_t)lines->h_giown[(size_t)g] < w * osamp)
+                        g++;
+                    gs[(size_t)i * ((size_t)nwave + 1) + (size_t)w] = (int32_t)g;
+                }
+            }
+            if (rc == PB_OK) rc = upload(&p->gs_start, gs.data(), gs.size());
+        }
     }
     {
         const char *e = getenv("PB_GATHER");
@@ -1474,7 +1774,7 @@ int pb_lbl_set_isoiext(pb_lbl *p, const int32_t *isoiext_h)
 
 int pb_lbl_set_gather_mode(pb_lbl *p, int mode)
 {
-    PB_REQUIRE(p && mode >= 0 && mode <= 2, "pb_lbl_set_gather_mode: mode must be 0, 1 or 2");
+    PB_REQUIRE(p && mode >= 0 && mode <= 3, "pb_lbl_set_gather_mode: mode must be 0..3");
     p->gather_mode = mode;
     return PB_OK;
 }
@@ -1542,6 +1842,12 @@ int pb_lbl_extinction(pb_lbl *p, double *ext_d, int64_t wbegin, int64_t wcount,
     a.ph_start = p->ph_start;
     a.rowcap = p->rowcap;
     a.ph_iso = p->ph_iso;
+    a.ph_bin = p->ph_bin;
+    a.ph_nbins = p->ph_nbins;
+    a.g_lead = p->g_lead;
+    a.ls_resident = p->ls_resident;
+    a.ls_block = p->ls_block;
+    a.gs_start = p->gs_start;
     a.giso = l->d_giso;
     a.ngroups = l->ngroups;
     a.inv_osamp = 1.0 / (double)v->osamp;
@@ -1610,6 +1916,11 @@ int pb_lbl_extinction(pb_lbl *p, double *ext_d, int64_t wbegin, int64_t wcount,
                                       (p->gather_mode == 0 && enough_blocks &&
                                        per_phase >= p->stage_threshold));
     const bool use_records = !p->resolution && l->ngroups > 0;
+    // layers with narrow profiles go to the resident-profile kernel (decided per layer on
+    // the device, from the layer alone); the kernel chosen above computes the others
+    const bool resident = use_records && p->res_cap > 0 && p->gs_start &&
+                          (p->gather_mode == 0 || p->gather_mode == 3);
+    a.res_cap = resident ? p->res_cap : 0;
     if (use_records && !p->rec_k) {
         const size_t n = (size_t)p->max_layers * (size_t)l->ngroups;
         if (hipMalloc(&p->rec_k, n * 8) != hipSuccess ||
@@ -1654,7 +1965,18 @@ int pb_lbl_extinction(pb_lbl *p, double *ext_d, int64_t wbegin, int64_t wcount,
     const bool timed = p->ev_used + 2 <= (int)p->ev.size();
     if (timed)
         PB_HIP(hipEventRecord(p->ev[p->ev_used], s));
-    p->last_gather = p->resolution ? 3 : staged ? 2 : 1;
+    p->last_gather = (p->resolution ? 3 : staged ? 2 : 1) + (resident ? 8 : 0);
+    if (resident) {
+        a.ntiles = pb::div_up(wcount, kResTile);
+        dim3 grid((unsigned)(8 * a.ntiles * layer_groups), a.nrows);
+        const size_t rlds = ((size_t)a.res_cap + 2) * 8 + (size_t)kResThreads * (16 + 4) +
+                            kResWaves * 4 + 64;
+        if (rlds > 64 * 1024)
+            PB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ext_resident),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)rlds));
+        k_ext_resident<<<grid, kResThreads, rlds, s>>>(a);
+        PB_LAUNCH_CHECK();
+    }
     if (p->resolution) {
         a.ntiles = pb::div_up(wcount, kBlock);
         dim3 grid((unsigned)(8 * a.ntiles * layer_groups), a.nrows);
@@ -1757,6 +2079,19 @@ int pb_lbl_last_state(pb_lbl *p, int32_t *ofactor_h, double *kmax_h, int nlayers
     return PB_OK;
 }
 
+int pb_lbl_last_layer_kinds(pb_lbl *p, int32_t *resident_h, int32_t *block_h, int nlayers,
+                            void *stream)
+{
+    PB_REQUIRE(p, "pb_lbl_last_layer_kinds: null handle");
+    PB_REQUIRE(nlayers >= 1 && nlayers <= p->max_layers, "pb_lbl_last_layer_kinds: bad sizes");
+    PB_HIP(hipStreamSynchronize(pb::as_stream(stream)));
+    if (resident_h)
+        PB_HIP(hipMemcpy(resident_h, p->ls_resident, (size_t)nlayers * 4, hipMemcpyDeviceToHost));
+    if (block_h)
+        PB_HIP(hipMemcpy(block_h, p->ls_block, (size_t)nlayers * 4, hipMemcpyDeviceToHost));
+    return PB_OK;
+}
+
 void pb_lbl_destroy(pb_lbl *p)
 {
     if (!p)
@@ -1771,6 +2106,9 @@ void pb_lbl_destroy(pb_lbl *p)
     (void)hipFree(p->d_isoiext);
     (void)hipFree(p->ls_ofactor);
     (void)hipFree(p->ls_scale);
+    (void)hipFree(p->ls_resident);
+    (void)hipFree(p->ls_block);
+    (void)hipFree(p->gs_start);
     (void)hipFree(p->ls_dnwn);
     (void)hipFree(p->ls_dwnstep);
     (void)hipFree(p->li_alphad);
@@ -1784,6 +2122,7 @@ void pb_lbl_destroy(pb_lbl *p)
     (void)hipFree(p->ph_iown);
     (void)hipFree(p->ph_start);
     (void)hipFree(p->ph_iso);
+    (void)hipFree(p->ph_bin);
     (void)hipFree(p->ph_lead);
     (void)hipFree(p->g_lead);
     (void)hipFree(p->rec_k);

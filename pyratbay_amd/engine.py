@@ -168,17 +168,18 @@ class LBL:
     def set_ethresh(self, ethresh):
         call('pb_lbl_set_ethresh', self._h, float(ethresh))
 
-    GATHER = {'auto': 0, 'global': 1, 'staged': 2}
+    GATHER = {'auto': 0, 'global': 1, 'staged': 2, 'resident': 3}
 
     def set_gather_mode(self, mode):
-        """'auto' | 'global' | 'staged' (see pbhip.h: pb_lbl_set_gather_mode)."""
+        """'auto' | 'global' | 'staged' | 'resident' (see pbhip.h: pb_lbl_set_gather_mode)."""
         call('pb_lbl_set_gather_mode', self._h, self.GATHER[mode])
 
     @property
     def last_gather_kernel(self):
         m = C.c_int(0)
         call('pb_lbl_last_gather_mode', self._h, C.byref(m))
-        return {0: None, 1: 'k_ext_resample', 2: 'k_ext_staged', 3: 'k_ext_linterp'}[m.value]
+        base = {0: None, 1: 'k_ext_resample', 2: 'k_ext_staged', 3: 'k_ext_linterp'}[m.value & 7]
+        return 'k_ext_resident+' + base if m.value & 8 else base
 
     def extinction(self, temp, dens, isoz, add=True, out=None, wbegin=0, wcount=None):
         """temp[L], dens[L,nmol], isoz[niso,L] device tensors -> ec[L,rows,wcount]."""
@@ -211,6 +212,13 @@ class LBL:
         call('pb_lbl_last_state', self._h, hptr(ofactor), hptr(kmax), nlayers, rows,
              _stream())
         return ofactor, kmax
+
+    def last_layer_kinds(self, nlayers):
+        """(resident[L] 0/1, block[L] doubles) of the last call: pb_lbl_last_layer_kinds."""
+        resident = np.zeros(nlayers, np.int32)
+        block = np.zeros(nlayers, np.int32)
+        call('pb_lbl_last_layer_kinds', self._h, hptr(resident), hptr(block), nlayers, _stream())
+        return resident, block
 
     def close(self):
         if self._h:

@@ -44,7 +44,9 @@ def build(eng, c, resolution, table_from_oracle, orc, ethresh=1e-30, cutoff=None
     return vt, ll, lbl
 
 
-@pytest.mark.parametrize('mode,gather', [('step', 'global'), ('step', 'staged'), ('res', 'auto')])
+@pytest.mark.parametrize('mode,gather', [('step', 'global'), ('step', 'staged'),
+                                         ('step', 'resident'), ('step', 'auto'),
+                                         ('res', 'auto')])
 @pytest.mark.parametrize('own_table', [False, True])
 def test_g2_extinction_golden(eng, golden, orc, mode, own_table, gather):
     g = golden('g2_extinction')
@@ -78,9 +80,11 @@ def test_g2_extinction_golden(eng, golden, orc, mode, own_table, gather):
         np.testing.assert_allclose(got, want, rtol=RTOL, err_msg=f'variant {k}')
     print(f'{mode}/{gather} own_table={own_table}: max rel err vs reference = {worst:.2e}')
     assert ll.nadd > 0
-    want_kernel = {'global': 'k_ext_resample', 'staged': 'k_ext_staged',
-                   'auto': 'k_ext_linterp'}[gather]
-    assert lbl.last_gather_kernel == want_kernel
+    want_kernel = {'global': ('k_ext_resample',), 'staged': ('k_ext_staged',),
+                   'resident': ('k_ext_resident+k_ext_resample',),
+                   'auto': ('k_ext_linterp',) if mode == 'res' else
+                           ('k_ext_resident+k_ext_resample', 'k_ext_resident+k_ext_staged')}[gather]
+    assert lbl.last_gather_kernel in want_kernel
 
 
 def test_groups_match_oracle_counters(eng, orc):
@@ -116,7 +120,7 @@ def test_groups_match_oracle_counters(eng, orc):
     assert np.all(kmax > 0)
 
 
-@pytest.mark.parametrize('gather', ['global', 'staged'])
+@pytest.mark.parametrize('gather', ['global', 'staged', 'resident'])
 @pytest.mark.parametrize('nwave,nlines,niso', [(2, 1, 1), (65, 40, 1), (1025, 3000, 2),
                                                (4097, 20000, 4), (9001, 60000, 2)])
 def test_synthetic_cases_vs_oracle(eng, orc, nwave, nlines, niso, gather):
@@ -152,7 +156,7 @@ def test_synthetic_cases_vs_oracle(eng, orc, nwave, nlines, niso, gather):
     print(f'W={nwave} N={nlines} {gather}: max rel err vs oracle (same table) = {worst:.2e}')
 
 
-@pytest.mark.parametrize('gather', ['global', 'staged'])
+@pytest.mark.parametrize('gather', ['global', 'staged', 'resident'])
 def test_wavenumber_shards_concatenate(eng, orc, gather):
     """Shards [wbegin, wbegin+wcount) of the global grid reproduce the full spectrum
     bit for bit (no exchange between shards)."""
