@@ -51,6 +51,15 @@ constexpr int kRecs = 4;                         // records in flight per wavefr
 static_assert(kTile <= kPmPad, "table padding must cover one tile");
 static_assert(kTile < 65536, "window coordinates are packed in 16 bits");
 
+// Record of the scatter kernel: everything one wavefront needs about a (layer, group) pair,
+// read with ONE scalar load.
+struct __attribute__((aligned(32))) Rec32 {
+    double k;            // co-added strength (before threshold / density)
+    long long off;       // table element read by output sample 0 (row start + q)
+    int ulo, uhi;        // window on the global output grid
+    int pad[2];
+};
+
 struct LblArgs {
     // Voigt table
     const double *pm;
@@ -90,6 +99,8 @@ struct LblArgs {
     int32_t *ls_block;                // largest phase-major profile block of the layer (doubles)
     int res_cap;
     const int32_t *gs_start;          // [niso][nwave+1]
+    // scatter kernel: one 32-byte record per (layer, position-sorted group)
+    struct Rec32 *rec32;
     // per (layer, phase-sorted group) records written by k_records [nlayers][ngroups]
     double *rec_k;                    // co-added strength (before threshold / density)
     int32_t *rec_ulo, *rec_uhi;       // window on the global output grid
@@ -566,7 +577,7 @@ __global__ __launch_bounds__(kBlock) void k_records(LblArgs a)
     double k = 0.0, lmax = 0.0;
     int ulo = 0, uhi = 0, q = 0, cell = 0, phi = 0, row = -1;
     // layers of the resident-profile kernel are walked in position order
-    const bool pos = a.res_cap > 0 && a.ls_resident[layer];
+    const bool pos = a.rec32 != nullptr || (a.res_cap > 0 && a.ls_resident[layer]);
     const int32_t *rk_iso = pos ? a.giso : a.rk_iso;
     const int32_t *rk_first = pos ? a.gfirst : a.rk_first;
     const int32_t *rk_count = pos ? a.gcount : a.rk_count;
@@ -615,12 +626,22 @@ __global__ __launch_bounds__(kBlock) void k_records(LblArgs a)
                 uhi = ulo;
         }
         const int64_t idx = (int64_t)layer * a.ngroups + g;
-        a.rec_k[idx] = k;
-        a.rec_ulo[idx] = ulo;
-        a.rec_uhi[idx] = uhi;
-        a.rec_q[idx] = q;
-        a.rec_cell[idx] = cell;
-        a.rec_phi[idx] = phi;
+        if (a.rec32) {
+            Rec32 r;
+            r.k = k;
+            r.off = a.pm_base[cell] + (long long)phi * a.pm_stride[cell] + q;
+            r.ulo = ulo;
+            r.uhi = uhi;
+            r.pad[0] = r.pad[1] = 0;
+            a.rec32[idx] = r;
+        } else {
+            a.rec_k[idx] = k;
+            a.rec_ulo[idx] = ulo;
+            a.rec_uhi[idx] = uhi;
+            a.rec_q[idx] = q;
+            a.rec_cell[idx] = cell;
+            a.rec_phi[idx] = phi;
+        }
     }
     if (row >= 0)
         atomicMax(&s_max[row], (unsigned long long)__double_as_longlong(lmax));
@@ -1187,6 +1208,162 @@ __global__ __launch_bounds__(kResThreads) void k_ext_resident(LblArgs a)
 }
 
 // ---------------------------------------------------------------------------
+// 3s. Scatter kernel (constant-step grid): ONE wavefront owns a tile of T output samples
+// held in LDS and walks, in (isotope, position) order, the records whose window reaches the
+// tile.  Per record and 64 samples: one coalesced `buffer_load_dwordx2` straight from the
+// phase-major table (the window is the buffer, lanes past its end read 0), one v_mul_f64,
+// one `ds_add_f64` into the tile -- products and sums rounded separately like the
+// reference's `ktmp[j] += k * profile[...]`.  No staging, no phase sorting, no workgroup
+// barrier; the table traffic is exactly the window lengths.  Record fields are wave-uniform
+// and arrive by scalar loads.  The tile belongs to one wavefront and LDS executes a
+// wavefront's operations in order, so every sample is summed in record order whatever the
+// tiling: results are bitwise reproducible and shards concatenate exactly.
+// ---------------------------------------------------------------------------
+constexpr int kScatterPad = 64;       // lanes past a window's end add zeros there
+
+// The walk of one tile with C chunks (64 samples each) per record in flight.
+template <int C>
+__device__ inline void scatter_walk(const LblArgs &a, double *s_tile, int layer, int row,
+                                    int64_t t0, int64_t tend, double kthresh)
+{
+    typedef int v2i __attribute__((ext_vector_type(2)));
+    typedef int v4i __attribute__((ext_vector_type(4)));
+    const int lane = threadIdx.x;
+    const int osamp = a.osamp;
+    const int ofactor = a.ls_ofactor[layer];
+    const Rec32 *recs = a.rec32 + (int64_t)layer * a.ngroups;
+
+    for (int iso = 0; iso < a.niso; iso++) {
+        const int iext = a.isoiext[iso];
+        if (iext < 0 || (a.add ? 0 : iext) != row)
+            continue;
+        const int64_t li = (int64_t)layer * a.niso + iso;
+        const double dens = a.add ? a.li_dens[li] : 1.0;
+        int64_t reach = a.li_hmax[li];
+        if (a.cutoff > 0.0)
+            reach = min(reach, (int64_t)(a.cutoff / a.ownstep) + 2 * (int64_t)ofactor + 2);
+        reach += osamp + ofactor;
+        const int64_t rs = reach / osamp + 1;
+        const int32_t *gs = a.gs_start + (int64_t)iso * (a.nwave + 1);
+        const int g0 = gs[max((int64_t)0, t0 - rs)];
+        const int g1 = gs[min((int64_t)a.nwave, tend + rs)];
+
+        // 64 records per batch, one per lane; the next batch is requested before this one
+        // is walked
+        v4i w0 = {0, 0, 0, 0}, w1 = {0, 0, 0, 0};
+        auto fetch = [&](int g) {
+            const v4i *p = reinterpret_cast<const v4i *>(recs + min(g + lane, g1 - 1));
+            w0 = p[0];
+            w1 = p[1];
+        };
+        if (g0 < g1)
+            fetch(g0);
+        for (int gb = g0; gb < g1; gb += 64) {
+            const double kk = __hiloint2double(w0.y, w0.x);
+            const long long off = ((long long)w0.w << 32) | (unsigned)w0.z;
+            const int lo = max(w1.x, (int)t0), hi = min(w1.y, (int)tend);
+            const bool ok = gb + lane < g1 && !(kk < kthresh) && lo < hi;
+            const double b_k = kk * dens;
+            const long long b_src = off + lo;
+            const int b_lo = lo - (int)t0, b_n = hi - lo;
+            unsigned long long live = __ballot(ok);
+            if (gb + 64 < g1)
+                fetch(gb + 64);
+
+            // the live records, two in flight: the C loads of the next one are issued before
+            // the current one is multiplied and added
+            struct Cur {
+                int dst, nch;
+                double k;
+            };
+            auto start = [&](double (&v)[C], Cur &c) {
+                const int sl = (int)__builtin_ctzll(live);
+                live &= live - 1;
+                c.k = bcast(b_k, sl);
+                const int s_lo = __builtin_amdgcn_readlane((int)b_src, sl);
+                const int s_hi = __builtin_amdgcn_readlane((int)(b_src >> 32), sl);
+                const int n = __builtin_amdgcn_readlane(b_n, sl);
+                c.dst = __builtin_amdgcn_readlane(b_lo, sl);
+                c.nch = (n + 63) >> 6;
+                const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+                    (void *)(a.pm + (((long long)s_hi << 32) | (unsigned)s_lo)), 0, n * 8,
+                    0x00020000);
+#pragma unroll
+                for (int q = 0; q < C; q++) {
+                    const v2i w = __builtin_amdgcn_raw_buffer_load_b64(rsrc, lane * 8, q * 512, 0);
+                    v[q] = __hiloint2double(w.y, w.x);
+                }
+            };
+            auto finish = [&](const double (&v)[C], const Cur &c) {
+                double *dst = s_tile + c.dst + lane;
+#pragma unroll
+                for (int q = 0; q < C; q++)
+                    if (q < c.nch)
+                        __hip_atomic_fetch_add(dst + q * 64, c.k * v[q], __ATOMIC_RELAXED,
+                                               __HIP_MEMORY_SCOPE_WORKGROUP);
+            };
+            double va[C], vb[C];
+            Cur ca, cb;
+            if (!live)
+                continue;
+            start(va, ca);
+            for (;;) {
+                if (!live) {
+                    finish(va, ca);
+                    break;
+                }
+                start(vb, cb);
+                finish(va, ca);
+                if (!live) {
+                    finish(vb, cb);
+                    break;
+                }
+                start(va, ca);
+                finish(vb, cb);
+            }
+        }
+    }
+}
+
+template <int T>
+__global__ __launch_bounds__(64) void k_ext_scatter(LblArgs a)
+{
+    __shared__ double s_tile[T + kScatterPad];
+    int tile, layer;
+    decode_block(a, tile, layer);
+    if (layer < 0)
+        return;
+    const int row = blockIdx.y;
+    const int lane = threadIdx.x;
+    const int64_t t0 = a.wbegin + (int64_t)tile * T;
+    const int64_t tend = min(t0 + T, a.wbegin + a.wcount);
+    const int tlen = (int)(tend - t0);
+    const double kthresh =
+        a.ethresh * __longlong_as_double((long long)a.kmax_bits[(int64_t)layer * a.nrows + row]);
+    for (int i = lane; i < T + kScatterPad; i += 64)
+        s_tile[i] = 0.0;
+    // chunks per record: the longest phase row this layer can select
+    const int rowmax = a.ls_block[layer] / a.osamp;
+    const int chunks = (min(rowmax, T) + 63) >> 6;
+    if (chunks <= 4)
+        scatter_walk<4>(a, s_tile, layer, row, t0, tend, kthresh);
+    else if (chunks <= 6)
+        scatter_walk<6>(a, s_tile, layer, row, t0, tend, kthresh);
+    else if (chunks <= 8)
+        scatter_walk<8>(a, s_tile, layer, row, t0, tend, kthresh);
+    else if (chunks <= 12)
+        scatter_walk<12>(a, s_tile, layer, row, t0, tend, kthresh);
+    else if (chunks <= 16)
+        scatter_walk<16>(a, s_tile, layer, row, t0, tend, kthresh);
+    else
+        scatter_walk<32>(a, s_tile, layer, row, t0, tend, kthresh);
+    __builtin_amdgcn_s_waitcnt(0);     // the tile is complete (same wavefront: in order)
+    double *out = a.ext + ((int64_t)layer * a.nrows + row) * a.wcount + (t0 - a.wbegin);
+    for (int i = lane; i < tlen; i += 64)
+        out[i] = s_tile[i];
+}
+
+// ---------------------------------------------------------------------------
 // 3b. gather, arbitrary output grid (resolution / wlstep mode): every output needs the
 // two dynamic-grid samples that bracket it (linterp, utils.h:139-163).  Uses the
 // reference-layout table (the stride between consecutive outputs is not constant).
@@ -1388,6 +1565,7 @@ struct pb_lbl {
     int rowcap = 0;
     int32_t *ls_resident = nullptr;   // [max_layers]
     int32_t *ls_block = nullptr;      // [max_layers]
+    Rec32 *rec32 = nullptr;           // [max_layers][ngroups], scatter kernel
     int32_t *gs_start = nullptr;      // [niso][nwave+1]
     int res_cap = 0;                  // LDS doubles of one resident profile block (0 = none fits)
     int gather_mode = 0;     // 0 = choose, 1 = global gather, 2 = LDS-staged, 3 = resident+global
@@ -1748,6 +1926,10 @@ int pb_lbl_create(pb_lbl **out, pb_voigt *voigt, pb_lines *lines, const double *
             p->gather_mode = 1;
         else if (e && !strcmp(e, "staged"))
             p->gather_mode = 2;
+        else if (e && !strcmp(e, "resident"))
+            p->gather_mode = 3;
+        else if (e && !strcmp(e, "scatter"))
+            p->gather_mode = 4;
         const char *t = getenv("PB_STAGE_THRESHOLD");
         if (t)
             p->stage_threshold = atof(t);
@@ -1774,7 +1956,7 @@ int pb_lbl_set_isoiext(pb_lbl *p, const int32_t *isoiext_h)
 
 int pb_lbl_set_gather_mode(pb_lbl *p, int mode)
 {
-    PB_REQUIRE(p && mode >= 0 && mode <= 3, "pb_lbl_set_gather_mode: mode must be 0..3");
+    PB_REQUIRE(p && mode >= 0 && mode <= 4, "pb_lbl_set_gather_mode: mode must be 0..4");
     p->gather_mode = mode;
     return PB_OK;
 }
@@ -1918,9 +2100,22 @@ int pb_lbl_extinction(pb_lbl *p, double *ext_d, int64_t wbegin, int64_t wcount,
     const bool use_records = !p->resolution && l->ngroups > 0;
     // layers with narrow profiles go to the resident-profile kernel (decided per layer on
     // the device, from the layer alone); the kernel chosen above computes the others
-    const bool resident = use_records && p->res_cap > 0 && p->gs_start &&
+    const bool scatter = use_records && p->gs_start && p->gather_mode == 4;
+    const bool resident = use_records && !scatter && p->res_cap > 0 && p->gs_start &&
                           (p->gather_mode == 0 || p->gather_mode == 3);
     a.res_cap = resident ? p->res_cap : 0;
+    a.rec32 = nullptr;
+    if (scatter) {
+        if (!p->rec32) {
+            const size_t n = (size_t)p->max_layers * (size_t)l->ngroups;
+            if (hipMalloc(&p->rec32, n * sizeof(Rec32)) != hipSuccess) {
+                pb::set_error("pb_lbl_extinction: cannot allocate %zu B of line records",
+                              n * sizeof(Rec32));
+                return PB_ERR_NOMEM;
+            }
+        }
+        a.rec32 = p->rec32;
+    }
     if (use_records && !p->rec_k) {
         const size_t n = (size_t)p->max_layers * (size_t)l->ngroups;
         if (hipMalloc(&p->rec_k, n * 8) != hipSuccess ||
@@ -1965,8 +2160,22 @@ int pb_lbl_extinction(pb_lbl *p, double *ext_d, int64_t wbegin, int64_t wcount,
     const bool timed = p->ev_used + 2 <= (int)p->ev.size();
     if (timed)
         PB_HIP(hipEventRecord(p->ev[p->ev_used], s));
-    p->last_gather = (p->resolution ? 3 : staged ? 2 : 1) + (resident ? 8 : 0);
-    if (resident) {
+    p->last_gather = scatter ? 4 : (p->resolution ? 3 : staged ? 2 : 1) + (resident ? 8 : 0);
+    if (scatter) {
+        int T = 512;
+        if (const char *e = getenv("PB_SCATTER_T"))
+            T = atoi(e);
+        T = T >= 2048 ? 2048 : T >= 1024 ? 1024 : 512;
+        a.ntiles = pb::div_up(wcount, T);
+        dim3 grid((unsigned)(8 * a.ntiles * layer_groups), a.nrows);
+        if (T == 2048)
+            k_ext_scatter<2048><<<grid, 64, 0, s>>>(a);
+        else if (T == 1024)
+            k_ext_scatter<1024><<<grid, 64, 0, s>>>(a);
+        else
+            k_ext_scatter<512><<<grid, 64, 0, s>>>(a);
+        PB_LAUNCH_CHECK();
+    } else if (resident) {
         a.ntiles = pb::div_up(wcount, kResTile);
         dim3 grid((unsigned)(8 * a.ntiles * layer_groups), a.nrows);
         const size_t rlds = ((size_t)a.res_cap + 2) * 8 + (size_t)kResThreads * (16 + 4) +
@@ -1977,7 +2186,9 @@ int pb_lbl_extinction(pb_lbl *p, double *ext_d, int64_t wbegin, int64_t wcount,
         k_ext_resident<<<grid, kResThreads, rlds, s>>>(a);
         PB_LAUNCH_CHECK();
     }
-    if (p->resolution) {
+    if (scatter) {
+        // the scatter kernel computed every layer
+    } else if (p->resolution) {
         a.ntiles = pb::div_up(wcount, kBlock);
         dim3 grid((unsigned)(8 * a.ntiles * layer_groups), a.nrows);
         k_ext_linterp<<<grid, kBlock, 0, s>>>(a);
@@ -2108,6 +2319,7 @@ void pb_lbl_destroy(pb_lbl *p)
     (void)hipFree(p->ls_scale);
     (void)hipFree(p->ls_resident);
     (void)hipFree(p->ls_block);
+    (void)hipFree(p->rec32);
     (void)hipFree(p->gs_start);
     (void)hipFree(p->ls_dnwn);
     (void)hipFree(p->ls_dwnstep);
