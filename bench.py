@@ -116,6 +116,21 @@ def cpu_baseline(case, voigt, budget_layers=8, gpu_ec=None, gpu_spectrum=None):
                         f'{seconds:.2f} s per spectrum'))
 
 
+def dominant_kernel(lbl, nlayers):
+    """Name of the gather kernel that did the work of the last call: when the automatic mode
+    also launched the resident-profile kernel, say which layers it actually took."""
+    name = lbl.last_gather_kernel
+    if name and name.startswith('k_ext_resident+'):
+        resident, _ = lbl.last_layer_kinds(nlayers)
+        n = int(resident.sum())
+        if n == 0:
+            return name.split('+', 1)[1]
+        if n == nlayers:
+            return 'k_ext_resident'
+        return f'{name} ({n} of {nlayers} layers resident)'
+    return name
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -234,7 +249,7 @@ def main():
                                        'wavenumber-sharded RT + all-gather' if layer_mode
                                        else f'wavenumber shards x{world} + all-gather'),
                        'init_seconds': round(t_init, 3)},
-            'roofline': {'bound': 'hbm', 'kernel': model.lbl.last_gather_kernel,
+            'roofline': {'bound': 'hbm', 'kernel': dominant_kernel(model.lbl, nlayers_rank),
                          'achieved': achieved,
                          'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
