@@ -34,6 +34,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <new>
+#include <type_traits>
 #include <vector>
 
 #include "pb_common.h"
@@ -123,6 +124,7 @@ struct LblArgs {
     double *ls_dwnstep;
     double *li_alphad, *li_dens, *li_z;
     int32_t *li_ilor, *li_hmax;
+    int32_t *li_rowmax;               // longest phase row the (layer, isotope) can select
     unsigned long long *kmax_bits;
     // grid
     const double *wn;
@@ -189,6 +191,7 @@ __global__ __launch_bounds__(64) void k_layer_state(LblArgs a)
             for (int d = dlo; d <= dhi; d++)
                 used = max(used, a.pm_stride[ilor * a.ndop + d]);
             atomicMax(&s_block, used * a.osamp);
+            a.li_rowmax[(int64_t)layer * a.niso + i] = used;
         }
         const int64_t k = (int64_t)layer * a.niso + i;
         a.li_alphad[k] = alphad;
@@ -727,9 +730,15 @@ __global__ __launch_bounds__(NW * 64, 8) void k_ext_staged(LblArgs a)
         s_row[i] = 0.0;                            // the pads stay zero for good
 
     // Row of one segment -> registers (issued early), registers -> LDS (after the walk).
-    double rowreg[2][kRowRegs];
+    // The registers form a ring of D sets of R doubles per lane (D*R = 2*kRowRegs): rows
+    // that fit one register per lane (<= kThreads samples) are fetched 4 segments ahead.
+    double ring[2 * kRowRegs];
+    // Rows of this (layer, isotope) are at most `rowlim` samples long: wavefronts whose
+    // lanes lie beyond it do not store (the buffers are zeroed per isotope).
+    int rowlim = a.rowcap;
     // out-of-window lanes fall outside the buffer descriptor and read 0 (no predicate)
-    auto load_row = [&](int sg, double (&reg)[kRowRegs]) {
+    auto load_row = [&](int sg, auto Rc, double *reg) {
+        constexpr int R = decltype(Rc)::value;
         const int i0 = __builtin_amdgcn_readfirstlane((int)(s_seg[sg] & 0xffff));
         const unsigned m = (unsigned)__builtin_amdgcn_readfirstlane((int)s_m[i0]);
         const int mlo = (int)(m & 0xffff), mhi = (int)(m >> 16);
@@ -740,16 +749,19 @@ __global__ __launch_bounds__(NW * 64, 8) void k_ext_staged(LblArgs a)
             (void *)(a.pm + so_u + mlo), 0, (mhi - mlo) * 8, 0x00020000);
         typedef int v2i __attribute__((ext_vector_type(2)));
 #pragma unroll
-        for (int r = 0; r < kRowRegs; r++) {
+        for (int r = 0; r < R; r++) {
             const v2i v = __builtin_amdgcn_raw_buffer_load_b64(
                 rsrc, (tid + r * kThreads - mlo) * 8, 0, 0);
             reg[r] = __hiloint2double(v.y, v.x);
         }
     };
-    auto store_row = [&](int buf, const double (&reg)[kRowRegs]) {
+    auto store_row = [&](int buf, auto Rc, const double *reg) {
+        constexpr int R = decltype(Rc)::value;
         double *dst = s_row + kStagePad + buf * rowspan;
 #pragma unroll
-        for (int r = 0; r < kRowRegs; r++) {
+        for (int r = 0; r < R; r++) {
+            if (wave * 64 + r * kThreads >= rowlim)
+                continue;
             const int mm = tid + r * kThreads;
             if (mm < a.rowcap)
                 dst[mm] = reg[r];
@@ -771,6 +783,14 @@ __global__ __launch_bounds__(NW * 64, 8) void k_ext_staged(LblArgs a)
         // candidates of every phase key: [s_phs[p], s_phs[p] + count) in the phase list,
         // then an exclusive scan of the counts (thread t owns a run of `per` phases)
         __syncthreads();
+        {
+            const int lim = min(a.rowcap, a.li_rowmax[li]);
+            if (lim != rowlim) {                   // wave-uniform
+                for (int i = tid; i < 2 * rowspan + kStagePad; i += kThreads)
+                    s_row[i] = 0.0;
+                rowlim = lim;
+            }
+        }
         const int per = (osamp + kThreads - 1) / kThreads;
         int mine = 0;
         for (int r = 0; r < per; r++) {
@@ -984,31 +1004,37 @@ __global__ __launch_bounds__(NW * 64, 8) void k_ext_staged(LblArgs a)
             };
             if (a.experiment == 5)
                 nseg = 0;
-            if (nseg > 0) {
-                load_row(0, rowreg[0]);
-                store_row(0, rowreg[0]);
-                if (nseg > 1)
-                    load_row(1, rowreg[1]);
+            // Software pipeline over the segments.  Segment j lives in register set j % D;
+            // its loads are issued D steps before its row is written to LDS buffer j % 2
+            // (one step before it is walked).  Every step issues exactly R loads (the
+            // segment index is clamped, a surplus row is loaded and dropped), so the number
+            // of loads in flight behind the row about to be stored is a compile-time
+            // constant and the wait before the store is `s_waitcnt vmcnt((D-1)*R)`.
+            auto run = [&](auto Dc, auto Rc) {
+                constexpr int D = decltype(Dc)::value, R = decltype(Rc)::value;
+#pragma unroll
+                for (int i = 0; i < D; i++)
+                    load_row(min(i, nseg - 1), Rc, ring + i * R);
+                store_row(0, Rc, ring);
                 __syncthreads();
-            }
-            for (int sg = 0; sg < nseg; sg += 2) {
-                // even segment: LDS buffer 0; its successor's row waits in rowreg[1]
-                if (sg + 2 < nseg)
-                    load_row(sg + 2, rowreg[0]);
-                walk(sg, 0);
-                if (sg + 1 < nseg)
-                    store_row(1, rowreg[1]);
-                __syncthreads();
-                if (sg + 1 >= nseg)
-                    break;
-                // odd segment: LDS buffer 1; rowreg[0] holds segment sg+2
-                if (sg + 3 < nseg)
-                    load_row(sg + 3, rowreg[1]);
-                walk(sg + 1, 1);
-                if (sg + 2 < nseg)
-                    store_row(0, rowreg[0]);
-                __syncthreads();
-            }
+                for (int base = 0; base < nseg; base += D) {
+#pragma unroll
+                    for (int i = 0; i < D; i++) {
+                        const int sg = base + i;
+                        if (sg >= nseg)
+                            break;
+                        load_row(min(sg + D, nseg - 1), Rc, ring + i * R);
+                        walk(sg, i & 1);
+                        if (sg + 1 < nseg)
+                            store_row((i + 1) & 1, Rc, ring + ((i + 1) % D) * R);
+                        __syncthreads();
+                    }
+                }
+            };
+            // (a ring of 4 single-register sets for rows of <= 512 samples was measured:
+            // it spills at the 64-VGPR budget of 8 waves/SIMD and runs 30 % slower)
+            if (nseg > 0)
+                run(std::integral_constant<int, 2>(), std::integral_constant<int, kRowRegs>());
         }
     }
 
@@ -1548,6 +1574,7 @@ struct pb_lbl {
     int32_t *d_divisors = nullptr, *d_isoimol = nullptr, *d_isoiext = nullptr;
     // workspace
     int32_t *ls_ofactor = nullptr, *ls_scale = nullptr, *li_ilor = nullptr, *li_hmax = nullptr;
+    int32_t *li_rowmax = nullptr;
     int64_t *ls_dnwn = nullptr;
     double *ls_dwnstep = nullptr, *li_alphad = nullptr, *li_dens = nullptr, *li_z = nullptr;
     unsigned long long *kmax_bits = nullptr;
@@ -1812,6 +1839,7 @@ int pb_lbl_create(pb_lbl **out, pb_voigt *voigt, pb_lines *lines, const double *
     alloc((void **)&p->li_z, LI * 8);
     alloc((void **)&p->li_ilor, LI * 4);
     alloc((void **)&p->li_hmax, LI * 4);
+    alloc((void **)&p->li_rowmax, LI * 4);
     alloc((void **)&p->kmax_bits, L * (size_t)rows * 8);
     alloc((void **)&p->ls_resident, L * 4);
     alloc((void **)&p->ls_block, L * 4);
@@ -2057,6 +2085,7 @@ int pb_lbl_extinction(pb_lbl *p, double *ext_d, int64_t wbegin, int64_t wcount,
     a.li_z = p->li_z;
     a.li_ilor = p->li_ilor;
     a.li_hmax = p->li_hmax;
+    a.li_rowmax = p->li_rowmax;
     a.kmax_bits = p->kmax_bits;
     a.wn = p->d_wn;
     a.own0 = l->own0;
@@ -2328,6 +2357,7 @@ void pb_lbl_destroy(pb_lbl *p)
     (void)hipFree(p->li_z);
     (void)hipFree(p->li_ilor);
     (void)hipFree(p->li_hmax);
+    (void)hipFree(p->li_rowmax);
     (void)hipFree(p->kmax_bits);
     (void)hipFree(p->ph_first);
     (void)hipFree(p->ph_count);
