@@ -213,6 +213,19 @@ int pb_emission_flux(double *flux_d, double *intensity_d, const double *tau_d,
                      const int32_t *ideep_d, const double *wn_d, const double *temp_d,
                      const double *mu_d, const double *weights_d, int nmu, int rtop,
                      int nlayers, int nwave, void *stream);
+/* Two-stream fluxes (pyratbay/pyrat/spectrum.py:454-522, Heng et al. 2014 Eqs. B5-B6) from
+ * the plane-parallel optical depth depth_d[nlayers,nwave] (computed with maxdepth = inf,
+ * opacity/optic_depth.py:124-125): flux_down_d, flux_up_d [nlayers,nwave]; the emission
+ * spectrum is flux_up_d row 0.  f_int_d[nwave] = internal flux added at the bottom (NULL =
+ * none), flux_top_d[nwave] = beta_irr*(rstar/smaxis)^2*starflux written into row rtop
+ * before the downward sweep, exactly like the reference (NULL = no irradiation).  exp1 is
+ * scipy.special.exp1 (SciPy 1.15.3 xsf/expint.h:22-52). */
+int pb_two_stream(double *flux_down_d, double *flux_up_d, const double *depth_d,
+                  const double *wn_d, const double *temp_d, const double *f_int_d,
+                  const double *flux_top_d, int rtop, int nlayers, int nwave, void *stream);
+/* f_int of spectrum.py:475-478: Planck at tint scaled to a bolometric sigma*tint^4. */
+int pb_internal_flux(double *f_int_d, const double *wn_d, double tint, int nwave, void *stream);
+
 /* _simpson.simps2D (src_c/_simpson.c:167-203): y_d[ny,nwave] */
 int pb_simps2D(double *out_d, const double *y_d, int ny, int nwave, const double *h_d,
                const int32_t *nint_d, const double *hsum_d, const double *hratio_d,

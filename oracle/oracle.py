@@ -241,6 +241,40 @@ def blackbody_wn(wn, temp, B=None):
     return B if ret else 1
 
 
+def exp1(x):
+    """scipy.special.exp1 for real arguments (xsf/expint.h:22-52)."""
+    f = lib().orc_exp1
+    f.restype = C.c_double
+    x = np.asarray(x, np.float64)
+    return np.array([f(C.c_double(v)) for v in x.ravel()]).reshape(x.shape)
+
+
+def internal_flux(wn, tint):
+    """f_int of pyrat/spectrum.py:475-478."""
+    w, wp = _d(wn)
+    out = np.empty(len(w))
+    lib().orc_internal_flux(out.ctypes.data_as(c_dp), wp, C.c_int(len(w)), C.c_double(tint))
+    return out
+
+
+def two_stream(depth, wn, temp, f_int, flux_top=None, rtop=0):
+    """(flux_down, flux_up) of pyrat/spectrum.py:454-522 from depth[L,W]."""
+    d, dp = _d(depth)
+    nlayers, nwave = d.shape
+    B = blackbody_wn_2D(wn, temp)
+    fi, fip = _d(f_int)
+    if flux_top is None:
+        ftp = None
+    else:
+        ft, ftp = _d(flux_top)
+    down = np.empty((nlayers, nwave))
+    up = np.empty((nlayers, nwave))
+    lib().orc_two_stream(down.ctypes.data_as(c_dp), up.ctypes.data_as(c_dp), dp,
+                         B.ctypes.data_as(c_dp), fip, ftp, C.c_int(rtop), C.c_int(nlayers),
+                         C.c_int(nwave))
+    return down, up
+
+
 # --------------------------------------------------------------------------
 # _simpson.*
 # --------------------------------------------------------------------------

@@ -620,6 +620,85 @@ void orc_blackbody_wn(double *B, const double *wn, int nwave, double temp)
 }
 
 /* =====================================================================
+ * Two-stream fluxes: pyratbay/pyrat/spectrum.py:454-522 (Heng et al. 2014, Eqs. B5-B6).
+ * exp1 = scipy.special.exp1 (SciPy 1.15.3, scipy/special/xsf/expint.h:22-52: the E1XB
+ * routine of Zhang & Jin, "Computation of Special Functions", 1996).
+ * ===================================================================== */
+double orc_exp1(double x)
+{
+    const double ga = 0.5772156649015328606065120900824024;     /* cephes SCIPY_EULER */
+    if (x == 0.0)
+        return INFINITY;
+    if (x <= 1.0) {
+        double e1 = 1.0, r = 1.0;
+        for (int k = 1; k < 26; k++) {
+            r = -r * k * x / pow(k + 1.0, 2);
+            e1 += r;
+            if (fabs(r) <= fabs(e1) * 1e-15)
+                break;
+        }
+        return -ga - log(x) + x * e1;
+    }
+    int m = 20 + (int)(80.0 / x);
+    double t0 = 0.0;
+    for (int k = m; k > 0; k--)
+        t0 = k / (1.0 + k / (x + t0));
+    return exp(-x) * (1.0 / (x + t0));
+}
+
+/* Internal flux spectrum (spectrum.py:475-478): Planck at tint scaled so that its
+ * trapezoid integral over wn equals sigma*tint^4; sigma = constants sigma (cgs). */
+void orc_internal_flux(double *f_int, const double *wn, int nwave, double tint)
+{
+    const double sigma = 5.6703744191844314e-05;     /* astrophysical_constants.py:71 */
+    orc_blackbody_wn(f_int, wn, nwave, tint);
+    double total = 0.0;
+    for (int i = 0; i + 1 < nwave; i++)
+        total += (wn[i + 1] - wn[i]) * (f_int[i + 1] + f_int[i]) / 2.0;
+    if (total > 0)
+        for (int i = 0; i < nwave; i++)
+            f_int[i] *= sigma * pow(tint, 4) / total;
+}
+
+/* depth[L,W], B[L,W] (Planck of every layer), f_int[W], flux_top[W] or NULL (the
+ * irradiation written into row rtop before the downward sweep, :498-500; the sweep then
+ * overwrites rows 1..L-1 exactly as the reference does) -> flux_down, flux_up [L,W]. */
+void orc_two_stream(double *flux_down, double *flux_up, const double *depth, const double *B,
+                    const double *f_int, const double *flux_top, int rtop, int nlayers,
+                    int nwave)
+{
+    const double pi = 3.141592653589793;
+    for (int j = 0; j < nwave; j++) {
+        for (int i = 0; i < nlayers; i++) {
+            flux_down[(int64_t)i * nwave + j] = 0.0;
+            flux_up[(int64_t)i * nwave + j] = 0.0;
+        }
+        if (flux_top)
+            flux_down[(int64_t)rtop * nwave + j] = flux_top[j];
+        for (int i = 0; i < nlayers - 1; i++) {
+            double dtau0 = depth[(int64_t)(i + 1) * nwave + j] - depth[(int64_t)i * nwave + j];
+            double trans = (1 - dtau0) * exp(-dtau0) + dtau0 * dtau0 * orc_exp1(dtau0);
+            double Bp = (B[(int64_t)(i + 1) * nwave + j] - B[(int64_t)i * nwave + j]) / dtau0;
+            flux_down[(int64_t)(i + 1) * nwave + j] =
+                trans * flux_down[(int64_t)i * nwave + j] +
+                pi * B[(int64_t)i * nwave + j] * (1 - trans) +
+                pi * Bp * (-2.0 / 3 * (1 - exp(-dtau0)) + dtau0 * (1 - trans / 3));
+        }
+        flux_up[(int64_t)(nlayers - 1) * nwave + j] =
+            flux_down[(int64_t)(nlayers - 1) * nwave + j] + f_int[j];
+        for (int i = nlayers - 2; i >= 0; i--) {
+            double dtau0 = depth[(int64_t)(i + 1) * nwave + j] - depth[(int64_t)i * nwave + j];
+            double trans = (1 - dtau0) * exp(-dtau0) + dtau0 * dtau0 * orc_exp1(dtau0);
+            double Bp = (B[(int64_t)(i + 1) * nwave + j] - B[(int64_t)i * nwave + j]) / dtau0;
+            flux_up[(int64_t)i * nwave + j] =
+                trans * flux_up[(int64_t)(i + 1) * nwave + j] +
+                pi * B[(int64_t)(i + 1) * nwave + j] * (1 - trans) +
+                pi * Bp * (2.0 / 3 * (1 - exp(-dtau0)) - dtau0 * (1 - trans / 3));
+        }
+    }
+}
+
+/* =====================================================================
  * Simpson family: _simpson.c:36-203, include/simpson.h:8-47
  * ===================================================================== */
 void orc_geth(const double *h, int n, double *hsum, double *hratio, double *hfactor)

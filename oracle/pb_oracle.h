@@ -74,6 +74,13 @@ void orc_blackbody_wn_2D(double *B, const double *wn, int nwave, const double *t
                          int nlayers, const int32_t *last /* may be NULL */);
 void orc_blackbody_wn(double *B, const double *wn, int nwave, double temp);
 
+/* two-stream fluxes (pyrat/spectrum.py:454-522) and scipy.special.exp1 */
+double orc_exp1(double x);
+void orc_internal_flux(double *f_int, const double *wn, int nwave, double tint);
+void orc_two_stream(double *flux_down, double *flux_up, const double *depth, const double *B,
+                    const double *f_int, const double *flux_top, int rtop, int nlayers,
+                    int nwave);
+
 /* ---- Simpson family: src_c/_simpson.c, include/simpson.h ---- */
 void orc_geth(const double *h, int n, double *hsum, double *hratio, double *hfactor);
 double orc_simps(const double *y, int n, const double *h, const double *hsum,

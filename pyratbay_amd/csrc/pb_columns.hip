@@ -454,6 +454,115 @@ __global__ __launch_bounds__(kBlock) void k_band_integrate(
         bandflux[b] = s_part[0];
 }
 
+// ---------------------------------------------------------------------------
+// Two-stream fluxes (pyratbay/pyrat/spectrum.py:454-522; Heng et al. 2014 Eqs. B5-B6).
+// exp1 = scipy.special.exp1 for real arguments (xsf/expint.h:22-52, the E1XB routine of
+// Zhang & Jin 1996): power series for x <= 1, backward continued fraction otherwise.
+// ---------------------------------------------------------------------------
+__device__ inline double exp1_real(double x)
+{
+    const double ga = 0.5772156649015328606065120900824024;
+    if (x == 0.0)
+        return INFINITY;
+    if (x <= 1.0) {
+        double e1 = 1.0, r = 1.0;
+        for (int k = 1; k < 26; k++) {
+            const double k1 = k + 1.0;
+            r = -r * k * x / (k1 * k1);
+            e1 += r;
+            if (fabs(r) <= fabs(e1) * 1e-15)
+                break;
+        }
+        return -ga - log(x) + x * e1;
+    }
+    const int m = 20 + (int)(80.0 / x);
+    double t0 = 0.0;
+    for (int k = m; k > 0; k--)
+        t0 = k / (1.0 + k / (x + t0));
+    return exp(-x) * (1.0 / (x + t0));
+}
+
+// One column per thread.  The downward sweep parks trans[i] in flux_up[i] so that the
+// upward sweep does not evaluate exp1 again; Planck values are recomputed in registers.
+__global__ __launch_bounds__(kBlock) void k_two_stream(
+    double *flux_down, double *flux_up, const double *depth, const double *wn,
+    const double *temp, const double *f_int, const double *flux_top, int rtop, int nlayers,
+    int nwave)
+{
+    const int j = blockIdx.x * kBlock + threadIdx.x;
+    if (j >= nwave)
+        return;
+    const double pi = 3.141592653589793;
+    const double w = wn[j];
+    const double factor = planck_factor(w);
+    // the irradiation is written into row rtop and the sweep overwrites rows 1..L-1
+    // (spectrum.py:498-509): it survives only when rtop == 0
+    double down = (flux_top && rtop == 0) ? flux_top[j] : 0.0;
+    flux_down[j] = down;
+    double dprev = depth[j];
+    double bprev = planck(factor, w, temp[0]);
+    for (int i = 0; i < nlayers - 1; i++) {
+        const double dnext = depth[(int64_t)(i + 1) * nwave + j];
+        const double bnext = planck(factor, w, temp[i + 1]);
+        const double dtau0 = dnext - dprev;
+        const double trans = (1 - dtau0) * exp(-dtau0) + dtau0 * dtau0 * exp1_real(dtau0);
+        const double bp = (bnext - bprev) / dtau0;
+        down = trans * down + pi * bprev * (1 - trans) +
+               pi * bp * (-2.0 / 3 * (1 - exp(-dtau0)) + dtau0 * (1 - trans / 3));
+        flux_down[(int64_t)(i + 1) * nwave + j] = down;
+        flux_up[(int64_t)i * nwave + j] = trans;
+        dprev = dnext;
+        bprev = bnext;
+    }
+    double up = down + (f_int ? f_int[j] : 0.0);
+    flux_up[(int64_t)(nlayers - 1) * nwave + j] = up;
+    // bprev = B[L-1], dprev = depth[L-1]
+    for (int i = nlayers - 2; i >= 0; i--) {
+        const double dlo = depth[(int64_t)i * nwave + j];
+        const double blo = planck(factor, w, temp[i]);
+        const double dtau0 = dprev - dlo;
+        const double trans = flux_up[(int64_t)i * nwave + j];
+        const double bp = (bprev - blo) / dtau0;
+        up = trans * up + pi * bprev * (1 - trans) +
+             pi * bp * (2.0 / 3 * (1 - exp(-dtau0)) - dtau0 * (1 - trans / 3));
+        flux_up[(int64_t)i * nwave + j] = up;
+        dprev = dlo;
+        bprev = blo;
+    }
+}
+
+// f_int (spectrum.py:475-478): Planck at tint, scaled so that its trapezoid integral over
+// wn is sigma*tint^4.  One workgroup; fixed-order tree sum.
+__global__ __launch_bounds__(kBlock) void k_internal_flux(double *f_int, const double *wn,
+                                                         double tint, int nwave)
+{
+    __shared__ double s_part[kBlock];
+    const double sigma = 5.6703744191844314e-05;      // constants/astrophysical_constants.py:71
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < nwave; i += kBlock) {
+        const double w = wn[i];
+        const double b = planck(planck_factor(w), w, tint);
+        f_int[i] = b;
+        if (i + 1 < nwave) {
+            const double w1 = wn[i + 1];
+            acc += (w1 - w) * (planck(planck_factor(w1), w1, tint) + b) / 2.0;
+        }
+    }
+    s_part[threadIdx.x] = acc;
+    __syncthreads();
+    for (int k = kBlock / 2; k > 0; k >>= 1) {
+        if ((int)threadIdx.x < k)
+            s_part[threadIdx.x] += s_part[threadIdx.x + k];
+        __syncthreads();
+    }
+    const double total = s_part[0];
+    if (total > 0) {
+        const double scale = sigma * pow(tint, 4.0) / total;
+        for (int i = threadIdx.x; i < nwave; i += kBlock)
+            f_int[i] *= scale;
+    }
+}
+
 }  // namespace
 
 // ===========================================================================
@@ -641,6 +750,34 @@ int pb_emission_flux(double *flux_d, double *intensity_d, const double *tau_d,
     k_emission_flux<<<pb::div_up(nwave, kBlock), kBlock, 0, pb::as_stream(stream)>>>(
         flux_d, intensity_d, tau_d, ideep_d, wn_d, temp_d, mu_d, weights_d, nmu, rtop,
         nlayers, nwave);
+    PB_LAUNCH_CHECK();
+    return PB_OK;
+}
+
+int pb_internal_flux(double *f_int_d, const double *wn_d, double tint, int nwave, void *stream)
+{
+    PB_REQUIRE(nwave >= 0, "pb_internal_flux: bad shape");
+    if (nwave == 0)
+        return PB_OK;
+    PB_REQUIRE(f_int_d && wn_d, "pb_internal_flux: null pointer");
+    k_internal_flux<<<1, kBlock, 0, pb::as_stream(stream)>>>(f_int_d, wn_d, tint, nwave);
+    PB_LAUNCH_CHECK();
+    return PB_OK;
+}
+
+int pb_two_stream(double *flux_down_d, double *flux_up_d, const double *depth_d,
+                  const double *wn_d, const double *temp_d, const double *f_int_d,
+                  const double *flux_top_d, int rtop, int nlayers, int nwave, void *stream)
+{
+    PB_REQUIRE(nlayers >= 1 && nwave >= 0, "pb_two_stream: bad shape");
+    PB_REQUIRE(rtop >= 0 && rtop < nlayers, "pb_two_stream: rtop out of range");
+    if (nwave == 0)
+        return PB_OK;
+    PB_REQUIRE(flux_down_d && flux_up_d && depth_d && wn_d && temp_d,
+               "pb_two_stream: null pointer");
+    k_two_stream<<<pb::div_up(nwave, kBlock), kBlock, 0, pb::as_stream(stream)>>>(
+        flux_down_d, flux_up_d, depth_d, wn_d, temp_d, f_int_d, flux_top_d, rtop, nlayers,
+        nwave);
     PB_LAUNCH_CHECK();
     return PB_OK;
 }

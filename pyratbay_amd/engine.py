@@ -313,6 +313,24 @@ def emission_flux(depth, ideep, wn, temp, mu, weights, rtop, want_intensity=Fals
     return (flux, inten) if want_intensity else flux
 
 
+def internal_flux(wn, tint):
+    """f_int of pyrat/spectrum.py:475-478 (Planck at tint scaled to sigma*tint^4)."""
+    out = torch.empty(wn.shape[0], dtype=torch.float64, device=wn.device)
+    call('pb_internal_flux', _ptr(out), _ptr(wn), float(tint), wn.shape[0], _stream())
+    return out
+
+
+def two_stream(depth, wn, temp, f_int=None, flux_top=None, rtop=0):
+    """pyrat/spectrum.py:454-522 -> (flux_down, flux_up) [L,W]; the emission spectrum is
+    flux_up[0].  flux_top = beta_irr*(rstar/smaxis)**2*starflux (or None)."""
+    nlayers, nwave = depth.shape
+    down = torch.empty((nlayers, nwave), dtype=torch.float64, device=depth.device)
+    up = torch.empty((nlayers, nwave), dtype=torch.float64, device=depth.device)
+    call('pb_two_stream', _ptr(down), _ptr(up), _ptr(depth), _ptr(wn), _ptr(temp),
+         _ptr(f_int), _ptr(flux_top), int(rtop), nlayers, nwave, _stream())
+    return down, up
+
+
 def blackbody_wn_2D(wn, temp, last=None):
     B = torch.zeros((temp.shape[0], wn.shape[0]), dtype=torch.float64, device=wn.device)
     call('pb_blackbody_wn_2D', _ptr(B), _ptr(wn), wn.shape[0], _ptr(temp), temp.shape[0],
@@ -376,7 +394,7 @@ class LBLSpectrum:
 
     def __init__(self, case, rt_path='transit', wbegin=0, wcount=None, itop=0,
                  quadrature_mu=None, quadrature_weights=None, keep_flat=False,
-                 voigt=None, lines=None):
+                 voigt=None, lines=None, tint=0.0, flux_top=None):
         require_gpu()
         g, atm, ln, iso, vg = (case['grid'], case['atm'], case['lines'], case['iso'],
                                case['voigt'])
@@ -415,6 +433,14 @@ class LBLSpectrum:
                 quadrature_weights = np.pi * (np.sin(bounds[1:])**2 - np.sin(bounds[:-1])**2)
             self.mu = dev(quadrature_mu)
             self.weights = dev(quadrature_weights)
+        if rt_path == 'two_stream':
+            # rt_path emission_two_stream: depth without the maxdepth stop
+            # (opacity/optic_depth.py:124-125), internal flux, optional irradiation
+            self.maxdepth = np.inf
+            self.f_int = internal_flux(self.wn, tint)
+            self.flux_top = None if flux_top is None else dev(
+                np.asarray(flux_top)[wbegin:wbegin + self.wcount])
+            self.flux_down = self.flux_up = None
         self.ec = torch.empty((self.nlayers, 1, self.wcount), dtype=torch.float64,
                               device='cuda')
         self.depth = self.ideep = self.spectrum = None
@@ -450,6 +476,10 @@ class LBLSpectrum:
         if self.rt_path == 'transit':
             self.spectrum = transmission(self.depth, self.ideep, self.radius, self.itop,
                                          self.rstar)
+        elif self.rt_path == 'two_stream':
+            self.flux_down, self.flux_up = two_stream(self.depth, self.wn, self.temp,
+                                                      self.f_int, self.flux_top, self.itop)
+            self.spectrum = self.flux_up[0]
         else:
             self.spectrum = emission_flux(self.depth, self.ideep, self.wn, self.temp,
                                           self.mu, self.weights, self.itop)

@@ -158,8 +158,9 @@ def main():
             return pb.run(cfg)
 
         run(CFG_TLI, 'tli')
-        for rt in ('transit', 'emission'):
-            pyrat = run(CFG_SPEC, f'spec_{rt}', rt=rt)
+        for rt in ('transit', 'emission', 'emission_two_stream'):
+            extra = 'smaxis = 0.045 au\ntint = 150.0\nbeta_irr = 0.25\n' if 'two_stream' in rt else ''
+            pyrat = run(CFG_SPEC + extra, f'spec_{rt}', rt=rt)
             spec, atm, od, voigt = pyrat.spec, pyrat.atm, pyrat.od, pyrat.voigt
             lbl = pyrat.opacity.models[pyrat.opacity.models_type.index('lbl')]
             store = dict(
@@ -183,6 +184,18 @@ def main():
                 store.update(quadrature_mu=spec.quadrature_mu,
                              quadrature_weights=np.ravel(spec.quadrature_weights),
                              intensity=spec.intensity)
+            if rt == 'emission_two_stream':
+                # the two-stream solver's own inputs and outputs; ec stays out (same as
+                # the emission fixture) to keep the file small
+                del store['ec']
+                for key in ('lwn', 'elow', 'gf', 'isoid', 'profile_sub', 'own'):
+                    store.pop(key, None)
+                store.update(tint=atm.tint, beta_irr=atm.beta_irr, smaxis=atm.smaxis,
+                             starflux=spec.starflux, f_int=spec.f_int,
+                             flux_up=spec.flux_up, flux_down=spec.flux_down,
+                             exp1_x=np.logspace(-8, 2.4, 300),
+                             exp1_y=__import__('scipy.special', fromlist=['exp1']).exp1(
+                                 np.logspace(-8, 2.4, 300)))
             np.savez_compressed(os.path.join(OUT, f'g6_e2e_{rt}.npz'), **store)
             print(rt, 'W', spec.nwave, 'L', atm.nlayers, 'lines', len(lbl.wn),
                   'spectrum', spec.spectrum.min(), spec.spectrum.max())

@@ -1,0 +1,171 @@
+"""Two-stream fluxes (pyrat/spectrum.py:454-522): oracle and HIP kernel against the fixture
+tests/golden/g6_e2e_emission_two_stream.npz, which holds what the REAL reference package
+produced for rt_path = emission_two_stream (depth, temperatures, f_int, starflux -> flux_up,
+flux_down, spectrum) plus a table of scipy.special.exp1 values.
+
+Tolerance.  The reference's formula is ill-conditioned where a layer is optically very
+thin: Bp = dB/dtau is multiplied by 2/3 (1 - exp(-dtau)) - dtau (1 - trans/3), a difference
+of two O(dtau) terms that cancel to O(dtau^2).  With dtau down to 1e-16 in the fixture a
+1-ulp difference in exp() moves the emergent flux by 1e-7 relative (numpy's exp vs glibc's
+exp vs the GPU's).  The fixture-level checks therefore use north_star's 1e-6; the
+well-conditioned synthetic case checks the implementation itself at 1e-11."""
+import numpy as np
+import pytest
+
+RTOL_FIXTURE = 1e-6
+RTOL_TIGHT = 1e-11
+
+
+def fixture(golden):
+    g = golden('g6_e2e_emission_two_stream')
+    top = float(g['beta_irr']) * (float(g['rstar']) / float(g['smaxis']))**2 * g['starflux']
+    return g, top
+
+
+def close_by_column(got, want, rtol):
+    """|got - want| <= rtol * (largest value of the column)."""
+    scale = np.max(np.abs(want), axis=0)
+    assert np.all(np.isfinite(got))
+    assert np.max(np.abs(got - want) / scale) <= rtol
+
+
+def conditioned_case(nlayers=40, nwave=700, seed=3):
+    rng = np.random.default_rng(seed)
+    wn = np.linspace(300.0, 9000.0, nwave)
+    temp = np.linspace(900.0, 2100.0, nlayers) + rng.normal(0, 15.0, nlayers)
+    dtau = 10**rng.uniform(-3, 1.2, (nlayers - 1, nwave))      # includes x <= 1 and x > 1
+    dtau[5, :7] = [1.0, 0.999999, 1.000001, 80.0, 40.0, 4.0, 1e-3]
+    depth = np.vstack([np.zeros(nwave), np.cumsum(dtau, axis=0)])
+    f_int = 10**rng.uniform(0, 2, nwave)
+    top = 10**rng.uniform(2, 4, nwave)
+    return wn, temp, depth, f_int, top
+
+
+def numpy_two_stream(depth, B, f_int, top):
+    """The reference's statements, with scipy's exp1."""
+    from scipy.special import exp1
+    L = depth.shape[0]
+    dtau0 = np.diff(depth, n=1, axis=0)
+    trans = (1 - dtau0) * np.exp(-dtau0) + dtau0**2 * exp1(dtau0)
+    Bp = np.diff(B, n=1, axis=0) / dtau0
+    down = np.zeros_like(depth)
+    up = np.zeros_like(depth)
+    if top is not None:
+        down[0] = top
+    for i in range(L - 1):
+        down[i + 1] = (trans[i] * down[i] + np.pi * B[i] * (1 - trans[i])
+                       + np.pi * Bp[i] * (-2 / 3 * (1 - np.exp(-dtau0[i]))
+                                          + dtau0[i] * (1 - trans[i] / 3)))
+    up[L - 1] = down[L - 1] + f_int
+    for i in reversed(range(L - 1)):
+        up[i] = (trans[i] * up[i + 1] + np.pi * B[i + 1] * (1 - trans[i])
+                 + np.pi * Bp[i] * (2 / 3 * (1 - np.exp(-dtau0[i]))
+                                    - dtau0[i] * (1 - trans[i] / 3)))
+    return down, up
+
+
+def test_oracle_exp1_is_scipys(orc, golden):
+    g, _ = fixture(golden)
+    assert np.array_equal(orc.exp1(g['exp1_x']), g['exp1_y'])
+    assert np.isinf(orc.exp1(np.array([0.0]))[0]) and np.isnan(orc.exp1(np.array([-0.5]))[0])
+
+
+def test_oracle_two_stream_vs_reference_run(orc, golden):
+    g, top = fixture(golden)
+    np.testing.assert_allclose(orc.internal_flux(g['wn'], float(g['tint'])), g['f_int'],
+                               rtol=1e-12)
+    down, up = orc.two_stream(g['depth'], g['wn'], g['temp'], g['f_int'], top, int(g['rtop']))
+    close_by_column(down, g['flux_down'], RTOL_FIXTURE)
+    close_by_column(up, g['flux_up'], RTOL_FIXTURE)
+    assert np.array_equal(g['spectrum'], g['flux_up'][0])
+
+
+def test_oracle_two_stream_conditioned(orc):
+    wn, temp, depth, f_int, top = conditioned_case()
+    want = numpy_two_stream(depth, orc.blackbody_wn_2D(wn, temp), f_int, top)
+    got = orc.two_stream(depth, wn, temp, f_int, top, 0)
+    np.testing.assert_allclose(got[0], want[0], rtol=RTOL_TIGHT)
+    np.testing.assert_allclose(got[1], want[1], rtol=RTOL_TIGHT)
+    # irradiation written below the top row is overwritten by the sweep (reference quirk)
+    lost = orc.two_stream(depth, wn, temp, f_int, top, 2)
+    none = orc.two_stream(depth, wn, temp, f_int, None, 0)
+    assert np.array_equal(lost[1], none[1])
+
+
+@pytest.fixture(scope='module')
+def eng():
+    from pyratbay_amd import engine
+    engine.require_gpu()
+    return engine
+
+
+@pytest.mark.gpu
+def test_hip_two_stream_conditioned(eng, orc):
+    wn, temp, depth, f_int, top = conditioned_case()
+    want = orc.two_stream(depth, wn, temp, f_int, top, 0)
+    d, w, t = eng.dev(depth), eng.dev(wn), eng.dev(temp)
+    down, up = eng.two_stream(d, w, t, eng.dev(f_int), eng.dev(top), 0)
+    np.testing.assert_allclose(down.cpu().numpy(), want[0], rtol=RTOL_TIGHT)
+    np.testing.assert_allclose(up.cpu().numpy(), want[1], rtol=RTOL_TIGHT)
+    # no internal flux, no irradiation; rtop > 0 drops the irradiation like the reference
+    want0 = orc.two_stream(depth, wn, temp, np.zeros_like(f_int), None, 0)
+    down0, up0 = eng.two_stream(d, w, t)
+    np.testing.assert_allclose(up0.cpu().numpy(), want0[1], rtol=RTOL_TIGHT)
+    down2, up2 = eng.two_stream(d, w, t, None, eng.dev(top), 2)
+    assert np.array_equal(up2.cpu().numpy(), up0.cpu().numpy())
+
+
+@pytest.mark.gpu
+def test_hip_two_stream_vs_reference_run(eng, golden):
+    g, top = fixture(golden)
+    wn = eng.dev(g['wn'])
+    f_int = eng.internal_flux(wn, float(g['tint']))
+    np.testing.assert_allclose(f_int.cpu().numpy(), g['f_int'], rtol=1e-12)
+    down, up = eng.two_stream(eng.dev(g['depth']), wn, eng.dev(g['temp']), f_int,
+                              eng.dev(top), int(g['rtop']))
+    close_by_column(down.cpu().numpy(), g['flux_down'], RTOL_FIXTURE)
+    close_by_column(up.cpu().numpy(), g['flux_up'], RTOL_FIXTURE)
+
+
+@pytest.mark.gpu
+def test_hip_two_stream_end_to_end(eng, golden):
+    """extinction -> depth without the maxdepth stop -> two-stream, from the line list and
+    atmosphere of the reference run (the emission fixture holds the same TLI arrays)."""
+    from tests.test_e2e_golden import voigt_inputs
+    g, top = fixture(golden)
+    e = golden('g6_e2e_emission')
+    L, W = g['depth'].shape
+    vt = eng.VoigtTable.build(e['lorentz'], e['doppler'], voigt_inputs(e),
+                              float(e['ownstep']), int(e['wnosamp']))
+    ll = eng.LineList(e['lwn'], e['elow'], e['gf'], e['isoid'], len(e['iso_mass']), e['own'])
+    lbl = eng.LBL(vt, ll, e['wn'], e['divisors'], e['mol_radius'], e['mol_mass'],
+                  e['iso_atm_index'], e['iso_mass'], e['iso_ratio'], e['iso_mol_index'],
+                  float(e['cutoff']), float(e['ethresh']), max_layers=L)
+    ec = lbl.extinction(eng.dev(g['temp']), eng.dev(g['dens']), eng.dev(g['iso_pf']),
+                        add=True).view(L, W)
+    itop = int(g['rtop'])
+    depth, _ = eng.plane_parallel_optical_depth(ec, eng.dev(-np.diff(g['radius'])), itop, L,
+                                                np.inf)
+    np.testing.assert_allclose(depth.cpu().numpy(), g['depth'], rtol=1e-10)
+    wn = eng.dev(g['wn'])
+    down, up = eng.two_stream(depth, wn, eng.dev(g['temp']),
+                              eng.internal_flux(wn, float(g['tint'])), eng.dev(top), itop)
+    close_by_column(up.cpu().numpy(), g['flux_up'], RTOL_FIXTURE)
+    print('two-stream spectrum max rel err vs pb.run() = '
+          f'{np.max(np.abs(up[0].cpu().numpy() / g["spectrum"] - 1)):.2e}')
+
+
+@pytest.mark.gpu
+def test_lbl_spectrum_two_stream_mode(eng, orc):
+    """LBLSpectrum(rt_path='two_stream'): the same stages behind the front-end class."""
+    from pyratbay_amd import synth
+    case = synth.lbl_case(2001, 12, 4000, wnosamp=24, nlor=18, ndop=9, extent=80.0,
+                          cutoff=3.0, niso=2, seed=11)
+    top = np.linspace(1e3, 5e3, 2001)
+    model = eng.LBLSpectrum(case, rt_path='two_stream', tint=300.0, flux_top=top)
+    spectrum = model.run().cpu().numpy()
+    depth = model.depth.cpu().numpy()
+    wn, temp = case['grid']['wn'], case['atm']['temp']
+    want = orc.two_stream(depth, wn, temp, orc.internal_flux(wn, 300.0), top, 0)
+    close_by_column(model.flux_up.cpu().numpy(), want[1], RTOL_FIXTURE)
+    assert np.array_equal(spectrum, model.flux_up[0].cpu().numpy())
