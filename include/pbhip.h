@@ -213,6 +213,37 @@ int pb_emission_flux(double *flux_d, double *intensity_d, const double *tau_d,
                      const int32_t *ideep_d, const double *wn_d, const double *temp_d,
                      const double *mu_d, const double *weights_d, int nmu, int rtop,
                      int nlayers, int nwave, void *stream);
+/* Continuum opacity terms, accumulated into ec_d[nlayers,nwave] in ONE pass:
+ *  - nrank1 terms cs_d[m][nwave] * f_d[m][nlayers]: Rayleigh (rayleigh.py:85-107, f = number
+ *    density of the scatterer), Lecavelier haze (lecavelier.py:73-100, f = p/kT) and
+ *    constant-cross-section gray clouds (gray.py:63-75, cs = 1, f = cs[l]*p/kT);
+ *  - ncia (<= 4) collision-induced-absorption tables cia_tab_d[c] -> [ntemp_c][nwave] on the
+ *    model grid, already per (molecule cm-3)^2, linear in temperature between the nodes
+ *    cia_temps_d[c] with the bracket rule of _spline.c:219-260 (lin_interp_2D), columns
+ *    [cia_lo[c], cia_hi[c]) only, times cia_f_d[c][nlayers] = product of the pair's
+ *    densities (cia.py:119-215).  A temperature off a table gives NaN there (the reference
+ *    raises ValueError; the Python front-end checks before the call).  cia_tab_d and
+ *    cia_temps_d are HOST arrays of device pointers;
+ *  - H- bound-free + free-free (hydrogen_ion.py:157-276, John 1988) when hm_sigma_bf_d is not
+ *    NULL: hm_sigma_bf_d[nwave] (Eq. 4), hm_ff_d[6][nwave] = 1e-29 * the wavelength
+ *    polynomials of Eq. 6 as rows multiplying sqrt(5040/T)^(i+2) (zero rows where a branch
+ *    does not use a power), hm_f_d[nlayers] = n_H * n_e. */
+int pb_continuum(double *ec_d, const double *wn_d, const double *temp_d, int nlayers, int nwave,
+                 int nrank1, const double *cs_d, const double *f_d, int ncia,
+                 const double *const *cia_tab_d, const double *const *cia_temps_d,
+                 const int32_t *cia_ntemp, const int32_t *cia_lo, const int32_t *cia_hi,
+                 const double *cia_f_d, const double *hm_sigma_bf_d, const double *hm_ff_d,
+                 const double *hm_f_d, void *stream);
+/* Alkali resonance doublets, src_c/_alkali.c:30-106 (alkali_cross_section): adds the cross
+ * section (cm2 molecule-1) of nlines (<= 8) lines to ec_d[nlayers,nwave] -- times
+ * density_d[nlayers] when that is not NULL (alkali.py:239-262).  pressure_d in barye,
+ * voigt_det_d[nlayers,nlines] = Voigt value at the detuning distance (alkali.py:56-89, host). */
+int pb_alkali_cross_section(double *ec_d, const double *pressure_d, const double *wn_d,
+                            const double *temp_d, const double *voigt_det_d, double detuning,
+                            double mass, double lorentz_par, double part_func, double cutoff,
+                            const double *wn0_h, const double *gf_h, int nlines,
+                            const double *density_d, int nlayers, int nwave, void *stream);
+
 /* Two-stream fluxes (pyratbay/pyrat/spectrum.py:454-522, Heng et al. 2014 Eqs. B5-B6) from
  * the plane-parallel optical depth depth_d[nlayers,nwave] (computed with maxdepth = inf,
  * opacity/optic_depth.py:124-125): flux_down_d, flux_up_d [nlayers,nwave]; the emission

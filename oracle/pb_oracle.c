@@ -699,6 +699,110 @@ void orc_two_stream(double *flux_down, double *flux_up, const double *depth, con
 }
 
 /* =====================================================================
+ * Continuum opacity terms with native arithmetic in the reference:
+ * alkali doublets (src_c/_alkali.c:30-106) and the CIA interpolation helpers
+ * (src_c/_spline.c:25-74 second_deriv, :95-131 splinterp_1D with include/spline.h:6-35,
+ * :219-260 lin_interp_2D).
+ * ===================================================================== */
+void orc_alkali_cross_section(double *ec, const double *pressure, const double *wn,
+                              const double *temp, const double *voigt_det, double detuning_wn,
+                              double mass, double lorentz_par, double part_func, double cutoff,
+                              const double *wn0, const double *gf, int nlines, int nlayers,
+                              int nwave)
+{
+    const double K_ATM = 1010000.0, K_C2 = 1.4387768775039338, K_C3 = 8.852821681767784e-13;
+    int flip = signbit(wn[1] - wn[0]);
+    for (int j = 0; j < nlines; j++)
+        for (int i = 0; i < nlayers; i++) {
+            double lorentz = lorentz_par * pow(temp[i] / 2000.0, -0.7) * pressure[i] / K_ATM;
+            double dsigma = detuning_wn * pow(temp[i] / 500.0, 0.6);
+            for (int k = 0; k < nwave; k++) {
+                int t = flip ? nwave - k - 1 : k;
+                double dwn = wn[t] - wn0[j];
+                double abs_dwn = fabs(dwn);
+                if (dwn < -cutoff)
+                    continue;
+                else if (dwn > cutoff)
+                    break;
+                if (abs_dwn >= dsigma)
+                    ec[(int64_t)i * nwave + t] +=
+                        voigt_det[(int64_t)i * nlines + j] * pow(abs_dwn / dsigma, -1.5) * K_C3 *
+                        gf[j] / part_func * exp(-K_C2 * (abs_dwn - dsigma) / temp[i]);
+                else
+                    ec[(int64_t)i * nwave + t] +=
+                        lorentz / K_PI / (pow(lorentz, 2.0) + pow(dwn, 2.0)) * K_C3 * gf[j] /
+                        part_func;
+            }
+        }
+    (void)mass;     /* the Doppler width is computed but unused by the reference (:66-76) */
+}
+
+/* second derivatives for the natural cubic spline; NB the reference divides by
+ * (xin[i+1] - YIN[i-1]) (_spline.c:52-53), kept as is */
+void orc_second_deriv(double *y2nd, const double *yin, const double *xin, int nin)
+{
+    int n = nin - 1;
+    double *u = calloc((size_t)(n > 0 ? n : 1), sizeof(double));
+    y2nd[0] = y2nd[n] = 0.0;
+    u[0] = 0.0;
+    for (int i = 1; i < n; i++) {
+        double sig = (xin[i] - xin[i - 1]) / (xin[i + 1] - yin[i - 1]);
+        double p = sig * y2nd[i - 1] + 2.0;
+        y2nd[i] = (sig - 1.0) / p;
+        u[i] = (yin[i + 1] - yin[i]) / (xin[i + 1] - xin[i]) -
+               (yin[i] - yin[i - 1]) / (xin[i] - xin[i - 1]);
+        u[i] = (6.0 * u[i] / (xin[i + 1] - xin[i - 1]) - sig * u[i - 1]) / p;
+    }
+    for (int i = n - 1; i >= 0; i--)
+        y2nd[i] = y2nd[i] * y2nd[i + 1] + u[i];
+    free(u);
+}
+
+void orc_splinterp_1D(double *yout, const double *yin, const double *xin, const double *y2nd,
+                      int nin, const double *xout, int nout, double extrap)
+{
+    int lo = 0, hi = nout - 1;
+    while (lo < nout && xout[lo] < xin[0])
+        yout[lo++] = extrap;
+    while (hi >= 0 && xout[hi] > xin[nin - 1])
+        yout[hi--] = extrap;
+    int i = 0;
+    for (int n = lo; n <= hi; n++) {
+        i = orc_nearest(xin, xout[n], i, nin - 1);
+        if (i == nin - 1 || xout[n] < xin[i])
+            i--;
+        double dx = xin[i + 1] - xin[i];
+        double a = (xin[i + 1] - xout[n]) / dx;
+        double b = (xout[n] - xin[i]) / dx;
+        yout[n] = a * yin[i] + b * yin[i + 1] +
+                  ((a * a * a - a) * y2nd[i] + (b * b * b - b) * y2nd[i + 1]) * dx * dx / 6.0;
+    }
+}
+
+/* yout[nout,nin2] rows lo..hi-1 of the second axis; returns 1 when an xout is off the table */
+int orc_lin_interp_2D(double *yout, const double *yin, const double *xin, const double *dy_dx,
+                      int nin, int nin2, const double *xout, int nout, int lo, int hi)
+{
+    for (int i = 0; i < nout; i++) {
+        if (xout[i] < xin[0] || xout[i] > xin[nin - 1])
+            return 1;
+        int index = orc_nearest(xin, xout[i], 0, nin - 1);
+        if (index == nin - 1 || xout[i] < xin[index])
+            index--;
+        if (xin[index] == xout[i]) {
+            for (int j = lo; j < hi; j++)
+                yout[(int64_t)i * nin2 + j] = yin[(int64_t)index * nin2 + j];
+            continue;
+        }
+        double deltax = xout[i] - xin[index];
+        for (int j = lo; j < hi; j++)
+            yout[(int64_t)i * nin2 + j] =
+                yin[(int64_t)index * nin2 + j] + deltax * dy_dx[(int64_t)index * nin2 + j];
+    }
+    return 0;
+}
+
+/* =====================================================================
  * Simpson family: _simpson.c:36-203, include/simpson.h:8-47
  * ===================================================================== */
 void orc_geth(const double *h, int n, double *hsum, double *hratio, double *hfactor)

@@ -74,6 +74,18 @@ void orc_blackbody_wn_2D(double *B, const double *wn, int nwave, const double *t
                          int nlayers, const int32_t *last /* may be NULL */);
 void orc_blackbody_wn(double *B, const double *wn, int nwave, double temp);
 
+/* continuum terms with native arithmetic in the reference (_alkali.c, _spline.c) */
+void orc_alkali_cross_section(double *ec, const double *pressure, const double *wn,
+                              const double *temp, const double *voigt_det, double detuning_wn,
+                              double mass, double lorentz_par, double part_func, double cutoff,
+                              const double *wn0, const double *gf, int nlines, int nlayers,
+                              int nwave);
+void orc_second_deriv(double *y2nd, const double *yin, const double *xin, int nin);
+void orc_splinterp_1D(double *yout, const double *yin, const double *xin, const double *y2nd,
+                      int nin, const double *xout, int nout, double extrap);
+int orc_lin_interp_2D(double *yout, const double *yin, const double *xin, const double *dy_dx,
+                      int nin, int nin2, const double *xout, int nout, int lo, int hi);
+
 /* two-stream fluxes (pyrat/spectrum.py:454-522) and scipy.special.exp1 */
 double orc_exp1(double x);
 void orc_internal_flux(double *f_int, const double *wn, int nwave, double tint);

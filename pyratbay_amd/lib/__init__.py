@@ -9,7 +9,8 @@ callers that cannot be changed -- the device-resident path is pyratbay_amd.engin
     for name in hip.MODULES:                      # before `import pyratbay`
         sys.modules[f'pyratbay.lib.{name}'] = getattr(hip, name)
 """
-from . import _extcoeff, vprofile, _trapezoid, _simpson, _blackbody, cutils, _indices
+from . import (_extcoeff, vprofile, _trapezoid, _simpson, _blackbody, cutils, _indices,
+               _alkali)
 
 MODULES = ['_extcoeff', 'vprofile', '_trapezoid', '_simpson', '_blackbody', 'cutils',
-           '_indices']
+           '_indices', '_alkali']

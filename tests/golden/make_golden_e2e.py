@@ -119,37 +119,44 @@ verb = 0
 '''
 
 
+def reference_package(work):
+    """Import the real package from a scratch copy under `work` (unmodified C extensions
+    compiled in place, import stand-ins for mc3/chemcat/h5py) and return the module."""
+    shutil.copytree(os.path.join(REF, 'pyratbay'), os.path.join(work, 'pkg', 'pyratbay'))
+    os.system(f'chmod -R u+w {work}')
+    # unmodified reference extensions (all ten .c files of src_c)
+    import subprocess
+    import sysconfig
+    import numpy
+    ext = sysconfig.get_config_var('EXT_SUFFIX')
+    libdir = os.path.join(work, 'pkg', 'pyratbay', 'lib')
+    for name in ('_extcoeff', 'vprofile', '_trapezoid', '_simpson', '_blackbody', 'cutils',
+                 '_indices', '_alkali', '_pt', '_spline'):
+        subprocess.check_call(
+            ['gcc', '-shared', '-fPIC', '-O3', '-ffast-math', '-w',
+             '-I' + sysconfig.get_paths()['include'], '-I' + numpy.get_include(),
+             '-I' + os.path.join(REF, 'src_c', 'include'),
+             os.path.join(REF, 'src_c', name + '.c'), '-o',
+             os.path.join(libdir, name + ext), '-lm'])
+    for rel, text in STUBS.items():
+        path = os.path.join(work, 'stubs', rel)
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        with open(path, 'w') as f:
+            f.write(textwrap.dedent(text))
+    sys.path.insert(0, os.path.join(work, 'pkg'))
+    sys.path.insert(0, os.path.join(work, 'stubs'))
+    import matplotlib
+    matplotlib.use('Agg')
+    import pyratbay as pb
+    return pb
+
+
 def main():
     if not os.path.isdir(REF):
         sys.exit('needs /root/reference')
     work = tempfile.mkdtemp(prefix='pb_e2e_')
     try:
-        shutil.copytree(os.path.join(REF, 'pyratbay'), os.path.join(work, 'pkg', 'pyratbay'))
-        os.system(f'chmod -R u+w {work}')
-        # unmodified reference extensions (all ten .c files of src_c)
-        import subprocess
-        import sysconfig
-        import numpy
-        ext = sysconfig.get_config_var('EXT_SUFFIX')
-        libdir = os.path.join(work, 'pkg', 'pyratbay', 'lib')
-        for name in ('_extcoeff', 'vprofile', '_trapezoid', '_simpson', '_blackbody', 'cutils',
-                     '_indices', '_alkali', '_pt', '_spline'):
-            subprocess.check_call(
-                ['gcc', '-shared', '-fPIC', '-O3', '-ffast-math', '-w',
-                 '-I' + sysconfig.get_paths()['include'], '-I' + numpy.get_include(),
-                 '-I' + os.path.join(REF, 'src_c', 'include'),
-                 os.path.join(REF, 'src_c', name + '.c'), '-o',
-                 os.path.join(libdir, name + ext), '-lm'])
-        for rel, text in STUBS.items():
-            path = os.path.join(work, 'stubs', rel)
-            os.makedirs(os.path.dirname(path), exist_ok=True)
-            with open(path, 'w') as f:
-                f.write(textwrap.dedent(text))
-        sys.path.insert(0, os.path.join(work, 'pkg'))
-        sys.path.insert(0, os.path.join(work, 'stubs'))
-        import matplotlib
-        matplotlib.use('Agg')
-        import pyratbay as pb
+        pb = reference_package(work)
 
         def run(cfg_text, name, **kw):
             cfg = os.path.join(work, name + '.cfg')

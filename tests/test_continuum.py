@@ -1,0 +1,230 @@
+"""Continuum opacity terms: Rayleigh, Lecavelier, gray cloud, CIA,
+H- and the alkali doublets.  The fixture tests/golden/g7_continuum.npz holds what the REAL
+reference classes return (tests/golden/make_golden_continuum.py).  CPU tests pin the
+oracle's restatement to it; GPU tests compare the HIP kernels with both."""
+import numpy as np
+import pytest
+
+RTOL = 1e-12
+
+
+@pytest.fixture(scope='module')
+def g(golden):
+    return golden('g7_continuum')
+
+
+@pytest.fixture(scope='module')
+def cont():
+    from oracle import continuum
+    return continuum
+
+
+def dens(g, key):
+    return float(g[f'vmr_{key}']) * g['dens_tot']
+
+
+def test_oracle_constants_match_fixture(g, cont):
+    assert cont.AMAGAT == float(g['amagat']) and cont.K == float(g['k_boltz'])
+    np.testing.assert_allclose(cont.nominal_density(g['pressure'], g['temp']), g['dens_tot'],
+                               rtol=1e-15)
+
+
+def test_oracle_rayleigh_lecavelier_gray(g, cont):
+    for species, key in (('H', 'H'), ('He', 'He'), ('H2', 'H2'), ('e-', 'e')):
+        cs = cont.rayleigh_cross_section(g['wn'], species)
+        np.testing.assert_allclose(cs, g[f'ray_{key}_cs'], rtol=1e-14)
+        np.testing.assert_allclose(cs * dens(g, key)[:, None], g[f'ray_{key}_ec'], rtol=1e-14)
+    cs = cont.lecavelier_cross_section(g['wn'], g['lec_pars'])
+    np.testing.assert_allclose(cs, g['lec_cs'], rtol=1e-14)
+    np.testing.assert_allclose(cs * g['dens_tot'][:, None], g['lec_ec'], rtol=1e-14)
+    layer = cont.gray_layer_cross_section(g['pressure'], g['gray_pars']) * g['dens_tot']
+    assert 0 < np.count_nonzero(layer) < len(layer)
+    np.testing.assert_allclose(layer[:, None] * np.ones(len(g['wn'])), g['gray_ec'], rtol=1e-14)
+
+
+def test_oracle_cia(g, cont):
+    for tag in ('h2h2', 'h2he'):
+        lo, hi = g[f'cia_{tag}_lohi']
+        cs = cont.cia_cross_section(g[f'cia_{tag}_tab'], g[f'cia_{tag}_temps'], g['temp'],
+                                    int(lo), int(hi))
+        np.testing.assert_allclose(cs, g[f'cia_{tag}_cs'], rtol=1e-14)
+        ec = cs * np.prod(g[f'cia_{tag}_dens'], axis=1, keepdims=True)
+        np.testing.assert_allclose(ec, g[f'cia_{tag}_ec'], rtol=1e-14)
+        assert hi < len(g['wn']) and np.all(cs[:, hi:] == 0)
+    with pytest.raises(ValueError):
+        cont.cia_cross_section(g['cia_h2he_tab'], g['cia_h2he_temps'], np.array([10.0]), 0, 5)
+    # the spline resampling of a raw table onto the model grid (init-time host work)
+    y, x = g['cia_raw_absorption'][1], g['cia_raw_wn']
+    ddev = cont.second_deriv(y, x)
+    np.testing.assert_allclose(ddev, g['cia_raw_ddev'], rtol=1e-12, atol=1e-30)
+    np.testing.assert_allclose(cont.splinterp_1D(y, x, ddev, g['wn'], 0.0), g['cia_raw_interp'],
+                               rtol=1e-12, atol=1e-30)
+
+
+def test_oracle_hminus(g, cont):
+    np.testing.assert_allclose(cont.hminus_sigma_bf(g['wn']), g['hm_sigma_bf'], rtol=1e-14)
+    bf, ff = cont.hminus_cross_sections(g['wn'], g['temp'])
+    np.testing.assert_allclose(bf, g['hm_cs_bf'], rtol=1e-13)
+    np.testing.assert_allclose(ff, g['hm_cs_ff'], rtol=1e-13)
+    ec = (bf + ff) * np.prod(g['hm_dens'], axis=1, keepdims=True)
+    np.testing.assert_allclose(ec, g['hm_ec'], rtol=1e-13)
+
+
+def test_oracle_alkali(g, cont):
+    for tag, key in (('na', 'Na'), ('k', 'K')):
+        det, mass, lpar, Z, cutoff = g[f'alk_{tag}_scalars']
+        cs = cont.alkali_cross_section(g['pressure'] * float(g['bar']), g['wn'], g['temp'],
+                                       g[f'alk_{tag}_voigt_det'], det, mass, lpar, Z, cutoff,
+                                       g[f'alk_{tag}_wn0'], g[f'alk_{tag}_gf'])
+        assert np.array_equal(cs == 0, g[f'alk_{tag}_cs'] == 0)
+        np.testing.assert_allclose(cs, g[f'alk_{tag}_cs'], rtol=RTOL)
+        np.testing.assert_allclose(cs * dens(g, key)[:, None], g[f'alk_{tag}_ec'], rtol=RTOL)
+
+
+# --------------------------------------------------------------------------
+# HIP path
+# --------------------------------------------------------------------------
+@pytest.fixture(scope='module')
+def eng():
+    from pyratbay_amd import engine
+    engine.require_gpu()
+    return engine
+
+
+def density_dict(g):
+    return {'H': dens(g, 'H'), 'He': dens(g, 'He'), 'H2': dens(g, 'H2'), 'e-': dens(g, 'e'),
+            'Na': dens(g, 'Na'), 'K': dens(g, 'K')}
+
+
+def cia_models(g, ct):
+    out = []
+    for tag, species in (('h2h2', ['H2', 'H2']), ('h2he', ['H2', 'He'])):
+        m = ct.Collision_Induced.__new__(ct.Collision_Induced)
+        m.species, m.nspec = species, 2
+        m.tab_cross_section, m.temps = g[f'cia_{tag}_tab'], g[f'cia_{tag}_temps']
+        m.ntemp, m.tmin, m.tmax = len(m.temps), m.temps.min(), m.temps.max()
+        m._wn_lo_idx, m._wn_hi_idx = (int(v) for v in g[f'cia_{tag}_lohi'])
+        out.append(m)
+    return out
+
+
+@pytest.mark.gpu
+def test_hip_each_family_vs_reference(eng, g):
+    """One family at a time, so that a term cannot hide behind a larger one."""
+    from pyratbay_amd import continuum as ct
+    wn, pressure, temp = g['wn'], g['pressure'], g['temp']
+    d = density_dict(g)
+    L, W = len(temp), len(wn)
+
+    def run(models, start=0.0):
+        ec = eng.dev(np.full((L, W), start))
+        ct.Continuum(wn, pressure, models).add(ec, temp, d)
+        return ec.cpu().numpy()
+
+    for species, key in (('H', 'H'), ('He', 'He'), ('H2', 'H2'), ('e-', 'e')):
+        np.testing.assert_allclose(run([ct.Kurucz(wn, species)]), g[f'ray_{key}_ec'], rtol=RTOL)
+    lec = ct.Lecavelier(pressure, wn=wn)
+    lec.calc_cross_section(g['lec_pars'])
+    np.testing.assert_allclose(run([lec]), g['lec_ec'], rtol=RTOL)
+    gray = ct.CCSgray(pressure, wn)
+    gray.pars[:] = g['gray_pars']
+    np.testing.assert_allclose(run([gray]), g['gray_ec'], rtol=RTOL)
+    for m, tag in zip(cia_models(g, ct), ('h2h2', 'h2he')):
+        got = run([m])
+        assert np.array_equal(got == 0, g[f'cia_{tag}_ec'] == 0)
+        np.testing.assert_allclose(got, g[f'cia_{tag}_ec'], rtol=RTOL)
+    np.testing.assert_allclose(run([ct.Hydrogen_Ion(wn)]), g['hm_ec'], rtol=RTOL)
+    for cls, tag in ((ct.SodiumVdW, 'na'), (ct.PotassiumVdW, 'k')):
+        model = cls(pressure, wn=wn)
+        np.testing.assert_allclose(model.voigt_det(temp), g[f'alk_{tag}_voigt_det'], rtol=1e-11)
+        got = run([model])
+        assert np.array_equal(got == 0, g[f'alk_{tag}_ec'] == 0)
+        np.testing.assert_allclose(got, g[f'alk_{tag}_ec'], rtol=1e-10)
+    # accumulation: the terms are ADDED to what the line-by-line stage left in ec
+    np.testing.assert_allclose(run([ct.Kurucz(wn, 'H2')], start=1e-9),
+                               1e-9 + g['ray_H2_ec'], rtol=RTOL)
+
+
+@pytest.mark.gpu
+def test_hip_all_terms_fused(eng, g):
+    from pyratbay_amd import continuum as ct
+    wn, pressure, temp = g['wn'], g['pressure'], g['temp']
+    lec = ct.Lecavelier(pressure, wn=wn)
+    lec.calc_cross_section(g['lec_pars'])
+    gray = ct.CCSgray(pressure, wn)
+    gray.pars[:] = g['gray_pars']
+    models = ([ct.Kurucz(wn, s) for s in ('H', 'He', 'H2', 'e-')] + [lec, gray]
+              + cia_models(g, ct) + [ct.Hydrogen_Ion(wn), ct.SodiumVdW(pressure, wn=wn),
+                                     ct.PotassiumVdW(pressure, wn=wn)])
+    ec = eng.dev(np.zeros((len(temp), len(wn))))
+    ct.Continuum(wn, pressure, models).add(ec, temp, density_dict(g))
+    want = sum(g[k] for k in ('ray_H_ec', 'ray_He_ec', 'ray_H2_ec', 'ray_e_ec', 'lec_ec',
+                              'gray_ec', 'cia_h2h2_ec', 'cia_h2he_ec', 'hm_ec', 'alk_na_ec',
+                              'alk_k_ec'))
+    np.testing.assert_allclose(ec.cpu().numpy(), want, rtol=1e-11)
+    with pytest.raises(ValueError):
+        ct.Continuum(wn, pressure, cia_models(g, ct)).add(ec, np.full(len(temp), 20.0),
+                                                          density_dict(g))
+
+
+@pytest.mark.gpu
+def test_hip_alkali_dropin(eng, g):
+    """pyratbay_amd.lib._alkali.alkali_cross_section: the reference's positional signature."""
+    from pyratbay_amd.lib import _alkali
+    det, mass, lpar, Z, cutoff = g['alk_na_scalars']
+    cs = np.zeros_like(g['alk_na_cs'])
+    wn = g['wn']
+    i_wn0 = np.argmin(np.abs(np.expand_dims(g['alk_na_wn0'], 1) - wn), axis=1)
+    assert _alkali.alkali_cross_section(
+        g['pressure'] * float(g['bar']), wn, g['temp'], g['alk_na_voigt_det'], cs, det, mass,
+        lpar, Z, cutoff, g['alk_na_wn0'], g['alk_na_gf'], g['alk_na_dwave'], i_wn0) == 1
+    np.testing.assert_allclose(cs, g['alk_na_cs'], rtol=1e-10)
+    # descending grid (the reference flips its loop, _alkali.c:55,79-82)
+    cs2 = np.zeros_like(cs)
+    _alkali.alkali_cross_section(
+        g['pressure'] * float(g['bar']), wn[::-1].copy(), g['temp'], g['alk_na_voigt_det'], cs2,
+        det, mass, lpar, Z, cutoff, g['alk_na_wn0'], g['alk_na_gf'], g['alk_na_dwave'], i_wn0)
+    np.testing.assert_allclose(cs2[:, ::-1], g['alk_na_cs'], rtol=1e-10)
+
+
+def test_front_end_host_precomputes(g):
+    """CPU: the grid-only precomputes of the front-end classes against the fixture."""
+    from pyratbay_amd import continuum as ct
+    wn = g['wn']
+    for species, key in (('H', 'H'), ('He', 'He'), ('H2', 'H2'), ('e-', 'e')):
+        np.testing.assert_allclose(ct.Kurucz(wn, species).cross_section, g[f'ray_{key}_cs'],
+                                   rtol=1e-14)
+    hm = ct.Hydrogen_Ion(wn)
+    np.testing.assert_allclose(hm.sigma_bf, g['hm_sigma_bf'], rtol=1e-14)
+    y, x = g['cia_raw_absorption'][1], g['cia_raw_wn']
+    ddev = ct.second_deriv(y, x)
+    np.testing.assert_allclose(ddev, g['cia_raw_ddev'], rtol=1e-12, atol=1e-30)
+    np.testing.assert_allclose(ct.splinterp_1D(y, x, ddev, wn, 0.0), g['cia_raw_interp'],
+                               rtol=1e-12, atol=1e-30)
+    for cls, tag in ((ct.SodiumVdW, 'na'), (ct.PotassiumVdW, 'k')):
+        model = cls(g['pressure'], wn=wn)
+        np.testing.assert_allclose(model.voigt_det(g['temp']), g[f'alk_{tag}_voigt_det'],
+                                   rtol=1e-11)
+        assert [model.detuning, model.mass, model.lpar, model.Z, model.cutoff] == list(
+            g[f'alk_{tag}_scalars'])
+
+
+def test_front_end_reads_cia_file(tmp_path, g):
+    """read_cs + spline resampling reproduce a table written in the reference's format."""
+    from pyratbay_amd import continuum as ct
+    temps = np.array([100.0, 550.0, 1000.0])
+    tab_wn = np.linspace(1000.0, 30000.0, 60)
+    cs = np.array([np.linspace(1, 2, 60) * 1e-6, np.linspace(2, 4, 60) * 1e-6,
+                   np.linspace(3, 7, 60) * 1e-6])
+    path = tmp_path / 'mock_cia.dat'
+    with open(path, 'w') as f:
+        f.write('# mock\n\n@SPECIES\nH2 He\n\n@TEMPERATURES\n        '
+                + ' '.join(f'{t:.0f}' for t in temps) + '\n\n# wn, cia\n@DATA\n')
+        for i, w in enumerate(tab_wn):
+            f.write(f'{w:10.1f} ' + ' '.join(f'{v:.6e}' for v in cs[:, i]) + '\n')
+    model = ct.Collision_Induced(str(path), wn=g['wn'])
+    assert model.species == ['H2', 'He'] and np.array_equal(model.temps, temps)
+    assert model.tab_cross_section.shape == (3, len(g['wn']))
+    # straight lines are reproduced by the spline; units per (molec cm-3)^2
+    want = np.interp(g['wn'], tab_wn, cs[1]) / ct.AMAGAT**2
+    np.testing.assert_allclose(model.tab_cross_section[1], want, rtol=3e-6)   # "%.6e" in the file
