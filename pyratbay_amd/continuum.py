@@ -264,19 +264,20 @@ class VanderWaals:
         Cc = np.array([[-0.3085, 0.5906, -0.3085, 0.5906]]).T
         D = np.array([[0.0210, -1.1858, -0.0210, 1.1858]]).T
         out = np.zeros((len(temperature), self.nlines))
+        ln2 = np.sqrt(np.log(2))
         for j, wn0 in enumerate(self.wn0):
-            dop = np.sqrt(2 * K * temperature / (self.mass * AMU)) * wn0 / LS
-            for i in range(len(temperature)):
-                x, hl, hg = wn0 + dsigma[i], lor[i], dop[i]
-                if hl / hg < 0.1:
-                    sigma = hg / np.sqrt(np.log(2))
-                    z = (x + 1j * hl - wn0) / sigma
-                    out[i, j] = wofz(z).real / (sigma * np.sqrt(np.pi))
-                else:
-                    X = (x - wn0) * np.sqrt(np.log(2)) / hg
-                    Y = hl * np.sqrt(np.log(2)) / hg
-                    V = np.sum((Cc * (Y - A) + D * (X - B)) / ((Y - A)**2 + (X - B)**2), axis=0)
-                    out[i, j] = np.squeeze(V) * np.sqrt(np.pi * np.log(2.0)) / (np.pi * hg)
+            hg = np.sqrt(2 * K * temperature / (self.mass * AMU)) * wn0 / LS
+            x = wn0 + dsigma
+            # Faddeeva branch
+            sigma = hg / ln2
+            z = (x + 1j * lor - wn0) / sigma
+            faddeeva = wofz(z).real / (sigma * np.sqrt(np.pi))
+            # rational branch (all layers at once; rows = the four terms)
+            X = (x - wn0) * ln2 / hg
+            Y = lor * ln2 / hg
+            V = np.sum((Cc * (Y - A) + D * (X - B)) / ((Y - A)**2 + (X - B)**2), axis=0)
+            rational = V * np.sqrt(np.pi * np.log(2.0)) / (np.pi * hg)
+            out[:, j] = np.where(lor / hg < 0.1, faddeeva, rational)
         return out
 
 
