@@ -529,8 +529,9 @@ class TableSpectrum:
     layer temperatures, weights by the species densities, and runs optical depth + RT."""
 
     def __init__(self, etable, ttable, wn, radius, rstar, rt_path='transit', itop=0,
-                 maxdepth=10.0, quadrature_mu=None, quadrature_weights=None):
+                 maxdepth=10.0, quadrature_mu=None, quadrature_weights=None, continuum=None):
         require_gpu()
+        self.continuum = continuum          # pyratbay_amd.continuum.Continuum or None
         self.etable = etable if isinstance(etable, torch.Tensor) else dev(etable)
         self.nspec, self.ntemp, self.nlayers, self.nwave = self.etable.shape
         self.ttable = dev(ttable)
@@ -551,13 +552,17 @@ class TableSpectrum:
         else:
             self.intervals = dev(-np.diff(np.asarray(radius, float)))
 
-    def eval(self, temp, dens):
+    def eval(self, temp, dens, continuum_density=None):
         """temp[L] (K, inside the table's range -- the caller rejects the rest like
-        line_sampling.py:426-427), dens[L, nspec] (molecules cm-3) -> spectrum[W]."""
+        line_sampling.py:426-427), dens[L, nspec] (molecules cm-3) -> spectrum[W].
+        With a Continuum attached, continuum_density = {species: n[L]} feeds its terms
+        (pyrat/opacity.py:206-257: every model adds to the same ec)."""
         self.temp = temp if isinstance(temp, torch.Tensor) else dev(temp)
         dens = dens if isinstance(dens, torch.Tensor) else dev(dens)
         self.ec.zero_()
         interp_ec(self.ec, self.etable, self.ttable, self.temp, dens, 0, self.nlayers)
+        if self.continuum is not None:
+            self.continuum.add(self.ec, self.temp.cpu().numpy(), continuum_density)
         if self.rt_path == 'transit':
             self.spectrum, self.depth, self.ideep = transit_spectrum(
                 self.ec, self.raypath, self.radius, self.rstar, self.itop, self.nlayers,

@@ -136,7 +136,7 @@ def test_hip_each_family_vs_reference(eng, g):
     np.testing.assert_allclose(run([ct.Hydrogen_Ion(wn)]), g['hm_ec'], rtol=RTOL)
     for cls, tag in ((ct.SodiumVdW, 'na'), (ct.PotassiumVdW, 'k')):
         model = cls(pressure, wn=wn)
-        np.testing.assert_allclose(model.voigt_det(temp), g[f'alk_{tag}_voigt_det'], rtol=1e-11)
+        np.testing.assert_allclose(model.voigt_det(temp), g[f'alk_{tag}_voigt_det'], rtol=1e-9)
         got = run([model])
         assert np.array_equal(got == 0, g[f'alk_{tag}_ec'] == 0)
         np.testing.assert_allclose(got, g[f'alk_{tag}_ec'], rtol=1e-10)
@@ -204,7 +204,7 @@ def test_front_end_host_precomputes(g):
     for cls, tag in ((ct.SodiumVdW, 'na'), (ct.PotassiumVdW, 'k')):
         model = cls(g['pressure'], wn=wn)
         np.testing.assert_allclose(model.voigt_det(g['temp']), g[f'alk_{tag}_voigt_det'],
-                                   rtol=1e-11)
+                                   rtol=1e-9)
         assert [model.detuning, model.mass, model.lpar, model.Z, model.cutoff] == list(
             g[f'alk_{tag}_scalars'])
 

@@ -1,0 +1,120 @@
+"""The widened path end to end against the REAL reference package
+(tests/golden/g8_table_run_{transit,emission}.npz, made by
+tests/golden/make_golden_table_run.py): sampled cross-section table -> interp_ec, plus the
+potassium doublet, two CIA tables, H2 Rayleigh and a Lecavelier haze added to the same
+extinction coefficient, optical depth, spectrum, four top-hat band integrals.
+
+CPU test: the oracle's pieces chained the same way.  GPU test: TableSpectrum + Continuum +
+PassBands."""
+import numpy as np
+import pytest
+
+RTOL = 1e-11
+
+
+def load(golden, rt):
+    g = golden(f'g8_table_run_{rt}')
+    species = [str(s) for s in g['species']]
+    dens = {s: np.ascontiguousarray(g['dens'][:, i]) for i, s in enumerate(species)}
+    dens['e-'] = dens.get('e-', np.zeros(len(g['temp'])))
+    return g, species, dens
+
+
+def bands_of(g):
+    out = []
+    for i in range(int(g['nbands'])):
+        resp = g[f'band{i}_response'] * (g[f'band{i}_wl'] if bool(g[f'band{i}_photon']) else 1.0)
+        out.append((int(g[f'band{i}_idx'][0]), resp, float(g[f'band{i}_height'])))
+        assert np.array_equal(g[f'band{i}_idx'], out[-1][0] + np.arange(len(resp)))
+    return out
+
+
+@pytest.mark.parametrize('rt', ['transit', 'emission'])
+def test_oracle_chain_reproduces_reference_run(orc, golden, rt):
+    from oracle import continuum as cont
+    g, species, dens = load(golden, rt)
+    wn, temp, press = g['wn'], g['temp'], g['press']
+    L, W = len(temp), len(wn)
+    # models in the reference's order: line_sample, alkali, cia, cia, rayleigh, cloud
+    table_species = [str(s) for s in g['table_species']]
+    etable = np.ascontiguousarray(g['table_opacity'][None] if g['table_opacity'].ndim == 3
+                                  else g['table_opacity'])
+    ec = np.zeros((L, W))
+    d_tab = np.ascontiguousarray(np.array([dens[s] for s in table_species]).T)
+    orc.interp_ec(ec, etable, g['table_temperature'], temp, d_tab, 0, L)
+    ec += cont.alkali_cross_section(press * 1e6 if press.max() < 1e4 else press, wn, temp,
+                                    g['alk_voigt_det'], 20.0, 39.0983, 0.14, 2.0,
+                                    float(g['alk_cutoff']), [12988.76, 13046.486],
+                                    [0.701455, 1.40929]) * dens['K'][:, None]
+    for c in range(2):
+        pair = [str(s) for s in g[f'cia{c}_species']]
+        lo, hi = (int(v) for v in g[f'cia{c}_lohi'])
+        cs = cont.cia_cross_section(g[f'cia{c}_tab'], g[f'cia{c}_temps'], temp, lo, hi)
+        ec += cs * (dens[pair[0]] * dens[pair[1]])[:, None]
+    ec += cont.rayleigh_cross_section(wn, 'H2') * dens['H2'][:, None]
+    p_bar = press / 1e6 if press.max() > 1e4 else press
+    ec += cont.lecavelier_cross_section(wn, g['lec_pars']) * cont.nominal_density(
+        p_bar, temp)[:, None]
+    np.testing.assert_allclose(ec, g['ec'], rtol=RTOL)
+    itop = int(g['rtop'])
+    if rt == 'transit':
+        depth, ideep = orc.optical_depth_transit(ec, g['radius'], itop, L, float(g['maxdepth']))
+        spectrum = orc.transmission(depth, g['radius'], float(g['rstar']), ideep, itop)
+    else:
+        depth = np.zeros((L, W))
+        ideep = np.full(W, L - 1, np.int32)
+        orc.plane_parallel_optical_depth(depth, ideep, ec, -orc.ediff(g['radius']),
+                                         float(g['maxdepth']), itop, L)
+        B = orc.blackbody_wn_2D(wn, temp)
+        inten = orc.intensity(depth, ideep, B, g['quadrature_mu'], itop)
+        spectrum = np.sum(inten * g['quadrature_weights'][:, None], axis=0)
+    assert np.array_equal(ideep, g['ideep'])
+    np.testing.assert_allclose(depth, g['depth'], rtol=RTOL)
+    np.testing.assert_allclose(spectrum, g['spectrum'], rtol=RTOL)
+    flux = [np.trapezoid(spectrum[s:s + len(r)] * r, wn[s:s + len(r)]) * h
+            for s, r, h in bands_of(g)]
+    np.testing.assert_allclose(flux, g['bandflux'], rtol=RTOL)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('rt', ['transit', 'emission'])
+def test_hip_chain_reproduces_reference_run(golden, rt):
+    from pyratbay_amd import engine, continuum as ct
+    engine.require_gpu()
+    g, species, dens = load(golden, rt)
+    wn, temp = g['wn'], g['temp']
+    p_bar = g['press'] / 1e6 if g['press'].max() > 1e4 else g['press']
+    cia = []
+    for c in range(2):
+        m = ct.Collision_Induced.__new__(ct.Collision_Induced)
+        m.species, m.nspec = [str(s) for s in g[f'cia{c}_species']], 2
+        m.tab_cross_section, m.temps = g[f'cia{c}_tab'], g[f'cia{c}_temps']
+        m.ntemp, m.tmin, m.tmax = len(m.temps), m.temps.min(), m.temps.max()
+        m._wn_lo_idx, m._wn_hi_idx = (int(v) for v in g[f'cia{c}_lohi'])
+        cia.append(m)
+    lec = ct.Lecavelier(p_bar, wn=wn)
+    lec.calc_cross_section(g['lec_pars'])
+    potassium = ct.PotassiumVdW(p_bar, wn=wn, cutoff=float(g['alk_cutoff']))
+    # host-side Voigt at the detuning distance: the rational branch sums four terms that
+    # cancel to ~1e-4 of their size, so the last digits depend on the summation order
+    np.testing.assert_allclose(potassium.voigt_det(temp), g['alk_voigt_det'], rtol=1e-9)
+    cont = ct.Continuum(wn, p_bar, [potassium] + cia + [ct.Kurucz(wn, 'H2'), lec])
+    etable = g['table_opacity'][None] if g['table_opacity'].ndim == 3 else g['table_opacity']
+    kw = {}
+    if rt == 'emission':
+        kw = dict(quadrature_mu=g['quadrature_mu'], quadrature_weights=g['quadrature_weights'])
+    model = engine.TableSpectrum(etable, g['table_temperature'], wn, g['radius'],
+                                 float(g['rstar']), rt_path=rt, itop=int(g['rtop']),
+                                 maxdepth=float(g['maxdepth']), continuum=cont, **kw)
+    d_tab = np.ascontiguousarray(np.array([dens[str(s)] for s in g['table_species']]).T)
+    spectrum = model.eval(temp, d_tab, dens)
+    np.testing.assert_allclose(model.ec.cpu().numpy(), g['ec'], rtol=1e-10)
+    assert np.array_equal(model.ideep.cpu().numpy(), g['ideep'])
+    np.testing.assert_allclose(model.depth.cpu().numpy(), g['depth'], rtol=1e-10)
+    np.testing.assert_allclose(spectrum.cpu().numpy(), g['spectrum'], rtol=1e-10)
+    bands = engine.PassBands(wn, bands_of(g))
+    flux = (bands.partial_integrate(spectrum) * bands.heights).cpu().numpy()
+    np.testing.assert_allclose(flux, g['bandflux'], rtol=1e-10)
+    print(f'{rt}: spectrum max rel err vs pb.run() = '
+          f'{np.max(np.abs(spectrum.cpu().numpy() / g["spectrum"] - 1)):.2e}; bandflux '
+          f'{np.max(np.abs(flux / g["bandflux"] - 1)):.2e}')
