@@ -394,12 +394,16 @@ class LBLSpectrum:
 
     def __init__(self, case, rt_path='transit', wbegin=0, wcount=None, itop=0,
                  quadrature_mu=None, quadrature_weights=None, keep_flat=False,
-                 voigt=None, lines=None, tint=0.0, flux_top=None):
+                 voigt=None, lines=None, tint=0.0, flux_top=None, continuum=None,
+                 continuum_density=None):
         require_gpu()
         g, atm, ln, iso, vg = (case['grid'], case['atm'], case['lines'], case['iso'],
                                case['voigt'])
         self.case = case
         self.rt_path = rt_path
+        # optional continuum terms (pyratbay_amd.continuum.Continuum on this shard's grid)
+        # and the host-side number densities {species: n[L]} they use
+        self.continuum, self.continuum_density = continuum, continuum_density
         self.nwave = g['nwave']
         self.nlayers = atm['nlayers']
         self.wbegin = wbegin
@@ -460,6 +464,9 @@ class LBLSpectrum:
     def extinction(self):
         self.lbl.extinction(self.temp, self.dens, self.isoz, add=True, out=self.ec,
                             wbegin=self.wbegin, wcount=self.wcount)
+        if self.continuum is not None:
+            self.continuum.add(self.ec.view(self.nlayers, self.wcount), self.case['atm']['temp'],
+                               self.continuum_density)
         return self.ec
 
     def optical_depth(self):

@@ -175,3 +175,31 @@ def test_hip_graph_replay(eng, case):
     fresh = eng.LBLSpectrum(case, rt_path='transit', voigt=model.voigt, lines=model.lines)
     fresh.set_atmosphere(temp, atm['dens'], isoz)
     assert np.array_equal(hot, fresh.run().cpu().numpy())
+
+
+def test_lbl_with_continuum(eng, case, orc):
+    """Line-by-line extinction + continuum terms in the same ec, then the transit stages."""
+    from pyratbay_amd import continuum as ct
+    from oracle import continuum as oc
+    g, atm = case['grid'], case['atm']
+    wn, temp = g['wn'], atm['temp']
+    pressure = np.logspace(-6, 2, atm['nlayers'])
+    n_h2 = pressure * ct.BAR / (ct.K * temp) * 0.85
+    lec = ct.Lecavelier(pressure, wn=wn)
+    lec.calc_cross_section([1.0, -3.0])
+    cont = ct.Continuum(wn, pressure, [ct.Kurucz(wn, 'H2'), lec])
+    plain = eng.LBLSpectrum(case, rt_path='transit')
+    plain.run()
+    model = eng.LBLSpectrum(case, rt_path='transit', voigt=plain.voigt, lines=plain.lines,
+                            continuum=cont, continuum_density={'H2': n_h2})
+    spectrum = model.run().cpu().numpy()
+    want_ec = (plain.ec.cpu().numpy()[:, 0]
+               + oc.rayleigh_cross_section(wn, 'H2') * n_h2[:, None]
+               + oc.lecavelier_cross_section(wn, [1.0, -3.0])
+               * oc.nominal_density(pressure, temp)[:, None])
+    np.testing.assert_allclose(model.ec.cpu().numpy()[:, 0], want_ec, rtol=1e-12)
+    depth, ideep = orc.optical_depth_transit(want_ec, atm['radius'], 0, atm['nlayers'],
+                                             case['maxdepth'])
+    want = orc.transmission(depth, atm['radius'], float(atm['rstar']), ideep, 0)
+    np.testing.assert_allclose(spectrum, want, rtol=1e-11)
+    assert np.all(spectrum >= plain.spectrum.cpu().numpy())
