@@ -566,92 +566,103 @@ __device__ inline int floor_div_inv(int a, double inv)
     return (int)floor(((double)a + 0.5) * inv);
 }
 
+constexpr int kRecLayers = 4;        // layers per thread of k_records (group data loaded once)
+
 __global__ __launch_bounds__(kBlock) void k_records(LblArgs a)
 {
-    extern __shared__ unsigned long long s_max[];                 // [nrows]
-    double *s_dop = reinterpret_cast<double *>(s_max + a.nrows); // [ndop] Doppler grid
-    const int layer = blockIdx.y;
+    extern __shared__ unsigned long long s_max[];                 // [kRecLayers][nrows]
+    double *s_dop = reinterpret_cast<double *>(s_max + kRecLayers * a.nrows);   // [ndop]
+    const int layer0 = blockIdx.y * kRecLayers;
     const int64_t g = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    for (int r = threadIdx.x; r < a.nrows; r += kBlock)
+    for (int r = threadIdx.x; r < kRecLayers * a.nrows; r += kBlock)
         s_max[r] = 0ull;
     for (int d = threadIdx.x; d < a.ndop; d += kBlock)
         s_dop[d] = a.doppler[d];
     __syncthreads();
-    double k = 0.0, lmax = 0.0;
-    int ulo = 0, uhi = 0, q = 0, cell = 0, phi = 0, row = -1;
-    // layers of the resident-profile kernel are walked in position order
-    const bool pos = a.rec32 != nullptr || (a.res_cap > 0 && a.ls_resident[layer]);
-    const int32_t *rk_iso = pos ? a.giso : a.rk_iso;
-    const int32_t *rk_first = pos ? a.gfirst : a.rk_first;
-    const int32_t *rk_count = pos ? a.gcount : a.rk_count;
-    const int32_t *rk_iown = pos ? a.giown : a.rk_iown;
-    const double *rk_lwn = pos ? a.g_lead : a.rk_lwn;
-    const double *rk_elow = pos ? a.g_lead + a.ngroups : a.rk_elow;
-    const double *rk_gf = pos ? a.g_lead + 2 * a.ngroups : a.rk_gf;
-    if (g < a.ngroups) {
-        const int iso = rk_iso[g];
-        row = a.isoiext[iso];
-        if (row >= 0 && a.add)
-            row = 0;
-        if (row >= 0) {
-            const int64_t li = (int64_t)layer * a.niso + iso;
-            const double temp = a.temp[layer];
-            const double ratio = a.isoratio[iso];
-            const double z = a.li_z[li];
-            const int first = rk_first[g];
-            const int count = rk_count[g];
-            const int iown = rk_iown[g];
-            const double wavn = rk_lwn[g];            // leader's record, in walk order
-            k = line_strength(ratio, rk_gf[g], rk_elow[g], wavn, temp, z);
-            lmax = k;
-            for (int m = 1; m < count; m++) {
-                const double kp = line_strength(ratio, a.gf[first + m], a.elow[first + m],
-                                                a.lwn[first + m], temp, z);
-                k += kp;
-                lmax = fmax(lmax, kp);
+    // the group's static data, in the order this layer's gather kernel walks the groups
+    // (layers of the resident-profile and scatter kernels: position order)
+    int iso = 0, first = 0, count = 0, iown = 0;
+    double wavn = 0.0, elow = 0.0, gf = 0.0;
+    int loaded = -1;                                              // 0 / 1 = order in registers
+    for (int i = 0; i < kRecLayers; i++) {
+        const int layer = layer0 + i;
+        if (layer >= a.nlayers)
+            break;
+        const int pos = (a.rec32 != nullptr || (a.res_cap > 0 && a.ls_resident[layer])) ? 1 : 0;
+        if (pos != loaded && g < a.ngroups) {                     // wave-uniform
+            iso = (pos ? a.giso : a.rk_iso)[g];
+            first = (pos ? a.gfirst : a.rk_first)[g];
+            count = (pos ? a.gcount : a.rk_count)[g];
+            iown = (pos ? a.giown : a.rk_iown)[g];
+            wavn = (pos ? a.g_lead : a.rk_lwn)[g];                // leader's record
+            elow = (pos ? a.g_lead + a.ngroups : a.rk_elow)[g];
+            gf = (pos ? a.g_lead + 2 * a.ngroups : a.rk_gf)[g];
+        }
+        loaded = pos;
+        double k = 0.0, lmax = 0.0;
+        int ulo = 0, uhi = 0, q = 0, cell = 0, phi = 0, row = -1;
+        if (g < a.ngroups) {
+            row = a.isoiext[iso];
+            if (row >= 0 && a.add)
+                row = 0;
+            if (row >= 0) {
+                const int64_t li = (int64_t)layer * a.niso + iso;
+                const double temp = a.temp[layer];
+                const double ratio = a.isoratio[iso];
+                const double z = a.li_z[li];
+                k = line_strength(ratio, gf, elow, wavn, temp, z);
+                lmax = k;
+                for (int m = 1; m < count; m++) {
+                    const double kp = line_strength(ratio, a.gf[first + m], a.elow[first + m],
+                                                    a.lwn[first + m], temp, z);
+                    k += kp;
+                    lmax = fmax(lmax, kp);
+                }
+                const int ofactor = a.ls_ofactor[layer];
+                const int scale = a.ls_scale[layer];
+                const Window w = group_window(a, wavn, iown, a.li_ilor[li], a.li_alphad[li],
+                                              ofactor, a.ls_dwnstep[layer], a.ls_dnwn[layer], 0,
+                                              a.ndop - 1, s_dop);
+                // kept samples: minj <= scale*jo < maxj, inside the profile and the grid
+                const double inv_scale = 1.0 / (double)scale;
+                ulo = -floor_div_inv(-(int)w.minj, inv_scale);
+                uhi = -floor_div_inv(-(int)w.maxj, inv_scale);
+                ulo = max(ulo, -floor_div_inv(w.half - iown, a.inv_osamp));
+                uhi = min(uhi, floor_div_inv(iown + w.half, a.inv_osamp) + 1);
+                uhi = min(uhi, a.nwave);
+                q = floor_div_inv(w.half - iown, a.inv_osamp);
+                phi = (w.half - iown) - q * a.osamp;
+                cell = w.cell;
+                if (uhi < ulo)
+                    uhi = ulo;
             }
-            const int ofactor = a.ls_ofactor[layer];
-            const int scale = a.ls_scale[layer];
-            const Window w = group_window(a, wavn, iown, a.li_ilor[li], a.li_alphad[li],
-                                          ofactor, a.ls_dwnstep[layer], a.ls_dnwn[layer], 0,
-                                          a.ndop - 1, s_dop);
-            // kept samples: minj <= scale*jo < maxj, inside the profile and the grid
-            const double inv_scale = 1.0 / (double)scale;
-            ulo = -floor_div_inv(-(int)w.minj, inv_scale);
-            uhi = -floor_div_inv(-(int)w.maxj, inv_scale);
-            ulo = max(ulo, -floor_div_inv(w.half - iown, a.inv_osamp));
-            uhi = min(uhi, floor_div_inv(iown + w.half, a.inv_osamp) + 1);
-            uhi = min(uhi, a.nwave);
-            q = floor_div_inv(w.half - iown, a.inv_osamp);
-            phi = (w.half - iown) - q * a.osamp;
-            cell = w.cell;
-            if (uhi < ulo)
-                uhi = ulo;
+            const int64_t idx = (int64_t)layer * a.ngroups + g;
+            if (a.rec32) {
+                Rec32 r;
+                r.k = k;
+                r.off = a.pm_base[cell] + (long long)phi * a.pm_stride[cell] + q;
+                r.ulo = ulo;
+                r.uhi = uhi;
+                r.pad[0] = r.pad[1] = 0;
+                a.rec32[idx] = r;
+            } else {
+                a.rec_k[idx] = k;
+                a.rec_ulo[idx] = ulo;
+                a.rec_uhi[idx] = uhi;
+                a.rec_q[idx] = q;
+                a.rec_cell[idx] = cell;
+                a.rec_phi[idx] = phi;
+            }
         }
-        const int64_t idx = (int64_t)layer * a.ngroups + g;
-        if (a.rec32) {
-            Rec32 r;
-            r.k = k;
-            r.off = a.pm_base[cell] + (long long)phi * a.pm_stride[cell] + q;
-            r.ulo = ulo;
-            r.uhi = uhi;
-            r.pad[0] = r.pad[1] = 0;
-            a.rec32[idx] = r;
-        } else {
-            a.rec_k[idx] = k;
-            a.rec_ulo[idx] = ulo;
-            a.rec_uhi[idx] = uhi;
-            a.rec_q[idx] = q;
-            a.rec_cell[idx] = cell;
-            a.rec_phi[idx] = phi;
-        }
+        if (row >= 0)
+            atomicMax(&s_max[i * a.nrows + row], (unsigned long long)__double_as_longlong(lmax));
     }
-    if (row >= 0)
-        atomicMax(&s_max[row], (unsigned long long)__double_as_longlong(lmax));
     __syncthreads();
-    for (int r = threadIdx.x; r < a.nrows; r += kBlock)
-        if (s_max[r] != 0ull)
-            atomicMax(&a.kmax_bits[(int64_t)layer * a.nrows + r], s_max[r]);
+    for (int r = threadIdx.x; r < kRecLayers * a.nrows; r += kBlock) {
+        const int layer = layer0 + r / a.nrows;
+        if (layer < a.nlayers && s_max[r] != 0ull)
+            atomicMax(&a.kmax_bits[(int64_t)layer * a.nrows + r % a.nrows], s_max[r]);
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -2176,8 +2187,8 @@ int pb_lbl_extinction(pb_lbl *p, double *ext_d, int64_t wbegin, int64_t wcount,
     k_layer_state<<<nlayers, 64, 0, s>>>(a);
     PB_LAUNCH_CHECK();
     if (use_records) {
-        dim3 grid(pb::div_up(l->ngroups, kBlock), nlayers);
-        k_records<<<grid, kBlock, (size_t)a.nrows * 8 + (size_t)a.ndop * 8, s>>>(a);
+        dim3 grid(pb::div_up(l->ngroups, kBlock), pb::div_up(nlayers, kRecLayers));
+        k_records<<<grid, kBlock, (size_t)kRecLayers * a.nrows * 8 + (size_t)a.ndop * 8, s>>>(a);
         PB_LAUNCH_CHECK();
     } else if (l->nlines > 0) {
         const int lines_per_block = 4096;
