@@ -109,7 +109,9 @@ int pb_lbl_set_ethresh(pb_lbl *p, double ethresh);
  *   1 = global gather only, 2 = LDS-staged only (falls back to 1 when a phase row does not
  *       fit in LDS), 3 = resident-profile kernel where it applies + global gather.
  * All sum the same terms; only the order differs (global, resident: isotope, position;
- * staged: isotope, phase, position).  The choice never depends on the wavenumber shard.
+ * staged: isotope, phase, position).  In mode 0 the choice depends on the size of the launch
+ * (layers x samples); with a fixed mode every tiling and sharding adds the same terms in the
+ * same order, so shards concatenate bit-exactly.
  * last_gather_mode reports what the last call ran: 1 global, 2 staged, 3 resolution mode,
  * plus 8 when the resident-profile kernel ran as well. */
 int pb_lbl_set_gather_mode(pb_lbl *p, int mode);

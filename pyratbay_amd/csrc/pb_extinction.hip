@@ -2131,9 +2131,11 @@ int pb_lbl_extinction(pb_lbl *p, double *ext_d, int64_t wbegin, int64_t wcount,
     const bool can_stage = !p->resolution && a.rowcap <= kStageRowMax && lds <= 160 * 1024 &&
                            l->ngroups > 0;
     // the staged kernel needs enough workgroups to hide its per-segment latency; small
-    // launches (multi-GPU shards) go to the global gather with record splitting
+    // launches (multi-GPU shards) go to the global gather with record splitting.  Measured
+    // on layer shards of C2 (tools/bench_rank.py): 40 and 20 layers staged 0.85 / 0.65 ms vs
+    // global 1.20 / 0.73; 10 layers 0.55 vs 0.53.
     const bool enough_blocks =
-        pb::div_up(wcount, 2 * kStagedWaves * kStageSpan) * (int64_t)nlayers >= 1500;
+        pb::div_up(wcount, kStagedWaves * kStageSpan) * (int64_t)nlayers >= 750;
     const bool staged = can_stage && (p->gather_mode == 2 ||
                                       (p->gather_mode == 0 && enough_blocks &&
                                        per_phase >= p->stage_threshold));
@@ -2233,11 +2235,10 @@ int pb_lbl_extinction(pb_lbl *p, double *ext_d, int64_t wbegin, int64_t wcount,
         dim3 grid((unsigned)(8 * a.ntiles * layer_groups), a.nrows);
         k_ext_linterp<<<grid, kBlock, 0, s>>>(a);
     } else if (staged) {
-        // sub-tiles per workgroup: as many as keep >= ~1500 workgroups in flight
+        // sub-tiles per workgroup: 2 when that still leaves >= 750 workgroups (4 measured
+        // slower at every size: 32 accumulators spill at the 64-register budget)
         const int64_t sub = kStagedWaves * kStageSpan;
-        int S = 4;
-        while (S > 1 && pb::div_up(wcount, S * sub) * (int64_t)nlayers < 1500)
-            S >>= 1;
+        int S = pb::div_up(wcount, 2 * sub) * (int64_t)nlayers >= 750 ? 2 : 1;
         if (const char *e = getenv("PB_STAGE_S"))
             S = atoi(e) >= 4 ? 4 : atoi(e) >= 2 ? 2 : 1;
         a.ntiles = pb::div_up(wcount, S * sub);
