@@ -102,6 +102,10 @@ struct LblArgs {
     const int32_t *gs_start;          // [niso][nwave+1]
     // scatter kernel: one 32-byte record per (layer, position-sorted group)
     struct Rec32 *rec32;
+    // staged kernel, small launches: the phases of a tile are split between nsplit workgroups
+    // (blockIdx.z); split 0 writes ext, the others part[split-1][layer][row][sample]
+    int nsplit;
+    double *part;
     // per (layer, phase-sorted group) records written by k_records [nlayers][ngroups]
     double *rec_k;                    // co-added strength (before threshold / density)
     int32_t *rec_ulo, *rec_uhi;       // window on the global output grid
@@ -806,7 +810,10 @@ __global__ __launch_bounds__(NW * 64, 8) void k_ext_staged(LblArgs a)
         int mine = 0;
         for (int r = 0; r < per; r++) {
             const int p = tid * per + r;
-            if (p < osamp) {
+            if (p < osamp && a.nsplit > 1 && p * a.nsplit / osamp != (int)blockIdx.z) {
+                s_phs[p] = 0;                      // another workgroup's phase
+                s_cum[p] = 0;
+            } else if (p < osamp) {
                 // two table lookups bracket each bound to within one bin (a fraction of a
                 // record per phase), then a short bisection makes it exact
                 const int32_t *bin = a.ph_bin + ((int64_t)iso * osamp + p) * (a.ph_nbins + 1);
@@ -1049,7 +1056,10 @@ __global__ __launch_bounds__(NW * 64, 8) void k_ext_staged(LblArgs a)
         }
     }
 
-    double *dst = a.ext + ((int64_t)layer * a.nrows + row) * a.wcount + (t0 - a.wbegin);
+    double *out = blockIdx.z == 0
+                      ? a.ext
+                      : a.part + (int64_t)(blockIdx.z - 1) * a.nlayers * a.nrows * a.wcount;
+    double *dst = out + ((int64_t)layer * a.nrows + row) * a.wcount + (t0 - a.wbegin);
 #pragma unroll
     for (int u = 0; u < S; u++) {
 #pragma unroll
@@ -1400,6 +1410,19 @@ __global__ __launch_bounds__(64) void k_ext_scatter(LblArgs a)
         out[i] = s_tile[i];
 }
 
+// ext += part[0] + part[1] + ... in that order (the phase splits of a small staged launch)
+__global__ __launch_bounds__(kBlock) void k_combine_parts(double *ext, const double *part,
+                                                         int nparts, int64_t n)
+{
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n)
+        return;
+    double v = ext[i];
+    for (int p = 0; p < nparts; p++)
+        v += part[(int64_t)p * n + i];
+    ext[i] = v;
+}
+
 // ---------------------------------------------------------------------------
 // 3b. gather, arbitrary output grid (resolution / wlstep mode): every output needs the
 // two dynamic-grid samples that bracket it (linterp, utils.h:139-163).  Uses the
@@ -1604,6 +1627,8 @@ struct pb_lbl {
     int32_t *ls_resident = nullptr;   // [max_layers]
     int32_t *ls_block = nullptr;      // [max_layers]
     Rec32 *rec32 = nullptr;           // [max_layers][ngroups], scatter kernel
+    double *part = nullptr;           // partial sums of a phase-split staged launch
+    size_t part_bytes = 0;
     int32_t *gs_start = nullptr;      // [niso][nwave+1]
     int res_cap = 0;                  // LDS doubles of one resident profile block (0 = none fits)
     int gather_mode = 0;     // 0 = choose, 1 = global gather, 2 = LDS-staged, 3 = resident+global
@@ -2134,8 +2159,16 @@ int pb_lbl_extinction(pb_lbl *p, double *ext_d, int64_t wbegin, int64_t wcount,
     // launches (multi-GPU shards) go to the global gather with record splitting.  Measured
     // on layer shards of C2 (tools/bench_rank.py): 40 and 20 layers staged 0.85 / 0.65 ms vs
     // global 1.20 / 0.73; 10 layers 0.55 vs 0.53.
-    const bool enough_blocks =
-        pb::div_up(wcount, kStagedWaves * kStageSpan) * (int64_t)nlayers >= 750;
+    // Below ~1000 workgroups the chip is not full and the kernel time is the serial chain of
+    // one workgroup (~540 segments per tile): the phases of a tile are then split between up
+    // to 4 workgroups whose partial sums are added in order by k_combine_parts.
+    const int64_t blocks1 = pb::div_up(wcount, kStagedWaves * kStageSpan) * (int64_t)nlayers;
+    int nsplit = 1;
+    if (blocks1 < 1000)
+        nsplit = (int)std::min<int64_t>(4, std::max<int64_t>(1, 2000 / std::max<int64_t>(1, blocks1)));
+    if (const char *e = getenv("PB_STAGE_SPLIT"))
+        nsplit = std::max(1, std::min(8, atoi(e)));
+    const bool enough_blocks = blocks1 * nsplit >= 750;
     const bool staged = can_stage && (p->gather_mode == 2 ||
                                       (p->gather_mode == 0 && enough_blocks &&
                                        per_phase >= p->stage_threshold));
@@ -2147,6 +2180,8 @@ int pb_lbl_extinction(pb_lbl *p, double *ext_d, int64_t wbegin, int64_t wcount,
                           (p->gather_mode == 0 || p->gather_mode == 3);
     a.res_cap = resident ? p->res_cap : 0;
     a.rec32 = nullptr;
+    a.nsplit = 1;
+    a.part = nullptr;
     if (scatter) {
         if (!p->rec32) {
             const size_t n = (size_t)p->max_layers * (size_t)l->ngroups;
@@ -2239,10 +2274,29 @@ int pb_lbl_extinction(pb_lbl *p, double *ext_d, int64_t wbegin, int64_t wcount,
         // slower at every size: 32 accumulators spill at the 64-register budget)
         const int64_t sub = kStagedWaves * kStageSpan;
         int S = pb::div_up(wcount, 2 * sub) * (int64_t)nlayers >= 750 ? 2 : 1;
+        if (S > 1)
+            nsplit = 1;
+        if (getenv("PB_STAGE_SPLIT"))
+            nsplit = std::max(1, std::min(8, atoi(getenv("PB_STAGE_SPLIT"))));
+        a.nsplit = nsplit;
+        if (nsplit > 1) {
+            const size_t need = (size_t)(nsplit - 1) * nlayers * a.nrows * wcount * 8;
+            if (need > p->part_bytes) {
+                (void)hipFree(p->part);
+                p->part = nullptr;
+                p->part_bytes = 0;
+                if (hipMalloc(&p->part, need) != hipSuccess) {
+                    pb::set_error("pb_lbl_extinction: cannot allocate %zu B of partial sums", need);
+                    return PB_ERR_NOMEM;
+                }
+                p->part_bytes = need;
+            }
+            a.part = p->part;
+        }
         if (const char *e = getenv("PB_STAGE_S"))
             S = atoi(e) >= 4 ? 4 : atoi(e) >= 2 ? 2 : 1;
         a.ntiles = pb::div_up(wcount, S * sub);
-        dim3 grid((unsigned)(8 * a.ntiles * layer_groups), a.nrows);
+        dim3 grid((unsigned)(8 * a.ntiles * layer_groups), a.nrows, (unsigned)nsplit);
         void (*kern)(LblArgs) = S == 4   ? k_ext_staged<kStagedWaves, 4>
                                 : S == 2 ? k_ext_staged<kStagedWaves, 2>
                                          : k_ext_staged<kStagedWaves, 1>;
@@ -2250,6 +2304,12 @@ int pb_lbl_extinction(pb_lbl *p, double *ext_d, int64_t wbegin, int64_t wcount,
             PB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         kern<<<grid, kStagedThreads, lds, s>>>(a);
+        if (nsplit > 1) {
+            PB_LAUNCH_CHECK();
+            const int64_t n = (int64_t)nlayers * a.nrows * wcount;
+            k_combine_parts<<<(unsigned)pb::div_up(n, kBlock), kBlock, 0, s>>>(ext_d, p->part,
+                                                                             nsplit - 1, n);
+        }
     } else {
         // record splitting when the launch would not fill the chip
         // (measured at C2: RS=2 beats RS=1 until the launch has ~16k workgroups; a 16-wave
@@ -2361,6 +2421,7 @@ void pb_lbl_destroy(pb_lbl *p)
     (void)hipFree(p->ls_resident);
     (void)hipFree(p->ls_block);
     (void)hipFree(p->rec32);
+    (void)hipFree(p->part);
     (void)hipFree(p->gs_start);
     (void)hipFree(p->ls_dnwn);
     (void)hipFree(p->ls_dwnstep);
