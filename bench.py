@@ -230,7 +230,7 @@ def main():
         achieved = kernel_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
         traffic = None
         tfile = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
-        if os.path.exists(tfile):
+        if world == 1 and os.path.exists(tfile):     # measured for the single-GPU launch only
             try:
                 traffic = json.load(open(tfile)).get(args.workload, {}).get('hbm_bytes_per_launch')
             except Exception:
