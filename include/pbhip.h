@@ -215,6 +215,27 @@ int pb_emission_flux(double *flux_d, double *intensity_d, const double *tau_d,
                      const int32_t *ideep_d, const double *wn_d, const double *temp_d,
                      const double *mu_d, const double *weights_d, int nmu, int rtop,
                      int nlayers, int nwave, void *stream);
+/* Radiative transfer with an opaque cloud deck (clouds/gray.py:92-150 Deck; the optical depth
+ * is then computed with ibottom = deck_itop + 1, pyrat_obj.py:134-138):
+ *  - transit (radiative_transfer.py:57-71): the interval that ends at layer deck_itop ends at
+ *    the cloud top instead, h = deck_rsurf - radius[deck_itop-1], with the integrand
+ *    interpolated linearly in radius; deck_itop <= itop or < 0 = no deck;
+ *  - emission (radiative_transfer.py:121-131): the caller passes temp_d with the cloud-top
+ *    temperature at index cloud_itop (Planck of that row) and ideep is clipped to cloud_itop;
+ *    cloud_itop < 0 = no deck. */
+int pb_transmission_deck(double *spectrum_d, const double *depth_d, const int32_t *ideep_d,
+                         const double *radius_d, int itop, double rstar, int deck_itop,
+                         double deck_rsurf, int nlayers, int nwave, void *stream);
+int pb_transit_spectrum_deck(double *spectrum_d, double *depth_d, int32_t *ideep_d,
+                             const double *ec_d, const double *raypath_d,
+                             const double *radius_d, double rstar, int itop, int ibottom,
+                             double maxdepth, int deck_itop, double deck_rsurf, int nlayers,
+                             int nwave, void *stream);
+int pb_emission_flux_deck(double *flux_d, double *intensity_d, const double *tau_d,
+                          const int32_t *ideep_d, const double *wn_d, const double *temp_d,
+                          const double *mu_d, const double *weights_d, int nmu, int rtop,
+                          int cloud_itop, int nlayers, int nwave, void *stream);
+
 /* Continuum opacity terms, accumulated into ec_d[nlayers,nwave] in ONE pass:
  *  - nrank1 terms cs_d[m][nwave] * f_d[m][nlayers]: Rayleigh (rayleigh.py:85-107, f = number
  *    density of the scatterer), Lecavelier haze (lecavelier.py:73-100, f = p/kT) and

@@ -400,3 +400,31 @@ def transmission(depth, radius, rstar, ideep, itop):
     integ = np.exp(-depth[itop:]) * np.expand_dims(radius[itop:], 1)
     spectrum = trapezoid2D(integ, h, nlay - 1)
     return (radius[itop]**2 + 2 * spectrum) / rstar**2
+
+
+def transmission_deck(depth, radius, rstar, ideep, itop, deck_rsurf=None, deck_itop=None):
+    """radiative_transfer.py:17-71 with the cloud-deck branch (numpy + orc_trapezoid2D)."""
+    depth = np.asarray(depth, float)
+    radius = np.asarray(radius, float)
+    nlayers = np.asarray(ideep) - itop + 1
+    h = np.ediff1d(radius[itop:])
+    integ = np.exp(-depth[itop:]) * np.expand_dims(radius[itop:], 1)
+    if deck_rsurf is not None and deck_itop > itop:
+        h[deck_itop - itop - 1] = deck_rsurf - radius[deck_itop - 1]
+        k = deck_itop - itop
+        x_lo, x_hi = radius[deck_itop], radius[deck_itop - 1]      # interp1d sorts x
+        slope = (integ[k - 1] - integ[k]) / (x_hi - x_lo)
+        integ[k] = slope * (deck_rsurf - x_lo) + integ[k]
+    spectrum = trapezoid2D(np.ascontiguousarray(integ), h, (nlayers - 1).astype(np.int32))
+    return (radius[itop]**2 + 2 * spectrum) / rstar**2
+
+
+def emission_deck(depth, ideep, wn, temp, mu, weights, rtop, cloud_tsurf=None, cloud_itop=None):
+    """plane_parallel_rt (radiative_transfer.py:74-139) + the quadrature sum."""
+    B = blackbody_wn_2D(wn, temp)
+    ideep = np.asarray(ideep)
+    if cloud_tsurf is not None:
+        B[cloud_itop] = blackbody_wn(wn, cloud_tsurf)
+        ideep = np.clip(ideep, 0, cloud_itop)
+    inten = intensity(depth, ideep.astype(np.int32), B, mu, rtop)
+    return np.sum(inten * np.asarray(weights)[:, None], axis=0)

@@ -60,6 +60,9 @@ _PROTOS = {
     'pb_blackbody_wn': [vp, vp, i32, f64, vp],
     'pb_intensity': [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp],
     'pb_emission_flux': [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp],
+    'pb_transmission_deck': [vp, vp, vp, vp, i32, f64, i32, f64, i32, i32, vp],
+    'pb_transit_spectrum_deck': [vp, vp, vp, vp, vp, vp, f64, i32, i32, f64, i32, f64, i32, i32, vp],
+    'pb_emission_flux_deck': [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp],
     'pb_continuum': [vp, vp, vp, i32, i32, i32, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp],
     'pb_alkali_cross_section': [vp, vp, vp, vp, vp, f64, f64, f64, f64, f64, vp, vp, i32, vp, i32, i32, vp],
     'pb_two_stream': [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp],

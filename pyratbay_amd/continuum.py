@@ -106,6 +106,35 @@ class CCSgray:
             self.pressure * BAR / temperature / K)
 
 
+class Deck:
+    """Instantly opaque gray cloud deck at pressure 10**pars[0] bar (gray.py:92-150).  It adds
+    nothing to ec; it sets the bottom of the optical-depth integration (ibottom = itop + 1)
+    and the cloud-top radius / temperature that the radiative transfer uses."""
+
+    def __init__(self, pressure, wn):
+        self.name = 'deck'
+        self.pressure = np.asarray(pressure, float)
+        self.wn = np.asarray(wn, float)
+        self.pars = [-1.0]
+        self.itop, self.rsurf, self.tsurf = None, 0.0, 0.0
+
+    def calc_extinction_coefficient(self, radius, temperature, pars=None):
+        if pars is not None:
+            self.pars[:] = pars
+        ptop = 10**self.pars[0]
+        nlayers = len(self.pressure)
+        if ptop >= self.pressure[-1]:
+            self.itop = nlayers - 1
+        elif ptop < self.pressure[0]:
+            self.itop = 1
+        else:
+            self.itop = int(np.where(self.pressure >= ptop)[0][0])
+        # scipy.interpolate.interp1d (linear) in pressure
+        self.tsurf = float(np.interp(ptop, self.pressure, temperature))
+        self.rsurf = float(np.interp(ptop, self.pressure, radius))
+        return self.itop, self.rsurf, self.tsurf
+
+
 def read_cs(csfile):
     """Cross-section table file (io/io.py:866-950): '@SPECIES', '@TEMPERATURES', '@DATA'
     blocks -> (cs[ntemp, nwave], species, temps, wn)."""

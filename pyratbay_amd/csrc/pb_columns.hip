@@ -116,9 +116,19 @@ __global__ __launch_bounds__(kBlock) void k_transit_tau(double *depth, const dou
             depth[(int64_t)r * nwave + col] = 0.0;
 }
 
+// Opaque cloud deck (radiative_transfer.py:62-66): at row deck_row = deck_itop - itop the
+// interval's far end is the cloud top: h = rsurf - radius[deck_itop-1] and the integrand is
+// the linear interpolation (scipy interp1d) of exp(-tau)*r between the two layers at rsurf.
+__device__ inline double deck_integrand(double f_above, double f_below, double r_above,
+                                        double r_below, double rsurf)
+{
+    const double slope = (f_above - f_below) / (r_above - r_below);
+    return slope * (rsurf - r_below) + f_below;
+}
+
 __global__ __launch_bounds__(kBlock) void k_transit_finish(
     double *depth, int32_t *ideep, double *spectrum, const double *radius, double rstar,
-    int itop, int ibottom, double maxdepth, int nlayers, int nwave)
+    int itop, int ibottom, double maxdepth, int nlayers, int nwave, int deck_row, double rsurf)
 {
     const int col = blockIdx.x * kBlock + threadIdx.x;
     if (col >= nwave)
@@ -141,9 +151,13 @@ __global__ __launch_bounds__(kBlock) void k_transit_finish(
             if (stop < 0) {
                 if (spectrum) {
                     const double rad = radius[itop + r];
-                    const double f = exp(-t[k]) * rad;
-                    if (r > 0)
+                    double f = exp(-t[k]) * rad;
+                    if (r > 0 && r == deck_row) {
+                        f = deck_integrand(fprev, f, rprev, rad, rsurf);
+                        acc += (rsurf - rprev) * (fprev + f);
+                    } else if (r > 0) {
                         acc += (rad - rprev) * (fprev + f);
+                    }
                     fprev = f;
                     rprev = rad;
                 }
@@ -222,7 +236,7 @@ __global__ void k_trapezoid2d(double *out, const double *data, const double *h,
 // ---------------------------------------------------------------------------
 __global__ void k_transmission(double *spectrum, const double *depth,
                                const int32_t *ideep, const double *radius, int itop,
-                               double rstar, int nlayers, int nwave)
+                               double rstar, int nlayers, int nwave, int deck_row, double rsurf)
 {
     int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= nwave)
@@ -237,7 +251,12 @@ __global__ void k_transmission(double *spectrum, const double *depth,
         for (int i = 0; i < n; i++) {
             double rnext = radius[itop + i + 1];
             double next = exp(-depth[(int64_t)(itop + i + 1) * nwave + j]) * rnext;
-            acc += (rnext - rprev) * (prev + next);
+            if (i + 1 == deck_row) {
+                next = deck_integrand(prev, next, rprev, rnext, rsurf);
+                acc += (rsurf - rprev) * (prev + next);
+            } else {
+                acc += (rnext - rprev) * (prev + next);
+            }
             prev = next;
             rprev = rnext;
         }
@@ -329,12 +348,12 @@ __global__ void k_emission_flux(double *flux, double *intensity, const double *t
                                 const int32_t *ideep, const double *wn,
                                 const double *temp, const double *mu,
                                 const double *weights, int nmu, int rtop, int nlayers,
-                                int nwave)
+                                int nwave, int ideep_max)
 {
     int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= nwave)
         return;
-    int last = ideep[j];
+    int last = min(ideep[j], ideep_max);    // np.clip(ideep, 0, cloud_itop) with a cloud deck
     if (last > nlayers - 1)
         last = nlayers - 1;
     const double w = wn[j];
@@ -600,7 +619,8 @@ int pb_optdepth(double *tau_d, const double *data_d, int64_t row_stride,
 static int transit_launch(double *depth_d, int32_t *ideep_d, double *spectrum_d,
                           const double *ec_d, const double *raypath_d, const double *radius_d,
                           double rstar, int itop, int ibottom, double maxdepth, int nlayers,
-                          int nwave, void *stream, const char *who)
+                          int nwave, void *stream, const char *who, int deck_itop = -1,
+                          double deck_rsurf = 0.0)
 {
     PB_REQUIRE(nlayers > 0 && nwave >= 0, "%s: bad shape", who);
     PB_REQUIRE(itop >= 0 && itop < nlayers, "%s: itop out of range", who);
@@ -620,9 +640,11 @@ static int transit_launch(double *depth_d, int32_t *ideep_d, double *spectrum_d,
     k_transit_tau<<<grid, kBlock, lds, pb::as_stream(stream)>>>(depth_d, ec_d, raypath_d, itop,
                                                               ibottom, nlayers, nwave);
     PB_LAUNCH_CHECK();
+    // radiative_transfer.py:63: the deck matters only when it lies below the top layer
+    const int deck_row = deck_itop > itop ? deck_itop - itop : -1;
     k_transit_finish<<<pb::div_up(nwave, kBlock), kBlock, 0, pb::as_stream(stream)>>>(
         depth_d, ideep_d, spectrum_d, radius_d, rstar, itop, ibottom, maxdepth, nlayers,
-        nwave);
+        nwave, deck_row, deck_rsurf);
     PB_LAUNCH_CHECK();
     return PB_OK;
 }
@@ -644,6 +666,19 @@ int pb_transit_spectrum(double *spectrum_d, double *depth_d, int32_t *ideep_d,
     PB_REQUIRE(spectrum_d, "pb_transit_spectrum: null spectrum");
     return transit_launch(depth_d, ideep_d, spectrum_d, ec_d, raypath_d, radius_d, rstar, itop,
                           ibottom, maxdepth, nlayers, nwave, stream, "pb_transit_spectrum");
+}
+
+int pb_transit_spectrum_deck(double *spectrum_d, double *depth_d, int32_t *ideep_d,
+                             const double *ec_d, const double *raypath_d,
+                             const double *radius_d, double rstar, int itop, int ibottom,
+                             double maxdepth, int deck_itop, double deck_rsurf, int nlayers,
+                             int nwave, void *stream)
+{
+    PB_REQUIRE(spectrum_d, "pb_transit_spectrum_deck: null spectrum");
+    PB_REQUIRE(deck_itop < nlayers, "pb_transit_spectrum_deck: deck_itop out of range");
+    return transit_launch(depth_d, ideep_d, spectrum_d, ec_d, raypath_d, radius_d, rstar, itop,
+                          ibottom, maxdepth, nlayers, nwave, stream,
+                          "pb_transit_spectrum_deck", deck_itop, deck_rsurf);
 }
 
 int pb_plane_parallel_optical_depth(double *depth_d, int32_t *ideep_d,
@@ -677,19 +712,30 @@ int pb_trapezoid2D(double *out_d, const double *data_d, const double *intervals_
     return PB_OK;
 }
 
+int pb_transmission_deck(double *spectrum_d, const double *depth_d, const int32_t *ideep_d,
+                         const double *radius_d, int itop, double rstar, int deck_itop,
+                         double deck_rsurf, int nlayers, int nwave, void *stream)
+{
+    PB_REQUIRE(nlayers > 0 && nwave >= 0, "pb_transmission: bad shape");
+    PB_REQUIRE(itop >= 0 && itop < nlayers, "pb_transmission: itop out of range");
+    PB_REQUIRE(deck_itop < nlayers, "pb_transmission: deck_itop out of range");
+    if (nwave == 0)
+        return PB_OK;
+    PB_REQUIRE(spectrum_d && depth_d && ideep_d && radius_d, "pb_transmission: null pointer");
+    const int deck_row = deck_itop > itop ? deck_itop - itop : -1;
+    k_transmission<<<pb::div_up(nwave, kBlock), kBlock, 0, pb::as_stream(stream)>>>(
+        spectrum_d, depth_d, ideep_d, radius_d, itop, rstar, nlayers, nwave, deck_row,
+        deck_rsurf);
+    PB_LAUNCH_CHECK();
+    return PB_OK;
+}
+
 int pb_transmission(double *spectrum_d, const double *depth_d, const int32_t *ideep_d,
                     const double *radius_d, int itop, double rstar, int nlayers,
                     int nwave, void *stream)
 {
-    PB_REQUIRE(nlayers > 0 && nwave >= 0, "pb_transmission: bad shape");
-    PB_REQUIRE(itop >= 0 && itop < nlayers, "pb_transmission: itop out of range");
-    if (nwave == 0)
-        return PB_OK;
-    PB_REQUIRE(spectrum_d && depth_d && ideep_d && radius_d, "pb_transmission: null pointer");
-    k_transmission<<<pb::div_up(nwave, kBlock), kBlock, 0, pb::as_stream(stream)>>>(
-        spectrum_d, depth_d, ideep_d, radius_d, itop, rstar, nlayers, nwave);
-    PB_LAUNCH_CHECK();
-    return PB_OK;
+    return pb_transmission_deck(spectrum_d, depth_d, ideep_d, radius_d, itop, rstar, -1, 0.0,
+                                nlayers, nwave, stream);
 }
 
 int pb_blackbody_wn_2D(double *B_d, const double *wn_d, int nwave, const double *temp_d,
@@ -740,7 +786,17 @@ int pb_emission_flux(double *flux_d, double *intensity_d, const double *tau_d,
                      const double *mu_d, const double *weights_d, int nmu, int rtop,
                      int nlayers, int nwave, void *stream)
 {
+    return pb_emission_flux_deck(flux_d, intensity_d, tau_d, ideep_d, wn_d, temp_d, mu_d,
+                                 weights_d, nmu, rtop, -1, nlayers, nwave, stream);
+}
+
+int pb_emission_flux_deck(double *flux_d, double *intensity_d, const double *tau_d,
+                          const int32_t *ideep_d, const double *wn_d, const double *temp_d,
+                          const double *mu_d, const double *weights_d, int nmu, int rtop,
+                          int cloud_itop, int nlayers, int nwave, void *stream)
+{
     PB_REQUIRE(nlayers > 0 && nwave >= 0, "pb_emission_flux: bad shape");
+    PB_REQUIRE(cloud_itop < nlayers, "pb_emission_flux: cloud_itop out of range");
     PB_REQUIRE(nmu >= 1 && nmu <= kMaxMu, "pb_emission_flux: nmu must be in [1,%d]", kMaxMu);
     PB_REQUIRE(rtop >= 0 && rtop < nlayers, "pb_emission_flux: rtop out of range");
     if (nwave == 0)
@@ -749,7 +805,7 @@ int pb_emission_flux(double *flux_d, double *intensity_d, const double *tau_d,
                "pb_emission_flux: null pointer");
     k_emission_flux<<<pb::div_up(nwave, kBlock), kBlock, 0, pb::as_stream(stream)>>>(
         flux_d, intensity_d, tau_d, ideep_d, wn_d, temp_d, mu_d, weights_d, nmu, rtop,
-        nlayers, nwave);
+        nlayers, nwave, cloud_itop >= 0 ? cloud_itop : nlayers - 1);
     PB_LAUNCH_CHECK();
     return PB_OK;
 }

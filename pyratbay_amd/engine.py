@@ -269,16 +269,19 @@ def optical_depth_transit(ec, raypath_packed, itop, ibottom, maxdepth):
     return depth, ideep
 
 
-def transit_spectrum(ec, raypath_packed, radius, rstar, itop, ibottom, maxdepth):
+def transit_spectrum(ec, raypath_packed, radius, rstar, itop, ibottom, maxdepth,
+                     deck_rsurf=None, deck_itop=None):
     """optic_depth.py:103-112 + radiative_transfer.py:57-71 in one call:
-    ec[L,W] -> spectrum[W], depth[L,W], ideep[W]."""
+    ec[L,W] -> spectrum[W], depth[L,W], ideep[W].  With an opaque cloud deck pass its
+    radius and the index of the layer right below it (and ibottom = deck_itop + 1)."""
     nlayers, nwave = ec.shape
     depth = torch.empty_like(ec)
     ideep = torch.empty(nwave, dtype=torch.int32, device=ec.device)
     spectrum = torch.empty(nwave, dtype=torch.float64, device=ec.device)
-    call('pb_transit_spectrum', _ptr(spectrum), _ptr(depth), _ptr(ideep), _ptr(ec),
+    call('pb_transit_spectrum_deck', _ptr(spectrum), _ptr(depth), _ptr(ideep), _ptr(ec),
          _ptr(raypath_packed), _ptr(radius), float(rstar), int(itop), int(ibottom),
-         float(maxdepth), nlayers, nwave, _stream())
+         float(maxdepth), -1 if deck_rsurf is None else int(deck_itop),
+         0.0 if deck_rsurf is None else float(deck_rsurf), nlayers, nwave, _stream())
     return spectrum, depth, ideep
 
 
@@ -293,23 +296,34 @@ def plane_parallel_optical_depth(ec, intervals, itop, ibottom, maxdepth, depth=N
     return depth, ideep
 
 
-def transmission(depth, ideep, radius, itop, rstar):
-    """radiative_transfer.py:57-71 (no cloud deck) -> spectrum[W]."""
+def transmission(depth, ideep, radius, itop, rstar, deck_rsurf=None, deck_itop=None):
+    """radiative_transfer.py:17-71 -> spectrum[W]; deck_rsurf / deck_itop = radius of an
+    opaque cloud deck and index of the layer right below it."""
     nlayers, nwave = depth.shape
     spectrum = torch.empty(nwave, dtype=torch.float64, device=depth.device)
-    call('pb_transmission', _ptr(spectrum), _ptr(depth), _ptr(ideep), _ptr(radius),
-         int(itop), float(rstar), nlayers, nwave, _stream())
+    call('pb_transmission_deck', _ptr(spectrum), _ptr(depth), _ptr(ideep), _ptr(radius),
+         int(itop), float(rstar), -1 if deck_rsurf is None else int(deck_itop),
+         0.0 if deck_rsurf is None else float(deck_rsurf), nlayers, nwave, _stream())
     return spectrum
 
 
-def emission_flux(depth, ideep, wn, temp, mu, weights, rtop, want_intensity=False):
-    """pyrat/spectrum.py:366-377: Planck + intensity per mu + quadrature sum."""
+def emission_flux(depth, ideep, wn, temp, mu, weights, rtop, want_intensity=False,
+                  cloud_tsurf=None, cloud_itop=None):
+    """pyrat/spectrum.py:366-377: Planck + intensity per mu + quadrature sum.  With an
+    opaque cloud deck (radiative_transfer.py:121-131) the layer cloud_itop radiates at
+    cloud_tsurf and is the deepest one seen."""
     nlayers, nwave = depth.shape
     flux = torch.empty(nwave, dtype=torch.float64, device=depth.device)
     inten = (torch.empty((len(mu), nwave), dtype=torch.float64, device=depth.device)
              if want_intensity else None)
-    call('pb_emission_flux', _ptr(flux), _ptr(inten), _ptr(depth), _ptr(ideep), _ptr(wn),
-         _ptr(temp), _ptr(mu), _ptr(weights), len(mu), int(rtop), nlayers, nwave, _stream())
+    itop_cloud = -1
+    if cloud_tsurf is not None:
+        temp = temp.clone()
+        temp[int(cloud_itop)] = float(cloud_tsurf)
+        itop_cloud = int(cloud_itop)
+    call('pb_emission_flux_deck', _ptr(flux), _ptr(inten), _ptr(depth), _ptr(ideep), _ptr(wn),
+         _ptr(temp), _ptr(mu), _ptr(weights), len(mu), int(rtop), itop_cloud, nlayers, nwave,
+         _stream())
     return (flux, inten) if want_intensity else flux
 
 

@@ -1,0 +1,144 @@
+"""The reference's OWN golden vectors that need no downloaded line data
+(tests/expected/expected_spectrum_{transmission,emission,eclipse}_{lec,cia,alkali,deck}_test.npz
+and the analytic 'clear' known-answer tests of tests/test_transmission.py:43-52,
+test_emission.py:43-52), carried in tests/golden/g9_reference_cases.npz together with the
+atmosphere and model parameters of each case (tests/golden/make_golden_reference_cases.py,
+which first checks that the real package reproduces those goldens here).
+
+Tolerances: the reference's own rtol 1e-4 against ITS golden (some of its files were made
+with an older build: CIA differs by 1e-6, the transit deck by 3e-5), 1e-10 against the
+spectrum the package computes today."""
+import numpy as np
+import pytest
+
+RT_CASES = [('transit', c) for c in ('clear', 'lec', 'cia', 'alkali', 'deck')] + \
+           [('emission', c) for c in ('clear', 'lec', 'cia', 'alkali', 'deck')] + \
+           [('eclipse', c) for c in ('lec', 'deck')]
+
+
+def setup(g, rt, case):
+    tag = f'{rt}_{case}'
+    grid = 'alk' if case == 'alkali' else 'std'
+    species = [str(s) for s in g['species']]
+    dens = {s: np.ascontiguousarray(g['dens'][:, i]) for i, s in enumerate(species)}
+    rtop, rstar, maxdepth, rplanet = g[f'{tag}_scalars']
+    deck = g[f'{tag}_deck'] if f'{tag}_deck' in g.files else None
+    return dict(tag=tag, wn=g[f'{grid}_wn'], dens=dens, press=g['press'], temp=g['temp'],
+                radius=g['radius'], rtop=int(rtop), rstar=float(rstar),
+                maxdepth=float(maxdepth), rplanet=float(rplanet), deck=deck,
+                starflux=g[f'{grid}_starflux'] if rt == 'eclipse' else None,
+                mu=g[f'{rt}_mu'] if rt != 'transit' else None,
+                weights=g[f'{rt}_weights'] if rt != 'transit' else None,
+                expected=g[f'{tag}_expected'], spectrum=g[f'{tag}_spectrum'],
+                ideep=g[f'{tag}_ideep'])
+
+
+def check(got, c, ideep=None):
+    if ideep is not None:
+        assert np.array_equal(ideep, c['ideep'])
+    np.testing.assert_allclose(got, c['spectrum'], rtol=1e-10)
+    np.testing.assert_allclose(got, c['expected'], rtol=1e-4)       # the reference's own bar
+
+
+@pytest.mark.parametrize('rt,case', RT_CASES)
+def test_oracle_reproduces_reference_goldens(orc, golden, rt, case):
+    from oracle import continuum as cont
+    g = golden('g9_reference_cases')
+    c = setup(g, rt, case)
+    wn, temp, press, dens = c['wn'], c['temp'], c['press'], c['dens']
+    L, W = len(temp), len(wn)
+    ec = np.zeros((L, W))
+    if case == 'lec':
+        ec += cont.lecavelier_cross_section(wn, g[f'{c["tag"]}_lec_pars']) * \
+            cont.nominal_density(press, temp)[:, None]
+    if case == 'cia':
+        for pair in (('H2', 'H2'), ('H2', 'He')):
+            key = 'cia_' + '_'.join(pair)
+            lo, hi = (int(v) for v in g[f'{key}_lohi'])
+            cs = cont.cia_cross_section(g[f'{key}_tab'], g[f'{key}_temps'], temp, lo, hi)
+            ec += cs * (dens[pair[0]] * dens[pair[1]])[:, None]
+    if case == 'alkali':
+        ec += cont.alkali_cross_section(press * 1e6, wn, temp, g[f'{c["tag"]}_voigt_det'], 30.0,
+                                        22.989769, 0.071, 2.0,
+                                        float(g[f'{c["tag"]}_alk_cutoff']),
+                                        [16960.87, 16978.07], [0.65464, 1.30918]) \
+            * dens['Na'][:, None]
+    itop, ibottom = c['rtop'], L
+    deck_itop = deck_rsurf = deck_tsurf = None
+    if c['deck'] is not None:
+        _, deck_itop, deck_rsurf, deck_tsurf = c['deck']
+        deck_itop = int(deck_itop)
+        ibottom = deck_itop + 1
+    if rt == 'transit':
+        depth, ideep = orc.optical_depth_transit(ec, c['radius'], itop, ibottom, c['maxdepth'])
+        got = orc.transmission_deck(depth, c['radius'], c['rstar'], ideep, itop, deck_rsurf,
+                                    deck_itop)
+    else:
+        depth = np.zeros((L, W))
+        ideep = np.full(W, L - 1, np.int32)
+        orc.plane_parallel_optical_depth(depth, ideep, ec, -orc.ediff(c['radius']),
+                                         c['maxdepth'], itop, ibottom)
+        got = orc.emission_deck(depth, ideep, wn, temp, c['mu'], c['weights'], itop, deck_tsurf,
+                                deck_itop)
+        if rt == 'eclipse':
+            np.testing.assert_allclose(got, g[f'{c["tag"]}_fplanet'], rtol=1e-10)
+            got = got * (1 / c['starflux'] * (c['rplanet'] / c['rstar'])**2)
+    check(got, c, ideep)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('rt,case', RT_CASES)
+def test_hip_reproduces_reference_goldens(golden, rt, case):
+    from pyratbay_amd import engine, continuum as ct
+    engine.require_gpu()
+    g = golden('g9_reference_cases')
+    c = setup(g, rt, case)
+    wn, temp, press, dens = c['wn'], c['temp'], c['press'], c['dens']
+    L, W = len(temp), len(wn)
+    models = []
+    if case == 'lec':
+        lec = ct.Lecavelier(press, wn=wn)
+        lec.calc_cross_section(g[f'{c["tag"]}_lec_pars'])
+        models.append(lec)
+    if case == 'cia':
+        for pair in (['H2', 'H2'], ['H2', 'He']):
+            key = 'cia_' + '_'.join(pair)
+            m = ct.Collision_Induced.__new__(ct.Collision_Induced)
+            m.species, m.nspec = pair, 2
+            m.tab_cross_section, m.temps = g[f'{key}_tab'], g[f'{key}_temps']
+            m.ntemp, m.tmin, m.tmax = len(m.temps), m.temps.min(), m.temps.max()
+            m._wn_lo_idx, m._wn_hi_idx = (int(v) for v in g[f'{key}_lohi'])
+            models.append(m)
+    if case == 'alkali':
+        models.append(ct.SodiumVdW(press, wn=wn, cutoff=float(g[f'{c["tag"]}_alk_cutoff'])))
+    ec = engine.dev(np.zeros((L, W)))
+    if models:
+        ct.Continuum(wn, press, models).add(ec, temp, dens)
+    itop, ibottom = c['rtop'], L
+    deck_itop = deck_rsurf = deck_tsurf = None
+    if c['deck'] is not None:
+        deck = ct.Deck(press, wn)
+        deck_itop, deck_rsurf, deck_tsurf = deck.calc_extinction_coefficient(
+            c['radius'], temp, pars=[c['deck'][0]])
+        assert deck_itop == int(c['deck'][1])
+        np.testing.assert_allclose([deck_rsurf, deck_tsurf], c['deck'][2:], rtol=1e-12)
+        ibottom = deck_itop + 1
+    radius = engine.dev(c['radius'])
+    if rt == 'transit':
+        path = engine.dev(engine.pack_raypath(engine.transit_path(c['radius'], itop), itop))
+        got, depth, ideep = engine.transit_spectrum(ec, path, radius, c['rstar'], itop, ibottom,
+                                                    c['maxdepth'], deck_rsurf, deck_itop)
+        # and the two-call form
+        depth2, ideep2 = engine.optical_depth_transit(ec, path, itop, ibottom, c['maxdepth'])
+        got2 = engine.transmission(depth2, ideep2, radius, itop, c['rstar'], deck_rsurf,
+                                   deck_itop)
+        assert np.array_equal(got2.cpu().numpy(), got.cpu().numpy())
+    else:
+        depth, ideep = engine.plane_parallel_optical_depth(
+            ec, engine.dev(-np.diff(c['radius'])), itop, ibottom, c['maxdepth'])
+        got = engine.emission_flux(depth, ideep, engine.dev(wn), engine.dev(temp),
+                                   engine.dev(c['mu']), engine.dev(c['weights']), itop,
+                                   cloud_tsurf=deck_tsurf, cloud_itop=deck_itop)
+        if rt == 'eclipse':
+            got = got * engine.dev(1 / c['starflux'] * (c['rplanet'] / c['rstar'])**2)
+    check(got.cpu().numpy(), c, ideep.cpu().numpy())
