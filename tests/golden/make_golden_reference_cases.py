@@ -137,6 +137,39 @@ def main():
                 print(tag, 'W', spec.nwave, 'max rel dev from the reference golden',
                       float(np.max(np.abs(spec.spectrum / expected - 1))))
         np.savez_compressed(os.path.join(HERE, 'g9_reference_cases.npz'), **store)
+
+        # ---- the golden vectors of tests/test_opacity_alkali.py and test_opacity_cia.py ----
+        import pyratbay.atmosphere as pa
+        import pyratbay.opacity as op
+        import pyratbay.spectrum as ps
+        g10 = {}
+        pressure = pa.pressure('1e-8 bar', '1e2 bar', 6)
+        g10['pressure'] = pressure
+        for tag, cls, lo, hi in (('na', op.alkali.SodiumVdW, 0.55, 0.65),
+                                 ('k', op.alkali.PotassiumVdW, 0.70, 0.84)):
+            wn = ps.constant_resolution_spectrum(1e4 / hi, 1e4 / lo, 15000.0)
+            model = cls(pressure, wn=wn, cutoff=1000.0)
+            name = 'Na' if tag == 'na' else 'K'
+            with np.load(f'{REF}/tests/expected/expected_alkali_{name}_opacity.npz') as d:
+                cs1, cs2 = d['expected_cs1'], d['expected_cs2']
+            np.testing.assert_allclose(model.calc_cross_section(np.tile(1000.0, 6)), cs1)
+            np.testing.assert_allclose(model.calc_cross_section(np.tile(2500.0, 6)), cs2)
+            g10[f'{tag}_wn'] = wn
+            g10[f'{tag}_expected_cs1'] = cs1
+            g10[f'{tag}_expected_cs2'] = cs2
+        wn = ps.constant_resolution_spectrum(1e4 / 10.0, 1e4 / 0.5, 15.0)
+        cia = op.Collision_Induced(
+            f'{REF}/pyratbay/data/CIA/CIA_Borysow_H2H2_0060-7000K_0.6-500um.dat', wn=wn)
+        with np.load(f'{REF}/tests/expected/expected_cia_H2H2_opacity.npz') as d:
+            cs1, cs2, cs3 = d['expected_cs1'], d['expected_cs2'], d['expected_cs3']
+        np.testing.assert_allclose(cia.calc_cross_section(np.tile(1200.0, 6)), cs1)
+        np.testing.assert_allclose(cia.calc_cross_section(np.tile(3050.0, 6)), cs2)
+        g10.update(cia_wn=wn, cia_tab=cia.tab_cross_section, cia_temps=cia.temps,
+                   cia_lohi=np.array([cia._wn_lo_idx, cia._wn_hi_idx]),
+                   cia_expected_cs1=cs1, cia_expected_cs2=cs2, cia_expected_cs3=cs3)
+        np.savez_compressed(os.path.join(HERE, 'g10_opacity_goldens.npz'), **g10)
+        print('g10_opacity_goldens.npz',
+              os.path.getsize(os.path.join(HERE, 'g10_opacity_goldens.npz')) // 1024, 'KiB')
     finally:
         os.chdir(HERE)
         shutil.rmtree(work, ignore_errors=True)
