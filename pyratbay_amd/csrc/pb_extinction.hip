@@ -711,6 +711,7 @@ __global__ __launch_bounds__(NW * 64, 8) void k_ext_staged(LblArgs a)
     const int rowspan = a.rowcap + kStagePad;                            // buffer pitch
     Rec *s_rec = reinterpret_cast<Rec *>(s_row + 2 * rowspan + kStagePad);   // [kThreads]
     long long *s_src = reinterpret_cast<long long *>(s_rec + kThreads);  // row start, -1 empty
+    unsigned long long *s_desc = reinterpret_cast<unsigned long long *>(s_src);   // per segment
     unsigned long long *s_segmask =
         reinterpret_cast<unsigned long long *>(s_src + kThreads);        // [NW]
     unsigned *s_m = reinterpret_cast<unsigned *>(s_segmask + NW);        // mlo | mhi << 16
@@ -754,14 +755,13 @@ __global__ __launch_bounds__(NW * 64, 8) void k_ext_staged(LblArgs a)
     // out-of-window lanes fall outside the buffer descriptor and read 0 (no predicate)
     auto load_row = [&](int sg, auto Rc, double *reg) {
         constexpr int R = decltype(Rc)::value;
-        const int i0 = __builtin_amdgcn_readfirstlane((int)(s_seg[sg] & 0xffff));
-        const unsigned m = (unsigned)__builtin_amdgcn_readfirstlane((int)s_m[i0]);
-        const int mlo = (int)(m & 0xffff), mhi = (int)(m >> 16);
-        const long long so = s_src[i0];
-        const long long so_u = ((long long)__builtin_amdgcn_readfirstlane((int)(so >> 32)) << 32) |
-                               (unsigned)__builtin_amdgcn_readfirstlane((int)so);
+        const unsigned long long d = s_desc[sg];
+        const unsigned dlo = (unsigned)__builtin_amdgcn_readfirstlane((int)d);
+        const unsigned dhi = (unsigned)__builtin_amdgcn_readfirstlane((int)(d >> 32));
+        const long long first = ((long long)(dhi & 0xffu) << 32) | dlo;
+        const int len = (int)((dhi >> 8) & 0xfffu), mlo = (int)(dhi >> 20);
         const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
-            (void *)(a.pm + so_u + mlo), 0, (mhi - mlo) * 8, 0x00020000);
+            (void *)(a.pm + first), 0, len * 8, 0x00020000);
         typedef int v2i __attribute__((ext_vector_type(2)));
 #pragma unroll
         for (int r = 0; r < R; r++) {
@@ -861,11 +861,12 @@ __global__ __launch_bounds__(NW * 64, 8) void k_ext_staged(LblArgs a)
             const int nrec = min(kThreads, total - x0);
             __syncthreads();
             // ---- one record per lane, in (phase, iown) order, from k_records ----
+            long long src = -1;                        // phase row of my record (table element)
+            unsigned mwin = 0;                         // its window in row coordinates
             {
                 double k = 0.0;
-                unsigned win = 0, mwin = 0;
+                unsigned win = 0;
                 int qoff = 0;
-                long long src = -1;
                 const int x = x0 + tid;
                 if (x < total) {
                     int plo = 0, pup = osamp;           // largest p with s_cum[p] <= x
@@ -940,6 +941,12 @@ __global__ __launch_bounds__(NW * 64, 8) void k_ext_staged(LblArgs a)
                     }
                     const int pos = before + __builtin_popcountll(livemask & ((1ull << lane) - 1ull));
                     s_seg[pos] = (unsigned)tid | ((unsigned)end << 16);
+                    // the row descriptor of the segment, packed: first element of the window
+                    // (40 bits) | window length << 40 (12 bits) | window start << 52 (12 bits).
+                    // It overwrites s_src, which nothing reads after the barrier above.
+                    const unsigned long long mlo = mwin & 0xffffu, mhi = mwin >> 16;
+                    s_desc[pos] = (unsigned long long)(src + (long long)mlo) | ((mhi - mlo) << 40) |
+                                  (mlo << 52);
                 }
             }
             __syncthreads();
