@@ -61,6 +61,15 @@ struct __attribute__((aligned(32))) Rec32 {
     int pad[2];
 };
 
+// Record of the staged kernel: 16 bytes per (layer, phase-sorted group).  The window end, the
+// row offset q and the phase follow from ulo, len, the cell's half-width and the group's
+// fine index (ph_iown), so they are not stored.
+struct __attribute__((aligned(16))) Rec16 {
+    double k;            // co-added strength (before threshold / density)
+    int32_t ulo;         // window start on the global output grid
+    uint32_t lc;         // window length (12 bits) | table cell << 12
+};
+
 struct LblArgs {
     // Voigt table
     const double *pm;
@@ -102,6 +111,8 @@ struct LblArgs {
     const int32_t *gs_start;          // [niso][nwave+1]
     // scatter kernel: one 32-byte record per (layer, position-sorted group)
     struct Rec32 *rec32;
+    // staged kernel: packed records of the layers it computes (null: SoA records)
+    Rec16 *rec16;
     // staged kernel, small launches: the phases of a tile are split between nsplit workgroups
     // (blockIdx.z); split 0 writes ext, the others part[split-1][layer][row][sample]
     int nsplit;
@@ -649,6 +660,12 @@ __global__ __launch_bounds__(kBlock) void k_records(LblArgs a)
                 r.uhi = uhi;
                 r.pad[0] = r.pad[1] = 0;
                 a.rec32[idx] = r;
+            } else if (a.rec16 && !pos) {
+                Rec16 r;
+                r.k = k;
+                r.ulo = ulo;
+                r.lc = (uint32_t)(uhi - ulo) | ((uint32_t)cell << 12);
+                a.rec16[idx] = r;
             } else {
                 a.rec_k[idx] = k;
                 a.rec_ulo[idx] = ulo;
@@ -877,19 +894,34 @@ __global__ __launch_bounds__(NW * 64, 8) void k_ext_staged(LblArgs a)
                         else
                             pup = mid;
                     }
-                    const int64_t idx = recbase + s_phs[plo] + (x - s_cum[plo]);
-                    k = a.rec_k[idx];
-                    const int ulo = a.rec_ulo[idx], uhi = a.rec_uhi[idx];
+                    const int64_t gidx = s_phs[plo] + (x - s_cum[plo]);
+                    const int64_t idx = recbase + gidx;
+                    int ulo, uhi, q, cell, phi;
+                    if (a.rec16) {
+                        const Rec16 r = a.rec16[idx];
+                        k = r.k;
+                        ulo = r.ulo;
+                        uhi = ulo + (int)(r.lc & 0xfffu);
+                        cell = (int)(r.lc >> 12);
+                        const int d = a.psize[cell] - a.ph_iown[gidx];      // half - iown
+                        q = floor_div_inv(d, a.inv_osamp);
+                        phi = d - q * osamp;
+                    } else {
+                        k = a.rec_k[idx];
+                        ulo = a.rec_ulo[idx];
+                        uhi = a.rec_uhi[idx];
+                        q = a.rec_q[idx];
+                        cell = a.rec_cell[idx];
+                        phi = a.rec_phi[idx];
+                    }
                     const int lo = (int)(max((int64_t)ulo, t0) - t0);
                     const int hi = (int)(min((int64_t)uhi, tend) - t0);
                     if (!(k < kthresh) && lo < hi) {
                         if (a.add)
                             k *= dens;
-                        const int q = a.rec_q[idx];
-                        const int cell = a.rec_cell[idx];
                         win = (unsigned)lo | ((unsigned)hi << 16);
                         qoff = (int)(q + t0) * 8;       // tile sample j reads row[j + q + t0]
-                        src = a.pm_base[cell] + (long long)a.rec_phi[idx] * a.pm_stride[cell];
+                        src = a.pm_base[cell] + (long long)phi * a.pm_stride[cell];
                         mwin = (unsigned)(ulo + q) | ((unsigned)(uhi + q) << 16);
                     } else {
                         k = 0.0;
@@ -1634,6 +1666,7 @@ struct pb_lbl {
     int32_t *ls_resident = nullptr;   // [max_layers]
     int32_t *ls_block = nullptr;      // [max_layers]
     Rec32 *rec32 = nullptr;           // [max_layers][ngroups], scatter kernel
+    Rec16 *rec16 = nullptr;           // [max_layers][ngroups], staged kernel
     double *part = nullptr;           // partial sums of a phase-split staged launch
     size_t part_bytes = 0;
     int32_t *gs_start = nullptr;      // [niso][nwave+1]
@@ -2187,6 +2220,18 @@ int pb_lbl_extinction(pb_lbl *p, double *ext_d, int64_t wbegin, int64_t wcount,
                           (p->gather_mode == 0 || p->gather_mode == 3);
     a.res_cap = resident ? p->res_cap : 0;
     a.rec32 = nullptr;
+    a.rec16 = nullptr;
+    if (staged && !scatter && v->nlor * v->ndop < (1 << 20) && !getenv("PB_REC_SOA")) {
+        if (!p->rec16) {
+            const size_t n = (size_t)p->max_layers * (size_t)l->ngroups;
+            if (hipMalloc(&p->rec16, n * sizeof(Rec16)) != hipSuccess) {
+                pb::set_error("pb_lbl_extinction: cannot allocate %zu B of line records",
+                              n * sizeof(Rec16));
+                return PB_ERR_NOMEM;
+            }
+        }
+        a.rec16 = p->rec16;
+    }
     a.nsplit = 1;
     a.part = nullptr;
     if (scatter) {
@@ -2428,6 +2473,7 @@ void pb_lbl_destroy(pb_lbl *p)
     (void)hipFree(p->ls_resident);
     (void)hipFree(p->ls_block);
     (void)hipFree(p->rec32);
+    (void)hipFree(p->rec16);
     (void)hipFree(p->part);
     (void)hipFree(p->gs_start);
     (void)hipFree(p->ls_dnwn);
