@@ -2326,8 +2326,8 @@ int pb_lbl_extinction(pb_lbl *p, double *ext_d, int64_t wbegin, int64_t wcount,
         // slower at every size: 32 accumulators spill at the 64-register budget)
         const int64_t sub = kStagedWaves * kStageSpan;
         int S = pb::div_up(wcount, 2 * sub) * (int64_t)nlayers >= 750 ? 2 : 1;
-        if (S > 1)
-            nsplit = 1;
+        if (S > 1)      // measured on a 40-layer shard of C2: 0.86 ms unsplit, 0.73 ms split in two
+            nsplit = pb::div_up(wcount, 2 * sub) * (int64_t)nlayers < 1500 ? 2 : 1;
         if (getenv("PB_STAGE_SPLIT"))
             nsplit = std::max(1, std::min(8, atoi(getenv("PB_STAGE_SPLIT"))));
         a.nsplit = nsplit;
