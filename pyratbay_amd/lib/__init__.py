@@ -10,7 +10,7 @@ callers that cannot be changed -- the device-resident path is pyratbay_amd.engin
         sys.modules[f'pyratbay.lib.{name}'] = getattr(hip, name)
 """
 from . import (_extcoeff, vprofile, _trapezoid, _simpson, _blackbody, cutils, _indices,
-               _alkali)
+               _alkali, _spline)
 
 MODULES = ['_extcoeff', 'vprofile', '_trapezoid', '_simpson', '_blackbody', 'cutils',
-           '_indices', '_alkali']
+           '_indices', '_alkali', '_spline']
