@@ -94,6 +94,7 @@ struct LblArgs {
     const int32_t *ph_bin;
     int ph_nbins;
     int rowcap;                       // longest phase row of the table (samples)
+    int rowlds;                       // longest row (or row chunk) a staged LDS buffer holds
     const int32_t *ph_iso;            // isotope of every phase-sorted group
     const int32_t *giso;              // isotope of every position-sorted group
     // group list that k_records walks (phase-sorted or position-sorted) and whether the
@@ -113,6 +114,11 @@ struct LblArgs {
     struct Rec32 *rec32;
     // staged kernel: packed records of the layers it computes (null: SoA records)
     Rec16 *rec16;
+    // long phase rows (> kStageRowMax samples) are cut into nch_max chunks of kStageRowMax
+    // samples; every (group, chunk) then has its own packed record and the gather kernel
+    // treats (phase, chunk) as a phase of its own.  Layout of a layer's records:
+    // [phase p][chunk k][position] = ps*nch_max + k*cnt_p + (g - ps).  1 = no chunking.
+    int nch_max;
     // staged kernel, small launches: the phases of a tile are split between nsplit workgroups
     // (blockIdx.z); split 0 writes ext, the others part[split-1][layer][row][sample]
     int nsplit;
@@ -140,6 +146,7 @@ struct LblArgs {
     double *li_alphad, *li_dens, *li_z;
     int32_t *li_ilor, *li_hmax;
     int32_t *li_rowmax;               // longest phase row the (layer, isotope) can select
+    int32_t *li_hlo, *li_hhi;         // smallest / largest profile half-width it can select
     unsigned long long *kmax_bits;
     // grid
     const double *wn;
@@ -202,11 +209,16 @@ __global__ __launch_bounds__(64) void k_layer_state(LblArgs a)
             const int dlo = max(0, pb::nearest_index(a.doppler, alphad * a.own0, 0, a.ndop - 1) - 1);
             const int dhi = min(a.ndop - 1,
                                 pb::nearest_index(a.doppler, alphad * a.own_last, 0, a.ndop - 1) + 1);
-            int used = 0;
-            for (int d = dlo; d <= dhi; d++)
+            int used = 0, hlo = INT_MAX, hhi = 0;
+            for (int d = dlo; d <= dhi; d++) {
                 used = max(used, a.pm_stride[ilor * a.ndop + d]);
+                hlo = min(hlo, a.psize[ilor * a.ndop + d]);
+                hhi = max(hhi, a.psize[ilor * a.ndop + d]);
+            }
             atomicMax(&s_block, used * a.osamp);
             a.li_rowmax[(int64_t)layer * a.niso + i] = used;
+            a.li_hlo[(int64_t)layer * a.niso + i] = hlo;
+            a.li_hhi[(int64_t)layer * a.niso + i] = hhi;
         }
         const int64_t k = (int64_t)layer * a.niso + i;
         a.li_alphad[k] = alphad;
@@ -581,6 +593,7 @@ __device__ inline int floor_div_inv(int a, double inv)
     return (int)floor(((double)a + 0.5) * inv);
 }
 
+constexpr int kChunkRow = 1024;      // samples per chunk of a long phase row (= kStageRowMax)
 constexpr int kRecLayers = 4;        // layers per thread of k_records (group data loaded once)
 
 __global__ __launch_bounds__(kBlock) void k_records(LblArgs a)
@@ -660,6 +673,24 @@ __global__ __launch_bounds__(kBlock) void k_records(LblArgs a)
                 r.uhi = uhi;
                 r.pad[0] = r.pad[1] = 0;
                 a.rec32[idx] = r;
+            } else if (a.rec16 && !pos && a.nch_max > 1) {
+                // one record per chunk of the phase row: the part of the window whose row
+                // coordinates u = sample + q fall into [c0, c0 + kStageRowMax)
+                const int64_t ps = a.ph_start[(int64_t)iso * (a.osamp + 1) + iown % a.osamp];
+                const int64_t pe = a.ph_start[(int64_t)iso * (a.osamp + 1) + iown % a.osamp + 1];
+                const int64_t li = (int64_t)layer * a.niso + iso;
+                const int nch = (min(a.rowcap, a.li_rowmax[li]) + kChunkRow - 1) / kChunkRow;
+                const int64_t lbase = (int64_t)layer * a.ngroups * a.nch_max;
+                const int mlo = ulo + q, mhi = uhi + q;
+                for (int c = 0; c < nch; c++) {
+                    const int c0 = c * kChunkRow;
+                    const int wlo = max(mlo, c0), whi = min(mhi, c0 + kChunkRow);
+                    Rec16 r;
+                    r.k = k;
+                    r.ulo = whi > wlo ? wlo - q : ulo;
+                    r.lc = (uint32_t)max(whi - wlo, 0) | ((uint32_t)cell << 12);
+                    a.rec16[lbase + ps * a.nch_max + (int64_t)c * (pe - ps) + (g - ps)] = r;
+                }
             } else if (a.rec16 && !pos) {
                 Rec16 r;
                 r.k = k;
@@ -725,7 +756,7 @@ __global__ __launch_bounds__(NW * 64, 8) void k_ext_staged(LblArgs a)
         int qoff;                 // byte offset of tile sample 0 from the row buffer start
         unsigned win;             // lo | hi << 16 (tile coordinates)
     };
-    const int rowspan = a.rowcap + kStagePad;                            // buffer pitch
+    const int rowspan = a.rowlds + kStagePad;                            // buffer pitch
     Rec *s_rec = reinterpret_cast<Rec *>(s_row + 2 * rowspan + kStagePad);   // [kThreads]
     long long *s_src = reinterpret_cast<long long *>(s_rec + kThreads);  // row start, -1 empty
     unsigned long long *s_desc = reinterpret_cast<unsigned long long *>(s_src);   // per segment
@@ -734,8 +765,9 @@ __global__ __launch_bounds__(NW * 64, 8) void k_ext_staged(LblArgs a)
     unsigned *s_m = reinterpret_cast<unsigned *>(s_segmask + NW);        // mlo | mhi << 16
     unsigned *s_seg = s_m + kThreads;                                    // i0 | i1 << 16
     int *s_part = reinterpret_cast<int *>(s_seg + kThreads);             // [NW] scan scratch
-    int *s_cum = s_part + NW;                                            // [osamp+1]
-    int *s_phs = s_cum + (osamp + 1);                                    // [osamp]
+    const int vmax = osamp * a.nch_max;                                  // (phase, chunk) pairs
+    int *s_cum = s_part + NW;                                            // [vmax+1]
+    int *s_phs = s_cum + (vmax + 1);                                     // [vmax]
 
     int tile, layer;
     decode_block(a, tile, layer);
@@ -768,7 +800,7 @@ __global__ __launch_bounds__(NW * 64, 8) void k_ext_staged(LblArgs a)
     double ring[2 * kRowRegs];
     // Rows of this (layer, isotope) are at most `rowlim` samples long: wavefronts whose
     // lanes lie beyond it do not store (the buffers are zeroed per isotope).
-    int rowlim = a.rowcap;
+    int rowlim = a.rowlds;
     // out-of-window lanes fall outside the buffer descriptor and read 0 (no predicate)
     auto load_row = [&](int sg, auto Rc, double *reg) {
         constexpr int R = decltype(Rc)::value;
@@ -795,7 +827,7 @@ __global__ __launch_bounds__(NW * 64, 8) void k_ext_staged(LblArgs a)
             if (wave * 64 + r * kThreads >= rowlim)
                 continue;
             const int mm = tid + r * kThreads;
-            if (mm < a.rowcap)
+            if (mm < a.rowlds)
                 dst[mm] = reg[r];
         }
     };
@@ -816,31 +848,56 @@ __global__ __launch_bounds__(NW * 64, 8) void k_ext_staged(LblArgs a)
         // then an exclusive scan of the counts (thread t owns a run of `per` phases)
         __syncthreads();
         {
-            const int lim = min(a.rowcap, a.li_rowmax[li]);
+            const int lim = min(a.rowlds, a.li_rowmax[li]);
             if (lim != rowlim) {                   // wave-uniform
                 for (int i = tid; i < 2 * rowspan + kStagePad; i += kThreads)
                     s_row[i] = 0.0;
                 rowlim = lim;
             }
         }
-        const int per = (osamp + kThreads - 1) / kThreads;
+        // "virtual phases": (phase p, chunk c) pairs, pv = p*nch + c; nch = 1 unless the rows of
+        // this (layer, isotope) are longer than kStageRowMax
+        const int nch = a.nch_max > 1
+                            ? (min(a.rowcap, a.li_rowmax[li]) + kChunkRow - 1) / kChunkRow
+                            : 1;
+        const int nvirt = osamp * nch;
+        const int per = (nvirt + kThreads - 1) / kThreads;
         int mine = 0;
         for (int r = 0; r < per; r++) {
-            const int p = tid * per + r;
-            if (p < osamp && a.nsplit > 1 && p * a.nsplit / osamp != (int)blockIdx.z) {
-                s_phs[p] = 0;                      // another workgroup's phase
-                s_cum[p] = 0;
-            } else if (p < osamp) {
+            const int pv = tid * per + r;
+            const int p = pv / nch, c = pv - p * nch;
+            if (pv < nvirt && a.nsplit > 1 && p * a.nsplit / osamp != (int)blockIdx.z) {
+                s_phs[pv] = 0;                     // another workgroup's phase
+                s_cum[pv] = 0;
+            } else if (pv < nvirt) {
                 // two table lookups bracket each bound to within one bin (a fraction of a
                 // record per phase), then a short bisection makes it exact
                 const int32_t *bin = a.ph_bin + ((int64_t)iso * osamp + p) * (a.ph_nbins + 1);
                 const int64_t binw = (int64_t)kBinSamples * osamp;
-                const int b0 = (int)min((int64_t)a.ph_nbins - 1, max((int64_t)0, flo) / binw);
-                const int b1 = (int)min((int64_t)a.ph_nbins - 1, max((int64_t)0, fhi + 1) / binw);
-                const int64_t s0 = lower_bound_i32(a.ph_iown, bin[b0], bin[b0 + 1], flo);
-                const int64_t s1 = lower_bound_i32(a.ph_iown, bin[b1], bin[b1 + 1], fhi + 1);
-                s_phs[p] = (int)s0;
-                s_cum[p] = (int)(s1 - s0);
+                // a chunk of a long row covers the samples [c0 - q, c0 + 1024 - q) with
+                // q = floor((half - iown)/osamp): only groups at fine positions within
+                // [t0*osamp + half - (c0+1024)*osamp, tend*osamp + half - c0*osamp] (+- one
+                // sample, half between the smallest and largest one of the isotope) reach the tile
+                int64_t clo = flo, chi = fhi;
+                if (a.nch_max > 1) {
+                    const int64_t c0 = (int64_t)c * kChunkRow;
+                    clo = max(clo, (t0 - c0 - kChunkRow - 1) * osamp + a.li_hlo[li]);
+                    chi = min(chi, (tend - c0 + 1) * osamp + a.li_hhi[li]);
+                    if (chi < clo)
+                        chi = clo - 1;
+                }
+                const int b0 = (int)min((int64_t)a.ph_nbins - 1, max((int64_t)0, clo) / binw);
+                const int b1 = (int)min((int64_t)a.ph_nbins - 1, max((int64_t)0, chi + 1) / binw);
+                const int64_t s0 = lower_bound_i32(a.ph_iown, bin[b0], bin[b0 + 1], clo);
+                const int64_t s1 = lower_bound_i32(a.ph_iown, bin[b1], bin[b1 + 1], chi + 1);
+                int64_t first = s0;                // entry of the layer's record array
+                if (a.nch_max > 1) {
+                    const int64_t ps = a.ph_start[(int64_t)iso * (osamp + 1) + p];
+                    const int64_t pe = a.ph_start[(int64_t)iso * (osamp + 1) + p + 1];
+                    first = ps * a.nch_max + (int64_t)c * (pe - ps) + (s0 - ps);
+                }
+                s_phs[pv] = (int)first;
+                s_cum[pv] = (int)(s1 - s0);
                 mine += (int)(s1 - s0);
             }
         }
@@ -863,15 +920,15 @@ __global__ __launch_bounds__(NW * 64, 8) void k_ext_staged(LblArgs a)
         }
         int run = base + incl - mine;
         for (int r = 0; r < per; r++) {
-            const int p = tid * per + r;
-            if (p < osamp) {
-                const int c = s_cum[p];
-                s_cum[p] = run;
+            const int pv = tid * per + r;
+            if (pv < nvirt) {
+                const int c = s_cum[pv];
+                s_cum[pv] = run;
                 run += c;
             }
         }
         if (tid == 0)
-            s_cum[osamp] = total;
+            s_cum[nvirt] = total;
         __syncthreads();
 
         for (int x0 = 0; x0 < total; x0 += kThreads) {
@@ -886,7 +943,7 @@ __global__ __launch_bounds__(NW * 64, 8) void k_ext_staged(LblArgs a)
                 int qoff = 0;
                 const int x = x0 + tid;
                 if (x < total) {
-                    int plo = 0, pup = osamp;           // largest p with s_cum[p] <= x
+                    int plo = 0, pup = nvirt;           // largest pv with s_cum[pv] <= x
                     while (pup - plo > 1) {
                         const int mid = (plo + pup) >> 1;
                         if (s_cum[mid] <= x)
@@ -894,8 +951,17 @@ __global__ __launch_bounds__(NW * 64, 8) void k_ext_staged(LblArgs a)
                         else
                             pup = mid;
                     }
-                    const int64_t gidx = s_phs[plo] + (x - s_cum[plo]);
-                    const int64_t idx = recbase + gidx;
+                    const int64_t entry = s_phs[plo] + (x - s_cum[plo]);
+                    int64_t gidx = entry;               // index in the phase-sorted group list
+                    int c0 = 0;                         // first row sample of my chunk
+                    if (a.nch_max > 1) {
+                        const int p = plo / nch, c = plo - p * nch;
+                        const int64_t ps = a.ph_start[(int64_t)iso * (osamp + 1) + p];
+                        const int64_t pe = a.ph_start[(int64_t)iso * (osamp + 1) + p + 1];
+                        gidx = entry - ps * (a.nch_max - 1) - (int64_t)c * (pe - ps);
+                        c0 = c * kChunkRow;
+                    }
+                    const int64_t idx = recbase * a.nch_max + entry;
                     int ulo, uhi, q, cell, phi;
                     if (a.rec16) {
                         const Rec16 r = a.rec16[idx];
@@ -906,6 +972,7 @@ __global__ __launch_bounds__(NW * 64, 8) void k_ext_staged(LblArgs a)
                         const int d = a.psize[cell] - a.ph_iown[gidx];      // half - iown
                         q = floor_div_inv(d, a.inv_osamp);
                         phi = d - q * osamp;
+                        q -= c0;                        // row index relative to the chunk
                     } else {
                         k = a.rec_k[idx];
                         ulo = a.rec_ulo[idx];
@@ -921,7 +988,7 @@ __global__ __launch_bounds__(NW * 64, 8) void k_ext_staged(LblArgs a)
                             k *= dens;
                         win = (unsigned)lo | ((unsigned)hi << 16);
                         qoff = (int)(q + t0) * 8;       // tile sample j reads row[j + q + t0]
-                        src = a.pm_base[cell] + (long long)phi * a.pm_stride[cell];
+                        src = a.pm_base[cell] + (long long)phi * a.pm_stride[cell] + c0;
                         mwin = (unsigned)(ulo + q) | ((unsigned)(uhi + q) << 16);
                     } else {
                         k = 0.0;
@@ -1647,7 +1714,7 @@ struct pb_lbl {
     int32_t *d_divisors = nullptr, *d_isoimol = nullptr, *d_isoiext = nullptr;
     // workspace
     int32_t *ls_ofactor = nullptr, *ls_scale = nullptr, *li_ilor = nullptr, *li_hmax = nullptr;
-    int32_t *li_rowmax = nullptr;
+    int32_t *li_rowmax = nullptr, *li_hlo = nullptr, *li_hhi = nullptr;
     int64_t *ls_dnwn = nullptr;
     double *ls_dwnstep = nullptr, *li_alphad = nullptr, *li_dens = nullptr, *li_z = nullptr;
     unsigned long long *kmax_bits = nullptr;
@@ -1916,6 +1983,8 @@ int pb_lbl_create(pb_lbl **out, pb_voigt *voigt, pb_lines *lines, const double *
     alloc((void **)&p->li_ilor, LI * 4);
     alloc((void **)&p->li_hmax, LI * 4);
     alloc((void **)&p->li_rowmax, LI * 4);
+    alloc((void **)&p->li_hlo, LI * 4);
+    alloc((void **)&p->li_hhi, LI * 4);
     alloc((void **)&p->kmax_bits, L * (size_t)rows * 8);
     alloc((void **)&p->ls_resident, L * 4);
     alloc((void **)&p->ls_block, L * 4);
@@ -2162,6 +2231,8 @@ int pb_lbl_extinction(pb_lbl *p, double *ext_d, int64_t wbegin, int64_t wcount,
     a.li_ilor = p->li_ilor;
     a.li_hmax = p->li_hmax;
     a.li_rowmax = p->li_rowmax;
+    a.li_hlo = p->li_hlo;
+    a.li_hhi = p->li_hhi;
     a.kmax_bits = p->kmax_bits;
     a.wn = p->d_wn;
     a.own0 = l->own0;
@@ -2189,12 +2260,21 @@ int pb_lbl_extinction(pb_lbl *p, double *ext_d, int64_t wbegin, int64_t wcount,
     // properties (never on the shard), so shards and the full grid run the same arithmetic.
     constexpr int kStagedWaves = 8;
     constexpr int kStagedThreads = kStagedWaves * 64;
+    // rows longer than kStageRowMax samples are staged in chunks: (phase, chunk) pairs act as
+    // phases and k_records writes one packed record per (group, chunk)
+    const int nch_max = (int)pb::div_up((int64_t)a.rowcap, (int64_t)kChunkRow);
+    a.nch_max = std::max(1, nch_max);
+    a.rowlds = std::min(a.rowcap, kStageRowMax);
     const size_t lds_fixed = (size_t)kStagedThreads * (16 + 8 + 4 + 4) + kStagedWaves * 12 +
-                             (size_t)(2 * v->osamp + 1) * 4 + 64;
-    const size_t lds = (2 * ((size_t)a.rowcap + kStagePad) + kStagePad) * 8 + lds_fixed;
+                             (size_t)(2 * v->osamp * a.nch_max + 1) * 4 + 64;
+    const size_t lds = (2 * ((size_t)a.rowlds + kStagePad) + kStagePad) * 8 + lds_fixed;
     const double per_phase = (double)l->ngroups / std::max(1, p->nwave) * 2048.0 / v->osamp;
-    const bool can_stage = !p->resolution && a.rowcap <= kStageRowMax && lds <= 160 * 1024 &&
-                           l->ngroups > 0;
+    const bool packable = v->nlor * v->ndop < (1 << 20);
+    const size_t rec16_bytes = (size_t)p->max_layers * (size_t)l->ngroups * a.nch_max * sizeof(Rec16);
+    const bool can_stage = !p->resolution && lds <= 160 * 1024 && l->ngroups > 0 &&
+                           (a.nch_max == 1 ||
+                            (a.nch_max <= 16 && packable && rec16_bytes <= ((size_t)96 << 30) &&
+                             !getenv("PB_NO_LONG_ROWS")));
     // the staged kernel needs enough workgroups to hide its per-segment latency; small
     // launches (multi-GPU shards) go to the global gather with record splitting.  Measured
     // on layer shards of C2 (tools/bench_rank.py): 40 and 20 layers staged 0.85 / 0.65 ms vs
@@ -2221,12 +2301,13 @@ int pb_lbl_extinction(pb_lbl *p, double *ext_d, int64_t wbegin, int64_t wcount,
     a.res_cap = resident ? p->res_cap : 0;
     a.rec32 = nullptr;
     a.rec16 = nullptr;
-    if (staged && !scatter && v->nlor * v->ndop < (1 << 20) && !getenv("PB_REC_SOA")) {
+    if (!staged || scatter)
+        a.nch_max = 1;
+    if (staged && !scatter && packable && (a.nch_max > 1 || !getenv("PB_REC_SOA"))) {
         if (!p->rec16) {
-            const size_t n = (size_t)p->max_layers * (size_t)l->ngroups;
-            if (hipMalloc(&p->rec16, n * sizeof(Rec16)) != hipSuccess) {
+            if (hipMalloc(&p->rec16, rec16_bytes) != hipSuccess) {
                 pb::set_error("pb_lbl_extinction: cannot allocate %zu B of line records",
-                              n * sizeof(Rec16));
+                              rec16_bytes);
                 return PB_ERR_NOMEM;
             }
         }
@@ -2484,6 +2565,8 @@ void pb_lbl_destroy(pb_lbl *p)
     (void)hipFree(p->li_ilor);
     (void)hipFree(p->li_hmax);
     (void)hipFree(p->li_rowmax);
+    (void)hipFree(p->li_hlo);
+    (void)hipFree(p->li_hhi);
     (void)hipFree(p->kmax_bits);
     (void)hipFree(p->ph_first);
     (void)hipFree(p->ph_count);

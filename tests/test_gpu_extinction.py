@@ -197,3 +197,46 @@ def test_empty_and_out_of_range_lines(eng):
         ext = host(lbl.extinction(eng.dev(atm['temp']), eng.dev(atm['dens']),
                                   eng.dev(iso['isoz'])))
         assert ext.shape == (3, 1, 513) and np.all(ext == 0)
+
+
+@pytest.mark.parametrize('gather', ['staged', 'global'])
+def test_long_rows_vs_oracle(eng, orc, gather):
+    """Phase rows longer than one staged LDS row (1024 samples): the staged kernel cuts them
+    into chunks, (phase, chunk) pairs acting as phases.  Wide cutoff on a fine grid gives
+    rows of ~3 200 samples here (4 chunks, the last one partial)."""
+    from pyratbay_amd import synth
+    case = synth.lbl_case(4097, 5, 2500, wnosamp=12, nlor=10, ndop=5, extent=4000.0,
+                          cutoff=80.0, niso=2, seed=21)
+    g, atm, ln, iso, vg = (case[k] for k in ('grid', 'atm', 'lines', 'iso', 'voigt'))
+    vt = eng.VoigtTable.build(vg['lorentz'], vg['doppler'], vg['size'], g['ownstep'], 12)
+    rowmax = int(np.max(2 * np.asarray(vt.size) + 1)) // 12
+    assert rowmax > 2048, rowmax
+    ll = eng.LineList(ln['lwn'], ln['elow'], ln['gf'], ln['lid'], 2, g['own'])
+    lbl = eng.LBL(vt, ll, g['wn'], g['divisors'], atm['mol_radius'], atm['mol_mass'],
+                  iso['isoimol'], iso['isomass'], iso['isoratio'], iso['isoiext'],
+                  vg['cutoff'], 1e-30, max_layers=5)
+    lbl.set_gather_mode(gather)
+    t, d, z = eng.dev(atm['temp']), eng.dev(atm['dens']), eng.dev(iso['isoz'])
+    ext = host(lbl.extinction(t, d, z, add=True))
+    assert lbl.last_gather_kernel == {'staged': 'k_ext_staged', 'global': 'k_ext_resample'}[gather]
+    profile = vt.flat()
+    worst = 0.0
+    for layer in range(5):
+        want = np.zeros((1, g['nwave']))
+        orc.extinction(want, profile, vt.size, vt.index, vg['lorentz'], vg['doppler'],
+                       g['wn'], g['own'], g['divisors'], atm['dens'][layer],
+                       atm['mol_radius'], atm['mol_mass'], iso['isoimol'], iso['isomass'],
+                       iso['isoratio'], iso['isoz'][:, layer].copy(), iso['isoiext'],
+                       ln['lwn'], ln['elow'], ln['gf'], ln['lid'], vg['cutoff'], 1e-30,
+                       atm['temp'][layer], 0, 1, 0)
+        got = ext[layer]
+        assert np.array_equal(got == 0, want == 0), layer
+        nz = want != 0
+        worst = max(worst, np.max(np.abs(got[nz] / want[nz] - 1)))
+        np.testing.assert_allclose(got, want, rtol=RTOL)
+    print(f'long rows ({rowmax} samples) {gather}: max rel err vs oracle = {worst:.2e}')
+    # shards of the chunked path concatenate exactly, too
+    if gather == 'staged':
+        parts = [host(lbl.extinction(t, d, z, wbegin=a, wcount=b - a))
+                 for a, b in ((0, 1500), (1500, 4097))]
+        assert np.array_equal(np.concatenate(parts, axis=2), ext)
