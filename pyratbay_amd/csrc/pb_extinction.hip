@@ -1733,7 +1733,8 @@ struct pb_lbl {
     int32_t *ls_resident = nullptr;   // [max_layers]
     int32_t *ls_block = nullptr;      // [max_layers]
     Rec32 *rec32 = nullptr;           // [max_layers][ngroups], scatter kernel
-    Rec16 *rec16 = nullptr;           // [max_layers][ngroups], staged kernel
+    Rec16 *rec16 = nullptr;           // [layers of the largest call][ngroups][nch_max], staged kernel
+    size_t rec16_alloc = 0;
     double *part = nullptr;           // partial sums of a phase-split staged launch
     size_t part_bytes = 0;
     int32_t *gs_start = nullptr;      // [niso][nwave+1]
@@ -2270,7 +2271,8 @@ int pb_lbl_extinction(pb_lbl *p, double *ext_d, int64_t wbegin, int64_t wcount,
     const size_t lds = (2 * ((size_t)a.rowlds + kStagePad) + kStagePad) * 8 + lds_fixed;
     const double per_phase = (double)l->ngroups / std::max(1, p->nwave) * 2048.0 / v->osamp;
     const bool packable = v->nlor * v->ndop < (1 << 20);
-    const size_t rec16_bytes = (size_t)p->max_layers * (size_t)l->ngroups * a.nch_max * sizeof(Rec16);
+    // sized for the layers of this call (a layer shard of a multi-GPU run holds few of them)
+    const size_t rec16_bytes = (size_t)nlayers * (size_t)l->ngroups * a.nch_max * sizeof(Rec16);
     const bool can_stage = !p->resolution && lds <= 160 * 1024 && l->ngroups > 0 &&
                            (a.nch_max == 1 ||
                             (a.nch_max <= 16 && packable && rec16_bytes <= ((size_t)96 << 30) &&
@@ -2304,12 +2306,19 @@ int pb_lbl_extinction(pb_lbl *p, double *ext_d, int64_t wbegin, int64_t wcount,
     if (!staged || scatter)
         a.nch_max = 1;
     if (staged && !scatter && packable && (a.nch_max > 1 || !getenv("PB_REC_SOA"))) {
-        if (!p->rec16) {
+        if (rec16_bytes > p->rec16_alloc) {
+            if (p->rec16) {
+                PB_HIP(hipStreamSynchronize(s));       // an earlier call may still read it
+                (void)hipFree(p->rec16);
+                p->rec16 = nullptr;
+                p->rec16_alloc = 0;
+            }
             if (hipMalloc(&p->rec16, rec16_bytes) != hipSuccess) {
                 pb::set_error("pb_lbl_extinction: cannot allocate %zu B of line records",
                               rec16_bytes);
                 return PB_ERR_NOMEM;
             }
+            p->rec16_alloc = rec16_bytes;
         }
         a.rec16 = p->rec16;
     }
