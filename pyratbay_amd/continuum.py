@@ -349,15 +349,24 @@ class Continuum:
         self.pressure_barye = dev(self.pressure * BAR)
         self._cs_key = None
 
-    def _rank1_arrays(self, temperature, density):
-        pairs = [m.rank1(self.pressure, temperature, density) for m in self.rank1]
-        cs = np.array([p[0] for p in pairs]).reshape(len(pairs), self.nwave)
-        f = np.array([p[1] for p in pairs]).reshape(len(pairs), len(temperature))
-        return cs, f
+    def _rank1_cross_sections(self):
+        """[nrank1, nwave] on the device; uploaded again only when a model's parameters
+        (Lecavelier: scale and exponent) change."""
+        key = tuple((id(m), tuple(np.ravel(getattr(m, 'pars', ())).tolist())) for m in self.rank1)
+        if key != self._cs_key:
+            rows = []
+            for m in self.rank1:
+                if isinstance(m, Lecavelier):
+                    m.calc_cross_section()
+                rows.append(np.ones(self.nwave) if isinstance(m, CCSgray) else m.cross_section)
+            self._cs_d = dev(np.array(rows).reshape(len(rows), self.nwave))
+            self._cs_key = key
+        return self._cs_d
 
     def add(self, ec, temperature, density):
         """ec[L,W] (device, float64) += every term.  temperature[L] and the number
-        densities {species: n[L]} (molecules cm-3) are host arrays: L values each."""
+        densities {species: n[L]} (molecules cm-3) are host arrays: L values each; they
+        travel to the device in ONE packed upload per call."""
         temperature = np.asarray(temperature, float)
         nlayers = len(temperature)
         assert ec.shape == (nlayers, self.nwave) and ec.is_contiguous()
@@ -365,31 +374,31 @@ class Continuum:
             if np.any(temperature < m.tmin) or np.any(temperature > m.tmax):
                 raise ValueError('Invalid temperature, values must be in the '
                                  f'{m.tmin:.1f}-{m.tmax:.1f} K range')
-        temp_d = dev(temperature)
-        keep = [temp_d]
-        nr1 = len(self.rank1)
-        cs_d = f_d = None
-        if nr1:
-            cs, f = self._rank1_arrays(temperature, density)
-            cs_d, f_d = dev(cs), dev(f)
-            keep += [cs_d, f_d]
-        ncia = len(self.cia)
+        nr1, ncia = len(self.rank1), len(self.cia)
+        # per-layer factors, packed: temperature | rank-1 | CIA | H- | alkali densities
+        parts = [temperature]
+        parts += [np.asarray(m.rank1(self.pressure, temperature, density)[1], float)
+                  for m in self.rank1]
+        parts += [np.prod([density[s] for s in m.species], axis=0) for m in self.cia]
+        if self.hminus:
+            parts.append(np.asarray(density['H'], float) * np.asarray(density['e-'], float))
+        parts += [np.asarray(density[m.species], float) for m in self.alkali]
+        packed = dev(np.concatenate([np.broadcast_to(p, nlayers) for p in parts]))
+        row = [packed[i * nlayers:(i + 1) * nlayers] for i in range(len(parts))]
+        temp_d = row[0]
+        f_d = packed[nlayers:(1 + nr1) * nlayers] if nr1 else None
+        cia_f_d = packed[(1 + nr1) * nlayers:(1 + nr1 + ncia) * nlayers] if ncia else None
+        nxt = 1 + nr1 + ncia
+        cs_d = self._rank1_cross_sections() if nr1 else None
         tabs = (C.c_void_p * max(ncia, 1))(*[t.data_ptr() for t in self.cia_tab])
         temps = (C.c_void_p * max(ncia, 1))(*[t.data_ptr() for t in self.cia_temps])
         ntemp = np.array([m.ntemp for m in self.cia] or [0], np.int32)
         lo = np.array([m._wn_lo_idx for m in self.cia] or [0], np.int32)
         hi = np.array([m._wn_hi_idx for m in self.cia] or [0], np.int32)
-        cia_f_d = None
-        if ncia:
-            cia_f = np.array([np.prod([density[s] for s in m.species], axis=0)
-                              for m in self.cia])
-            cia_f_d = dev(cia_f)
-            keep.append(cia_f_d)
         hm = (None, None, None)
         if self.hminus:
-            hm_f = dev(np.asarray(density['H'], float) * np.asarray(density['e-'], float))
-            keep.append(hm_f)
-            hm = (self.hm_sigma_bf, self.hm_ff, hm_f)
+            hm = (self.hm_sigma_bf, self.hm_ff, row[nxt])
+            nxt += 1
         if nr1 or ncia or self.hminus:
             call('pb_continuum', _ptr(ec), _ptr(self.wn), _ptr(temp_d), nlayers, self.nwave,
                  nr1, _ptr(cs_d), _ptr(f_d), ncia,
@@ -397,10 +406,11 @@ class Continuum:
                  C.cast(temps, C.c_void_p) if ncia else None,
                  hptr(ntemp), hptr(lo), hptr(hi), _ptr(cia_f_d), _ptr(hm[0]), _ptr(hm[1]),
                  _ptr(hm[2]), _stream())
-        for m in self.alkali:
+        keep = [packed]
+        for ia, m in enumerate(self.alkali):
             vd = dev(m.voigt_det(temperature))
-            dens_d = dev(density[m.species])
-            keep += [vd, dens_d]
+            dens_d = row[nxt + ia]
+            keep.append(vd)
             wn0, gf = np.array(m.wn0, float), np.array(m.gf, float)
             call('pb_alkali_cross_section', _ptr(ec), _ptr(self.pressure_barye), _ptr(self.wn),
                  _ptr(temp_d), _ptr(vd), float(m.detuning), float(m.mass), float(m.lpar),
