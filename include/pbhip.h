@@ -267,6 +267,12 @@ int pb_alkali_cross_section(double *ec_d, const double *pressure_d, const double
                             const double *wn0_h, const double *gf_h, int nlines,
                             const double *density_d, int nlayers, int nwave, void *stream);
 
+/* Gaussian log-likelihood of band-integrated models (tools/retrieval_tools.py:98-104):
+ * loglike_d[w] = -0.5*sum_b ((data_d[b] - bandflux_d[w,b]) / uncert_d[b])^2
+ *                -0.5*sum_b log(2*pi*uncert_d[b]^2), or -inf when that is not finite. */
+int pb_loglike(double *loglike_d, const double *bandflux_d, const double *data_d,
+               const double *uncert_d, int nwalkers, int nbands, void *stream);
+
 /* Two-stream fluxes (pyratbay/pyrat/spectrum.py:454-522, Heng et al. 2014 Eqs. B5-B6) from
  * the plane-parallel optical depth depth_d[nlayers,nwave] (computed with maxdepth = inf,
  * opacity/optic_depth.py:124-125): flux_down_d, flux_up_d [nlayers,nwave]; the emission

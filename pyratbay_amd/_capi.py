@@ -65,6 +65,7 @@ _PROTOS = {
     'pb_emission_flux_deck': [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp],
     'pb_continuum': [vp, vp, vp, i32, i32, i32, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp],
     'pb_alkali_cross_section': [vp, vp, vp, vp, vp, f64, f64, f64, f64, f64, vp, vp, i32, vp, i32, i32, vp],
+    'pb_loglike': [vp, vp, vp, vp, i32, i32, vp],
     'pb_two_stream': [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp],
     'pb_internal_flux': [vp, vp, f64, i32, vp],
     'pb_simps2D': [vp, vp, i32, i32, vp, vp, vp, vp, vp, vp],

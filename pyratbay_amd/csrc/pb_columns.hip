@@ -582,6 +582,34 @@ __global__ __launch_bounds__(kBlock) void k_internal_flux(double *f_int, const d
     }
 }
 
+// ---------------------------------------------------------------------------
+// Gaussian log-likelihood of band fluxes (pyratbay/tools/retrieval_tools.py:98-104): one
+// walker per wavefront, -0.5*sum(((data-model)/uncert)^2) - 0.5*sum(log(2*pi*uncert^2)),
+// -inf when not finite.  Sums in lane-strided order, then a fixed butterfly.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_loglike(double *loglike, const double *model,
+                                                const double *data, const double *uncert,
+                                                int nbands)
+{
+    const int w = blockIdx.x;
+    const double *m = model + (int64_t)w * nbands;
+    double chi = 0.0, norm = 0.0;
+    for (int b = threadIdx.x; b < nbands; b += 64) {
+        const double r = (data[b] - m[b]) / uncert[b];
+        chi += r * r;
+        norm += log(2.0 * 3.141592653589793 * (uncert[b] * uncert[b]));
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        chi += __shfl_xor(chi, d);
+        norm += __shfl_xor(norm, d);
+    }
+    if (threadIdx.x == 0) {
+        const double ll = -0.5 * chi - 0.5 * norm;
+        loglike[w] = isfinite(ll) ? ll : -INFINITY;
+    }
+}
+
 }  // namespace
 
 // ===========================================================================
@@ -834,6 +862,19 @@ int pb_two_stream(double *flux_down_d, double *flux_up_d, const double *depth_d,
     k_two_stream<<<pb::div_up(nwave, kBlock), kBlock, 0, pb::as_stream(stream)>>>(
         flux_down_d, flux_up_d, depth_d, wn_d, temp_d, f_int_d, flux_top_d, rtop, nlayers,
         nwave);
+    PB_LAUNCH_CHECK();
+    return PB_OK;
+}
+
+int pb_loglike(double *loglike_d, const double *bandflux_d, const double *data_d,
+               const double *uncert_d, int nwalkers, int nbands, void *stream)
+{
+    PB_REQUIRE(nwalkers >= 0 && nbands >= 1, "pb_loglike: bad shape");
+    if (nwalkers == 0)
+        return PB_OK;
+    PB_REQUIRE(loglike_d && bandflux_d && data_d && uncert_d, "pb_loglike: null pointer");
+    k_loglike<<<nwalkers, 64, 0, pb::as_stream(stream)>>>(loglike_d, bandflux_d, data_d, uncert_d,
+                                                         nbands);
     PB_LAUNCH_CHECK();
     return PB_OK;
 }

@@ -327,6 +327,16 @@ def emission_flux(depth, ideep, wn, temp, mu, weights, rtop, want_intensity=Fals
     return (flux, inten) if want_intensity else flux
 
 
+def loglike(bandflux, data, uncert):
+    """tools/retrieval_tools.py:98-104 for a batch of walkers: bandflux[nw, nbands] (or
+    [nbands]) -> loglike[nw]; non-finite values become -inf like the reference's reject."""
+    bf = bandflux if bandflux.dim() == 2 else bandflux.view(1, -1)
+    out = torch.empty(bf.shape[0], dtype=torch.float64, device=bf.device)
+    call('pb_loglike', _ptr(out), _ptr(bf.contiguous()), _ptr(data), _ptr(uncert), bf.shape[0],
+         bf.shape[1], _stream())
+    return out
+
+
 def internal_flux(wn, tint):
     """f_int of pyrat/spectrum.py:475-478 (Planck at tint scaled to sigma*tint^4)."""
     out = torch.empty(wn.shape[0], dtype=torch.float64, device=wn.device)

@@ -185,3 +185,22 @@ def test_interp_ec_golden(eng, golden):
     m = torch.zeros((nmol, nlayers, nwave), dtype=torch.float64, device='cuda')
     eng.interp_ec(m, et, tt, te, de, 0, nlayers + 3, per_mol=True)
     np.testing.assert_allclose(host(m), g['per_mol'], rtol=RTOL)
+
+
+def test_loglike_matches_reference_formula(eng):
+    """retrieval_tools.py:98-104 on a batch of walkers, including a rejected one."""
+    rng = np.random.default_rng(5)
+    nw, nb = 7, 133
+    model = rng.uniform(1e-3, 2e-3, (nw, nb))
+    data = rng.uniform(1e-3, 2e-3, nb)
+    uncert = rng.uniform(1e-5, 5e-5, nb)
+    model[3, 10] = np.inf                                   # eval()'s reject value
+    want = np.array([-0.5 * np.sum(((data - m) / uncert)**2.0)
+                     - 0.5 * np.sum(np.log(2.0 * np.pi * uncert**2.0)) for m in model])
+    want[~np.isfinite(want)] = -np.inf
+    got = eng.loglike(eng.dev(model), eng.dev(data), eng.dev(uncert)).cpu().numpy()
+    assert got[3] == -np.inf
+    ok = np.isfinite(want)
+    np.testing.assert_allclose(got[ok], want[ok], rtol=1e-13)
+    one = eng.loglike(eng.dev(model[0]), eng.dev(data), eng.dev(uncert)).cpu().numpy()
+    assert one.shape == (1,) and one[0] == got[0]
