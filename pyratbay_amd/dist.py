@@ -88,9 +88,11 @@ class SpectrumGather:
         self.send[:self.wcount].copy_(local)
         all_gather_flat(self.recv, self.send, self.group)
         blocks = self.recv.view(self.world, self.pad)
-        for r in range(self.world):
-            n = int(self.bounds[r + 1] - self.bounds[r])
-            self.full[self.bounds[r]:self.bounds[r + 1]].copy_(blocks[r, :n])
+        base, rem = divmod(self.nwave, self.world)          # see shard_bounds
+        if rem:
+            self.full[:rem * (base + 1)].view(rem, base + 1).copy_(blocks[:rem, :base + 1])
+        if base:
+            self.full[rem * (base + 1):].view(self.world - rem, base).copy_(blocks[rem:, :base])
         return self.full
 
 
@@ -117,9 +119,16 @@ def layer_exchange(ec_mine, nlayers, nwave, world, rank, group=None, buffers=Non
         buffers = (torch.zeros((world, lp, wp), dtype=ec_mine.dtype, device=ec_mine.device),
                    torch.empty((world, lp, wp), dtype=ec_mine.dtype, device=ec_mine.device))
     send, recv = buffers
-    for dest in range(world):
-        a, b = int(bounds[dest]), int(bounds[dest + 1])
-        send[dest, :, :b - a].copy_(ec_mine[:, a:b])
+    # balanced shards are `rem` blocks of base+1 columns followed by blocks of `base` columns:
+    # two strided copies pack all destinations (not one small kernel per destination)
+    base, rem = divmod(int(nwave), int(world))
+    if rem:
+        send[:rem, :, :base + 1].copy_(
+            ec_mine.as_strided((rem, lp, base + 1), (base + 1, nwave, 1), ec_mine.storage_offset()))
+    if base:
+        send[rem:, :, :base].copy_(
+            ec_mine.as_strided((world - rem, lp, base), (base, nwave, 1),
+                               ec_mine.storage_offset() + rem * (base + 1)))
     if world > 1:
         all_to_all_flat(recv.view(-1), send.view(-1), group)
     else:
