@@ -819,8 +819,15 @@ __global__ __launch_bounds__(NW * 64, 8) void k_ext_staged(LblArgs a)
             reg[r] = __hiloint2double(v.y, v.x);
         }
     };
-    auto store_row = [&](int buf, auto Rc, const double *reg) {
+    auto store_row = [&](int buf, auto Rc, const double *reg, auto Dc) {
         constexpr int R = decltype(Rc)::value;
+        // The (D-1)*R loads issued after this set stay in flight.  The wait is explicit and
+        // unconditional: left to the conditional stores below, the path that skips them
+        // reaches the loop header with the set still pending and the compiler drains the
+        // whole prefetch queue (vmcnt(0)) at the top of every other segment.
+        constexpr int kInFlight = (decltype(Dc)::value - 1) * R;
+        __builtin_amdgcn_s_waitcnt((kInFlight & 0xf) | (0x7 << 4) | (0xf << 8) |
+                                   ((kInFlight >> 4) << 14));
         double *dst = s_row + kStagePad + buf * rowspan;
 #pragma unroll
         for (int r = 0; r < R; r++) {
@@ -1095,7 +1102,7 @@ __global__ __launch_bounds__(NW * 64, 8) void k_ext_staged(LblArgs a)
 #pragma unroll
                 for (int u = 0; u < S; u++) {
                     const unsigned h = (unsigned)__builtin_amdgcn_readlane((int)hits[u], sg & 63);
-                    if (h < 0x10000u || a.experiment == 2)
+                    if (h < 0x10000u)
                         continue;
                     const int first = (int)(h & 0xffff);
                     const int last = first + (int)(h >> 16);
@@ -1126,8 +1133,6 @@ __global__ __launch_bounds__(NW * 64, 8) void k_ext_staged(LblArgs a)
                         visit(recs[r]);
                 }
             };
-            if (a.experiment == 5)
-                nseg = 0;
             // Software pipeline over the segments.  Segment j lives in register set j % D;
             // its loads are issued D steps before its row is written to LDS buffer j % 2
             // (one step before it is walked).  Every step issues exactly R loads (the
@@ -1136,23 +1141,33 @@ __global__ __launch_bounds__(NW * 64, 8) void k_ext_staged(LblArgs a)
             // constant and the wait before the store is `s_waitcnt vmcnt((D-1)*R)`.
             auto run = [&](auto Dc, auto Rc) {
                 constexpr int D = decltype(Dc)::value, R = decltype(Rc)::value;
-#pragma unroll
-                for (int i = 0; i < D; i++)
-                    load_row(min(i, nseg - 1), Rc, ring + i * R);
-                store_row(0, Rc, ring);
+                static_assert(D == 2, "two register sets, two LDS buffers");
+                load_row(0, Rc, ring);
+                load_row(min(1, nseg - 1), Rc, ring + R);
+                store_row(0, Rc, ring, Dc);
                 __syncthreads();
-                for (int base = 0; base < nseg; base += D) {
-#pragma unroll
-                    for (int i = 0; i < D; i++) {
-                        const int sg = base + i;
-                        if (sg >= nseg)
-                            break;
-                        load_row(min(sg + D, nseg - 1), Rc, ring + i * R);
-                        walk(sg, i & 1);
-                        if (sg + 1 < nseg)
-                            store_row((i + 1) & 1, Rc, ring + ((i + 1) % D) * R);
-                        __syncthreads();
-                    }
+                // Two steps per trip so that register sets and LDS buffers are compile-time
+                // names, and NO exit inside the trip: the structurised CFG routes an exit
+                // through the back edge, which leaves a static path on which the header is
+                // entered with the youngest loads pending -- the compiler then drains the
+                // queue (vmcnt(0)) at the top of every trip.  The last one or two segments
+                // are walked after the loop.
+                int sg = 0;
+                for (; sg + 2 < nseg; sg += 2) {
+                    load_row(sg + 2, Rc, ring);
+                    walk(sg, 0);
+                    store_row(1, Rc, ring + R, Dc);
+                    __syncthreads();
+                    load_row(min(sg + 3, nseg - 1), Rc, ring + R);
+                    walk(sg + 1, 1);
+                    store_row(0, Rc, ring, Dc);
+                    __syncthreads();
+                }
+                walk(sg, 0);
+                if (sg + 1 < nseg) {
+                    store_row(1, Rc, ring + R, std::integral_constant<int, 1>());
+                    __syncthreads();
+                    walk(sg + 1, 1);
                 }
             };
             // (a ring of 4 single-register sets for rows of <= 512 samples was measured:
