@@ -120,7 +120,7 @@ struct LblArgs {
     // [phase p][chunk k][position] = ps*nch_max + k*cnt_p + (g - ps).  1 = no chunking.
     int nch_max;
     // staged kernel, small launches: the phases of a tile are split between nsplit workgroups
-    // (blockIdx.z); split 0 writes ext, the others part[split-1][layer][row][sample]
+    // (see the kernel's block decoding); split 0 writes ext, the others part[split-1][layer][row][sample]
     int nsplit;
     double *part;
     // per (layer, phase-sorted group) records written by k_records [nlayers][ngroups]
@@ -769,8 +769,19 @@ __global__ __launch_bounds__(NW * 64, 8) void k_ext_staged(LblArgs a)
     int *s_cum = s_part + NW;                                            // [vmax+1]
     int *s_phs = s_cum + (vmax + 1);                                     // [vmax]
 
-    int tile, layer;
-    decode_block(a, tile, layer);
+    // Blocks b and b+8 share an XCD.  The unit handed to an XCD is a (layer, phase split)
+    // pair, deepest layer first: the splits of one layer read different phase rows, so
+    // spreading them over the XCDs costs no L2 sharing, and a launch of few layers (a
+    // multi-GPU rank: 10 layers on 8 XCDs) still loads every XCD alike.
+    int tile, layer, zsplit;
+    {
+        const int id = blockIdx.x;
+        const int k = id >> 3;
+        tile = k % a.ntiles;
+        const int unit = (k / a.ntiles) * 8 + (id & 7);
+        layer = a.nlayers - 1 - unit / a.nsplit;       // < 0 for the padding blocks
+        zsplit = unit % a.nsplit;
+    }
     if (layer < 0 || (a.res_cap > 0 && a.ls_resident[layer]))
         return;
     const int row = blockIdx.y;
@@ -873,7 +884,7 @@ __global__ __launch_bounds__(NW * 64, 8) void k_ext_staged(LblArgs a)
         for (int r = 0; r < per; r++) {
             const int pv = tid * per + r;
             const int p = pv / nch, c = pv - p * nch;
-            if (pv < nvirt && a.nsplit > 1 && p * a.nsplit / osamp != (int)blockIdx.z) {
+            if (pv < nvirt && a.nsplit > 1 && p * a.nsplit / osamp != zsplit) {
                 s_phs[pv] = 0;                     // another workgroup's phase
                 s_cum[pv] = 0;
             } else if (pv < nvirt) {
@@ -1177,9 +1188,9 @@ __global__ __launch_bounds__(NW * 64, 8) void k_ext_staged(LblArgs a)
         }
     }
 
-    double *out = blockIdx.z == 0
+    double *out = zsplit == 0
                       ? a.ext
-                      : a.part + (int64_t)(blockIdx.z - 1) * a.nlayers * a.nrows * a.wcount;
+                      : a.part + (int64_t)(zsplit - 1) * a.nlayers * a.nrows * a.wcount;
     double *dst = out + ((int64_t)layer * a.nrows + row) * a.wcount + (t0 - a.wbegin);
 #pragma unroll
     for (int u = 0; u < S; u++) {
@@ -2299,13 +2310,37 @@ int pb_lbl_extinction(pb_lbl *p, double *ext_d, int64_t wbegin, int64_t wcount,
     // Below ~1000 workgroups the chip is not full and the kernel time is the serial chain of
     // one workgroup (~540 segments per tile): the phases of a tile are then split between up
     // to 4 workgroups whose partial sums are added in order by k_combine_parts.
-    const int64_t blocks1 = pb::div_up(wcount, kStagedWaves * kStageSpan) * (int64_t)nlayers;
-    int nsplit = 1;
-    if (blocks1 < 1000)
+    // Tiling of the staged kernel: S sub-tiles of 2048 samples per workgroup and nsplit
+    // workgroups per tile.
+    //  * light tiles (C2: ~8 records per phase row): S = 2 while that leaves >= 750
+    //    workgroups (4 measured slower at every size: 32 accumulators spill at the 64-register
+    //    budget), split in two below 1500 (a 40-layer shard of C2: 0.86 ms unsplit, 0.73 split);
+    //    smaller launches S = 1 and up to 4 splits;
+    //  * heavy tiles (>= 64 groups per phase row and 2048 samples: 1e6 lines on 1e5 samples):
+    //    a workgroup then runs for milliseconds and the launch ends when the slowest one
+    //    does, so aim for ~8000 workgroups (1e6 lines, 80 layers: 8.13 ms unsplit, 7.33 with 4
+    //    splits; a 10-layer rank 2.03 -> 1.83 with 8), the partial sums staying below 1 GB.
+    const int64_t sub = kStagedWaves * kStageSpan;
+    const int64_t blocks1 = pb::div_up(wcount, sub) * (int64_t)nlayers;
+    const int64_t blocks2 = pb::div_up(wcount, 2 * sub) * (int64_t)nlayers;
+    int S = 1, nsplit = 1;
+    if (per_phase >= 64.0) {
+        S = 2;
+        nsplit = (int)std::min<int64_t>(8, pb::div_up((int64_t)8000, blocks2));
+        const int64_t plane = (int64_t)nlayers * a.nrows * wcount * 8;
+        while (nsplit > 1 && (nsplit - 1) * plane > ((int64_t)1 << 30))
+            nsplit--;
+    } else if (blocks2 >= 750) {
+        S = 2;
+        nsplit = blocks2 < 1500 ? 2 : 1;
+    } else if (blocks1 < 1000) {
         nsplit = (int)std::min<int64_t>(4, std::max<int64_t>(1, 2000 / std::max<int64_t>(1, blocks1)));
+    }
+    if (const char *e = getenv("PB_STAGE_S"))
+        S = atoi(e) >= 4 ? 4 : atoi(e) >= 2 ? 2 : 1;
     if (const char *e = getenv("PB_STAGE_SPLIT"))
         nsplit = std::max(1, std::min(8, atoi(e)));
-    const bool enough_blocks = blocks1 * nsplit >= 750;
+    const bool enough_blocks = pb::div_up(wcount, S * sub) * (int64_t)nlayers * nsplit >= 750;
     const bool staged = can_stage && (p->gather_mode == 2 ||
                                       (p->gather_mode == 0 && enough_blocks &&
                                        per_phase >= p->stage_threshold));
@@ -2427,14 +2462,6 @@ int pb_lbl_extinction(pb_lbl *p, double *ext_d, int64_t wbegin, int64_t wcount,
         dim3 grid((unsigned)(8 * a.ntiles * layer_groups), a.nrows);
         k_ext_linterp<<<grid, kBlock, 0, s>>>(a);
     } else if (staged) {
-        // sub-tiles per workgroup: 2 when that still leaves >= 750 workgroups (4 measured
-        // slower at every size: 32 accumulators spill at the 64-register budget)
-        const int64_t sub = kStagedWaves * kStageSpan;
-        int S = pb::div_up(wcount, 2 * sub) * (int64_t)nlayers >= 750 ? 2 : 1;
-        if (S > 1)      // measured on a 40-layer shard of C2: 0.86 ms unsplit, 0.73 ms split in two
-            nsplit = pb::div_up(wcount, 2 * sub) * (int64_t)nlayers < 1500 ? 2 : 1;
-        if (getenv("PB_STAGE_SPLIT"))
-            nsplit = std::max(1, std::min(8, atoi(getenv("PB_STAGE_SPLIT"))));
         a.nsplit = nsplit;
         if (nsplit > 1) {
             const size_t need = (size_t)(nsplit - 1) * nlayers * a.nrows * wcount * 8;
@@ -2450,10 +2477,9 @@ int pb_lbl_extinction(pb_lbl *p, double *ext_d, int64_t wbegin, int64_t wcount,
             }
             a.part = p->part;
         }
-        if (const char *e = getenv("PB_STAGE_S"))
-            S = atoi(e) >= 4 ? 4 : atoi(e) >= 2 ? 2 : 1;
         a.ntiles = pb::div_up(wcount, S * sub);
-        dim3 grid((unsigned)(8 * a.ntiles * layer_groups), a.nrows, (unsigned)nsplit);
+        const int unit_groups = (nlayers * nsplit + 7) / 8;     // (layer, split) units per XCD
+        dim3 grid((unsigned)(8 * a.ntiles * unit_groups), a.nrows);
         void (*kern)(LblArgs) = S == 4   ? k_ext_staged<kStagedWaves, 4>
                                 : S == 2 ? k_ext_staged<kStagedWaves, 2>
                                          : k_ext_staged<kStagedWaves, 1>;
