@@ -2303,38 +2303,30 @@ int pb_lbl_extinction(pb_lbl *p, double *ext_d, int64_t wbegin, int64_t wcount,
                            (a.nch_max == 1 ||
                             (a.nch_max <= 16 && packable && rec16_bytes <= ((size_t)96 << 30) &&
                              !getenv("PB_NO_LONG_ROWS")));
-    // the staged kernel needs enough workgroups to hide its per-segment latency; small
-    // launches (multi-GPU shards) go to the global gather with record splitting.  Measured
-    // on layer shards of C2 (tools/bench_rank.py): 40 and 20 layers staged 0.85 / 0.65 ms vs
-    // global 1.20 / 0.73; 10 layers 0.55 vs 0.53.
-    // Below ~1000 workgroups the chip is not full and the kernel time is the serial chain of
-    // one workgroup (~540 segments per tile): the phases of a tile are then split between up
-    // to 4 workgroups whose partial sums are added in order by k_combine_parts.
-    // Tiling of the staged kernel: S sub-tiles of 2048 samples per workgroup and nsplit
-    // workgroups per tile.
-    //  * light tiles (C2: ~8 records per phase row): S = 2 while that leaves >= 750
-    //    workgroups (4 measured slower at every size: 32 accumulators spill at the 64-register
-    //    budget), split in two below 1500 (a 40-layer shard of C2: 0.86 ms unsplit, 0.73 split);
-    //    smaller launches S = 1 and up to 4 splits;
-    //  * heavy tiles (>= 64 groups per phase row and 2048 samples: 1e6 lines on 1e5 samples):
-    //    a workgroup then runs for milliseconds and the launch ends when the slowest one
-    //    does, so aim for ~8000 workgroups (1e6 lines, 80 layers: 8.13 ms unsplit, 7.33 with 4
-    //    splits; a 10-layer rank 2.03 -> 1.83 with 8), the partial sums staying below 1 GB.
+    // the staged kernel needs enough workgroups to hide its per-segment latency; launches that
+    // stay below 750 even when split eight ways go to the global gather with record splitting.
+    // Tiling of the staged kernel: S = 2 sub-tiles of 2048 samples per workgroup (1 measured
+    // slower at every launch size once the splits are spread over the XCDs; 4 spills: 32
+    // accumulators at the 64-register budget) and nsplit workgroups per tile, each with its
+    // share of the phases.  A launch ends when its slowest workgroup does, so small launches
+    // and launches of long-running workgroups are split further:
+    //  * light tiles (C2: ~8 records per phase row): aim for ~2000 workgroups.  Layer shards
+    //    of C2 (tools/sweep_split.sh): 40 layers 0.70 ms unsplit / 0.65 in two; 20 layers
+    //    0.40 in two / 0.37 in four; 10 layers 0.23 in four or eight; all 80 layers 1.19
+    //    unsplit / 1.20 in two.
+    //  * heavy tiles (>= 64 groups per phase row and 2048 samples: 1e6 lines on 1e5 samples;
+    //    a workgroup then runs for milliseconds): aim for ~8000.  1e6 lines, 80 layers:
+    //    8.13 ms unsplit, 7.33 in four; a 10-layer shard 2.03 -> 1.13 in eight.
+    // The partial sums stay below 1 GB.
     const int64_t sub = kStagedWaves * kStageSpan;
-    const int64_t blocks1 = pb::div_up(wcount, sub) * (int64_t)nlayers;
     const int64_t blocks2 = pb::div_up(wcount, 2 * sub) * (int64_t)nlayers;
-    int S = 1, nsplit = 1;
-    if (per_phase >= 64.0) {
-        S = 2;
-        nsplit = (int)std::min<int64_t>(8, pb::div_up((int64_t)8000, blocks2));
+    int S = 2;
+    int nsplit = (int)std::min<int64_t>(
+        8, pb::div_up((int64_t)(per_phase >= 64.0 ? 8000 : 2000), std::max<int64_t>(1, blocks2)));
+    {
         const int64_t plane = (int64_t)nlayers * a.nrows * wcount * 8;
         while (nsplit > 1 && (nsplit - 1) * plane > ((int64_t)1 << 30))
             nsplit--;
-    } else if (blocks2 >= 750) {
-        S = 2;
-        nsplit = blocks2 < 1500 ? 2 : 1;
-    } else if (blocks1 < 1000) {
-        nsplit = (int)std::min<int64_t>(4, std::max<int64_t>(1, 2000 / std::max<int64_t>(1, blocks1)));
     }
     if (const char *e = getenv("PB_STAGE_S"))
         S = atoi(e) >= 4 ? 4 : atoi(e) >= 2 ? 2 : 1;
