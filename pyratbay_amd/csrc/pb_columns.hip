@@ -64,8 +64,13 @@ __global__ void k_optdepth(double *tau, const double *data, int64_t row_stride,
 // transmission spectrum exp(-tau)*r over the rows down to ideep
 // (radiative_transfer.py:57-71) in the same pass.
 // ---------------------------------------------------------------------------
-constexpr int kRowsPerThread = 16;
+constexpr int kRowsPerThread = 16;     // 32 and 40 measured slower at W = 1e5
+// Narrow grids (a wavenumber shard of a multi-GPU run: 12 500 columns) do not fill the chip
+// with one thread per (column, 16 rows): they take 4 rows per thread and 64-thread workgroups.
+constexpr int kRowsPerThreadNarrow = 4;
+constexpr int kNarrowColumns = 32768;
 
+template <int kRows>
 __global__ __launch_bounds__(kBlock) void k_transit_tau(double *depth, const double *ec,
                                                         const double *raypath, int itop,
                                                         int ibottom, int nlayers, int nwave)
@@ -73,23 +78,23 @@ __global__ __launch_bounds__(kBlock) void k_transit_tau(double *depth, const dou
     // ray-path segments of this block's rows, [segment i][row k], zero where i >= r:
     // adding 0 * s leaves a sum unchanged, so one predicate-free loop serves all rows
     extern __shared__ __align__(16) double s_path[];
-    const int col = blockIdx.x * kBlock + threadIdx.x;
+    const int col = blockIdx.x * blockDim.x + threadIdx.x;
     const int nrow = nlayers - itop;
     const int nimpact = min(ibottom, nlayers) - itop;     // rows 0..nimpact-1 are evaluated
-    const int rb = blockIdx.y * kRowsPerThread;
-    const int rlast = min(rb + kRowsPerThread, nimpact) - 1;       // last evaluated row here
+    const int rb = blockIdx.y * kRows;
+    const int rlast = min(rb + kRows, nimpact) - 1;       // last evaluated row here
     const int nseg = max(rlast, 0);                                 // segments i < rlast
-    for (int e = threadIdx.x; e < nseg * kRowsPerThread; e += kBlock) {
-        const int i = e / kRowsPerThread, k = e % kRowsPerThread;
+    for (int e = threadIdx.x; e < nseg * kRows; e += blockDim.x) {
+        const int i = e / kRows, k = e % kRows;
         const int r = rb + k;
         s_path[e] = (r <= rlast && i < r) ? raypath[(r * (r - 1)) / 2 + i] : 0.0;
     }
     __syncthreads();
     if (col >= nwave)
         return;
-    double tau[kRowsPerThread];
+    double tau[kRows];
 #pragma unroll
-    for (int k = 0; k < kRowsPerThread; k++)
+    for (int k = 0; k < kRows; k++)
         tau[k] = 0.0;
     if (nseg > 0) {
         const double *src = ec + (int64_t)itop * nwave + col;
@@ -99,14 +104,14 @@ __global__ __launch_bounds__(kBlock) void k_transit_tau(double *depth, const dou
             const double next = src[(int64_t)(i + 1) * nwave];
             const double s = next + prev;
             prev = next;
-            const double *pk = s_path + i * kRowsPerThread;          // LDS broadcast reads
+            const double *pk = s_path + i * kRows;          // LDS broadcast reads
 #pragma unroll
-            for (int k = 0; k < kRowsPerThread; k++)
+            for (int k = 0; k < kRows; k++)
                 tau[k] += pk[k] * s;
         }
     }
 #pragma unroll
-    for (int k = 0; k < kRowsPerThread; k++) {
+    for (int k = 0; k < kRows; k++) {
         const int r = rb + k;
         if (r < nrow)
             depth[(int64_t)(itop + r) * nwave + col] = tau[k];     // 0 for r >= nimpact
@@ -130,7 +135,7 @@ __global__ __launch_bounds__(kBlock) void k_transit_finish(
     double *depth, int32_t *ideep, double *spectrum, const double *radius, double rstar,
     int itop, int ibottom, double maxdepth, int nlayers, int nwave, int deck_row, double rsurf)
 {
-    const int col = blockIdx.x * kBlock + threadIdx.x;
+    const int col = blockIdx.x * blockDim.x + threadIdx.x;
     if (col >= nwave)
         return;
     const int nimpact = min(ibottom, nlayers) - itop;
@@ -659,18 +664,25 @@ static int transit_launch(double *depth_d, int32_t *ideep_d, double *spectrum_d,
     const int nrow = nlayers - itop;
     PB_REQUIRE(nrow == 1 || raypath_d, "%s: null raypath", who);
     PB_REQUIRE(!spectrum_d || radius_d, "%s: null radius", who);
-    dim3 grid(pb::div_up(nwave, kBlock), pb::div_up(nrow, kRowsPerThread));
-    const size_t lds = (size_t)nrow * kRowsPerThread * sizeof(double);
+    const bool narrow = nwave <= kNarrowColumns;
+    const int rows = narrow ? kRowsPerThreadNarrow : kRowsPerThread;
+    const int threads = narrow ? 64 : kBlock;
+    dim3 grid(pb::div_up(nwave, threads), pb::div_up(nrow, rows));
+    const size_t lds = (size_t)nrow * rows * sizeof(double);
     if (lds > 64 * 1024) {
         pb::set_error("%s: %d layers need %zu B of LDS", who, nrow, lds);
         return PB_ERR_UNSUPPORTED;
     }
-    k_transit_tau<<<grid, kBlock, lds, pb::as_stream(stream)>>>(depth_d, ec_d, raypath_d, itop,
-                                                              ibottom, nlayers, nwave);
+    if (narrow)
+        k_transit_tau<kRowsPerThreadNarrow><<<grid, threads, lds, pb::as_stream(stream)>>>(
+            depth_d, ec_d, raypath_d, itop, ibottom, nlayers, nwave);
+    else
+        k_transit_tau<kRowsPerThread><<<grid, threads, lds, pb::as_stream(stream)>>>(
+            depth_d, ec_d, raypath_d, itop, ibottom, nlayers, nwave);
     PB_LAUNCH_CHECK();
     // radiative_transfer.py:63: the deck matters only when it lies below the top layer
     const int deck_row = deck_itop > itop ? deck_itop - itop : -1;
-    k_transit_finish<<<pb::div_up(nwave, kBlock), kBlock, 0, pb::as_stream(stream)>>>(
+    k_transit_finish<<<pb::div_up(nwave, threads), threads, 0, pb::as_stream(stream)>>>(
         depth_d, ideep_d, spectrum_d, radius_d, rstar, itop, ibottom, maxdepth, nlayers,
         nwave, deck_row, deck_rsurf);
     PB_LAUNCH_CHECK();

@@ -36,8 +36,20 @@ for rank in (0, world - 1):
         torch.cuda.synchronize()
         t += [ev[0].elapsed_time(ev[1]), ev[1].elapsed_time(ev[2])]
     t /= 10
-    res.append((rank, n, t[0], t[1], m.lbl.last_gather_kernel))
+    # wall clock of back-to-back steps (host enqueue included), and of the enqueue alone
+    import time
+    torch.cuda.synchronize()
+    w0 = time.perf_counter()
+    for _ in range(50):
+        m.lbl.extinction(sh.temp, sh.dens, sh.isoz, add=True, out=sh.ec[:n])
+        engine.transit_spectrum(ec_cols, m.raypath, m.radius, m.rstar, 0, sh.nlayers, 10.0)
+    w1 = time.perf_counter()
+    torch.cuda.synchronize()
+    w2 = time.perf_counter()
+    res.append((rank, n, t[0], t[1], m.lbl.last_gather_kernel, (w2 - w0) / 50 * 1e3,
+                (w1 - w0) / 50 * 1e3))
     del sh
 for r in res:
     print(f'world {world} rank {r[0]}: {r[1]} layers  extinction {r[2]:.3f} ms  '
-          f'depth+spectrum on W/{world} {r[3]:.3f} ms  [{r[4]}]')
+          f'depth+spectrum on W/{world} {r[3]:.3f} ms  [{r[4]}]  '
+          f'wall {r[5]:.3f} ms/step (host enqueue {r[6]:.3f})')
