@@ -739,7 +739,7 @@ constexpr int kStageRowMax = 1024;   // longest phase row the kernel stages
 
 // NW wavefronts per workgroup, S sub-tiles of NW*256 samples each (tile = S*NW*256); one
 // record per thread per batch.
-template <int NW, int S>
+template <int NW, int S, bool kDma>
 __global__ __launch_bounds__(NW * 64, 8) void k_ext_staged(LblArgs a)
 {
     constexpr int kThreads = NW * 64;
@@ -757,7 +757,8 @@ __global__ __launch_bounds__(NW * 64, 8) void k_ext_staged(LblArgs a)
         unsigned win;             // lo | hi << 16 (tile coordinates)
     };
     const int rowspan = a.rowlds + kStagePad;                            // buffer pitch
-    Rec *s_rec = reinterpret_cast<Rec *>(s_row + 2 * rowspan + kStagePad);   // [kThreads]
+    constexpr int kNB = 2;                        // row buffers
+    Rec *s_rec = reinterpret_cast<Rec *>(s_row + kNB * rowspan + kStagePad);   // [kThreads]
     long long *s_src = reinterpret_cast<long long *>(s_rec + kThreads);  // row start, -1 empty
     unsigned long long *s_desc = reinterpret_cast<unsigned long long *>(s_src);   // per segment
     unsigned long long *s_segmask =
@@ -802,16 +803,58 @@ __global__ __launch_bounds__(NW * 64, 8) void k_ext_staged(LblArgs a)
 #pragma unroll
     for (int u = 0; u < S; u++)
         acc[u][0] = acc[u][1] = acc[u][2] = acc[u][3] = 0.0;
-    for (int i = tid; i < 2 * rowspan + kStagePad; i += kThreads)
+    for (int i = tid; i < kNB * rowspan + kStagePad; i += kThreads)
         s_row[i] = 0.0;                            // the pads stay zero for good
 
     // Row of one segment -> registers (issued early), registers -> LDS (after the walk).
     // The registers form a ring of D sets of R doubles per lane (D*R = 2*kRowRegs): rows
     // that fit one register per lane (<= kThreads samples) are fetched 4 segments ahead.
-    double ring[2 * kRowRegs];
+    double ring[kDma ? 1 : 2 * kRowRegs];
     // Rows of this (layer, isotope) are at most `rowlim` samples long: wavefronts whose
     // lanes lie beyond it do not store (the buffers are zeroed per isotope).
     int rowlim = a.rowlds;
+    // kDma: the row of a segment goes global -> LDS directly (`buffer_load_dwordx4 ... lds`,
+    // 1 KiB = 128 samples per wave-instruction), issued by ONE wavefront per segment (the
+    // wavefronts take turns), one step ahead of the walk.  No row registers, no LDS stores
+    // and one descriptor chain per workgroup and segment instead of eight.  Lanes outside
+    // the window read 0 through the buffer range check (checked per dword at the upper end;
+    // a lane below the window is out of range as a whole, so the LDS image is shifted by the
+    // parity e of the window start -- row sample m sits at position m - e, which the
+    // records' offsets account for -- and no lane straddles the lower edge).  The
+    // instruction is issued from inline asm: the compiler would otherwise drain it
+    // (vmcnt(0)) before the next LDS read; the wait before the barrier is explicit.
+    auto dma_row = [&](int sg, int buf) {
+        const unsigned long long d = s_desc[sg];
+        const unsigned dlo = (unsigned)__builtin_amdgcn_readfirstlane((int)d);
+        const unsigned dhi = (unsigned)__builtin_amdgcn_readfirstlane((int)(d >> 32));
+        const long long first = ((long long)(dhi & 0xffu) << 32) | dlo;
+        const int len = (int)((dhi >> 8) & 0xfffu), mlo = (int)(dhi >> 20);
+        const unsigned long long base = (unsigned long long)(a.pm + first);
+        typedef int v4i __attribute__((ext_vector_type(4)));
+        v4i rsrc;
+        rsrc.x = __builtin_amdgcn_readfirstlane((int)base);
+        rsrc.y = __builtin_amdgcn_readfirstlane((int)((base >> 32) & 0xffffu));
+        rsrc.z = __builtin_amdgcn_readfirstlane(len * 8);
+        rsrc.w = 0x00020000;
+        int voff = (2 * lane - (mlo & ~1)) * 8;
+        unsigned dst = (unsigned)(size_t)(__attribute__((address_space(3))) char *)(
+            reinterpret_cast<char *>(s_row + kStagePad + buf * rowspan));
+        dst = (unsigned)__builtin_amdgcn_readfirstlane((int)dst);
+        for (int c = 0; c * 128 < rowlim; c++) {
+            unsigned keep;
+            asm volatile("s_nop 4\n\t"
+                         "s_mov_b32 %0, m0\n\t"
+                         "s_mov_b32 m0, %1\n\t"
+                         "s_nop 0\n\t"
+                         "buffer_load_dwordx4 %2, %3, 0 offen lds\n\t"
+                         "s_mov_b32 m0, %0"
+                         : "=&s"(keep)
+                         : "s"(dst), "v"(voff), "s"(rsrc)
+                         : "memory");
+            voff += 1024;
+            dst += 1024;
+        }
+    };
     // out-of-window lanes fall outside the buffer descriptor and read 0 (no predicate)
     auto load_row = [&](int sg, auto Rc, double *reg) {
         constexpr int R = decltype(Rc)::value;
@@ -868,7 +911,7 @@ __global__ __launch_bounds__(NW * 64, 8) void k_ext_staged(LblArgs a)
         {
             const int lim = min(a.rowlds, a.li_rowmax[li]);
             if (lim != rowlim) {                   // wave-uniform
-                for (int i = tid; i < 2 * rowspan + kStagePad; i += kThreads)
+                for (int i = tid; i < kNB * rowspan + kStagePad; i += kThreads)
                     s_row[i] = 0.0;
                 rowlim = lim;
             }
@@ -1006,6 +1049,8 @@ __global__ __launch_bounds__(NW * 64, 8) void k_ext_staged(LblArgs a)
                             k *= dens;
                         win = (unsigned)lo | ((unsigned)hi << 16);
                         qoff = (int)(q + t0) * 8;       // tile sample j reads row[j + q + t0]
+                        if (kDma)
+                            qoff -= ((ulo + q) & 1) * 8;  // the image starts at an even sample
                         src = a.pm_base[cell] + (long long)phi * a.pm_stride[cell] + c0;
                         mwin = (unsigned)(ulo + q) | ((unsigned)(uhi + q) << 16);
                     } else {
@@ -1183,8 +1228,25 @@ __global__ __launch_bounds__(NW * 64, 8) void k_ext_staged(LblArgs a)
             };
             // (a ring of 4 single-register sets for rows of <= 512 samples was measured:
             // it spills at the 64-VGPR budget of 8 waves/SIMD and runs 30 % slower)
-            if (nseg > 0)
+            if (kDma) {
+                // the row of segment sg+1 is requested by one wavefront (they take turns)
+                // while sg is walked, and has landed before the barrier that ends the step.
+                // (Three buffers and a request two steps ahead measured slower, 1.22 vs 1.14 ms
+                // at C2: 48 KB of LDS leave three workgroups per CU.)
+                if (wave == 0)
+                    dma_row(0, 0);
+                __builtin_amdgcn_s_waitcnt(0x0f70);           // vmcnt(0)
+                __syncthreads();
+                for (int sg = 0; sg < nseg; sg++) {
+                    if (sg + 1 < nseg && wave == ((sg + 1) & (NW - 1)))
+                        dma_row(sg + 1, (sg + 1) & 1);
+                    walk(sg, sg & 1);
+                    __builtin_amdgcn_s_waitcnt(0x0f70);       // the row of sg+1 has landed
+                    __syncthreads();
+                }
+            } else if (nseg > 0) {
                 run(std::integral_constant<int, 2>(), std::integral_constant<int, kRowRegs>());
+            }
         }
     }
 
@@ -2291,9 +2353,12 @@ int pb_lbl_extinction(pb_lbl *p, double *ext_d, int64_t wbegin, int64_t wcount,
     // phases and k_records writes one packed record per (group, chunk)
     const int nch_max = (int)pb::div_up((int64_t)a.rowcap, (int64_t)kChunkRow);
     a.nch_max = std::max(1, nch_max);
-    a.rowlds = std::min(a.rowcap, kStageRowMax);
+    a.rowlds = (std::min(a.rowcap, kStageRowMax) + 1) & ~1;     // even: 16-byte aligned buffers
     const size_t lds_fixed = (size_t)kStagedThreads * (16 + 8 + 4 + 4) + kStagedWaves * 12 +
                              (size_t)(2 * v->osamp * a.nch_max + 1) * 4 + 64;
+    bool dma = true;                     // rows by LDS-DMA (k_ext_staged); PB_STAGE_DMA=0: via registers
+    if (const char *e = getenv("PB_STAGE_DMA"))
+        dma = atoi(e) != 0;
     const size_t lds = (2 * ((size_t)a.rowlds + kStagePad) + kStagePad) * 8 + lds_fixed;
     const double per_phase = (double)l->ngroups / std::max(1, p->nwave) * 2048.0 / v->osamp;
     const bool packable = v->nlor * v->ndop < (1 << 20);
@@ -2472,9 +2537,13 @@ int pb_lbl_extinction(pb_lbl *p, double *ext_d, int64_t wbegin, int64_t wcount,
         a.ntiles = pb::div_up(wcount, S * sub);
         const int unit_groups = (nlayers * nsplit + 7) / 8;     // (layer, split) units per XCD
         dim3 grid((unsigned)(8 * a.ntiles * unit_groups), a.nrows);
-        void (*kern)(LblArgs) = S == 4   ? k_ext_staged<kStagedWaves, 4>
-                                : S == 2 ? k_ext_staged<kStagedWaves, 2>
-                                         : k_ext_staged<kStagedWaves, 1>;
+        void (*kern)(LblArgs) =
+            dma ? (S == 4   ? k_ext_staged<kStagedWaves, 4, true>
+                   : S == 2 ? k_ext_staged<kStagedWaves, 2, true>
+                            : k_ext_staged<kStagedWaves, 1, true>)
+                : (S == 4   ? k_ext_staged<kStagedWaves, 4, false>
+                   : S == 2 ? k_ext_staged<kStagedWaves, 2, false>
+                            : k_ext_staged<kStagedWaves, 1, false>);
         if (lds > 64 * 1024)
             PB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
