@@ -240,3 +240,39 @@ def test_long_rows_vs_oracle(eng, orc, gather):
         parts = [host(lbl.extinction(t, d, z, wbegin=a, wcount=b - a))
                  for a, b in ((0, 1500), (1500, 4097))]
         assert np.array_equal(np.concatenate(parts, axis=2), ext)
+
+
+def test_staged_variants_agree(eng, monkeypatch):
+    """The staged kernel's row staging (LDS-DMA, or through registers with PB_STAGE_DMA=0) and
+    its tiling (PB_STAGE_S, PB_STAGE_SPLIT) are performance choices: the two staging forms
+    give the same bits, and splitting the phases of a tile between workgroups changes only the
+    association of the per-sample sums."""
+    from pyratbay_amd import synth
+    case = synth.lbl_case(9001, 6, 60000, wnosamp=24, nlor=18, ndop=9, extent=80.0,
+                          cutoff=3.0, niso=2, seed=77)
+    g, atm, ln, iso, vg = (case[k] for k in ('grid', 'atm', 'lines', 'iso', 'voigt'))
+    vt = eng.VoigtTable.build(vg['lorentz'], vg['doppler'], vg['size'], g['ownstep'], 24)
+    ll = eng.LineList(ln['lwn'], ln['elow'], ln['gf'], ln['lid'], 2, g['own'])
+    lbl = eng.LBL(vt, ll, g['wn'], g['divisors'], atm['mol_radius'], atm['mol_mass'],
+                  iso['isoimol'], iso['isomass'], iso['isoratio'], iso['isoiext'],
+                  vg['cutoff'], 1e-30, max_layers=6)
+    lbl.set_gather_mode('staged')
+    t, d, z = eng.dev(atm['temp']), eng.dev(atm['dens']), eng.dev(iso['isoz'])
+
+    def run(**env):
+        for k, v in env.items():
+            monkeypatch.setenv(k, str(v))
+        out = host(lbl.extinction(t, d, z, add=True))
+        assert lbl.last_gather_kernel == 'k_ext_staged'
+        for k in env:
+            monkeypatch.delenv(k)
+        return out
+
+    base = run(PB_STAGE_S=2, PB_STAGE_SPLIT=1)
+    assert np.array_equal(run(PB_STAGE_S=2, PB_STAGE_SPLIT=1, PB_STAGE_DMA=0), base)
+    assert np.array_equal(run(PB_STAGE_S=1, PB_STAGE_SPLIT=1), base)
+    for split in (2, 3, 4, 8):
+        for dma in (0, 1):
+            got = run(PB_STAGE_S=2, PB_STAGE_SPLIT=split, PB_STAGE_DMA=dma)
+            assert np.array_equal(got == 0, base == 0)
+            np.testing.assert_allclose(got, base, rtol=1e-13)
