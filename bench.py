@@ -195,15 +195,29 @@ def main():
     torch.cuda.synchronize()
     t_init = time.perf_counter() - t0
 
-    for _ in range(args.warmup):
-        step()
+    # N > 1, layer-sharded: consecutive spectra are software-pipelined (the all-to-all and the
+    # all-gather of spectrum i run beside the extinction of spectrum i+1; every spectrum of
+    # the timed region is complete before its closing synchronisation).  PB_PIPELINE=0: one
+    # spectrum at a time.
+    pipelined = layer_mode and os.environ.get('PB_PIPELINE', '1') != '0'
+
+    def run_steps(k):
+        if pipelined:
+            for _ in range(k):
+                sharded.submit()
+            return sharded.flush()
+        out = None
+        for _ in range(k):
+            out = step()
+        return [out]
+
+    run_steps(args.warmup)
     model.lbl.timing_begin(args.steps)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
+    run_steps(args.steps)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -214,7 +228,8 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     if os.environ.get('PB_DUMP_SPECTRUM'):
-        np.save(f"{os.environ['PB_DUMP_SPECTRUM']}.rank{rank}.npy", step().cpu().numpy())
+        np.save(f"{os.environ['PB_DUMP_SPECTRUM']}.rank{rank}.npy",
+                run_steps(3)[-1].cpu().numpy())
 
     if rank == 0:
         ms_per_step = 1e3 * elapsed / args.steps
@@ -246,7 +261,9 @@ def main():
                        'voigt_table_bytes': int(model.voigt.device_bytes),
                        'parallelism': ('single GPU' if world == 1 else
                                        f'layer-sharded extinction x{world} + all-to-all + '
-                                       'wavenumber-sharded RT + all-gather' if layer_mode
+                                       'wavenumber-sharded RT + all-gather' +
+                                       (', consecutive spectra pipelined' if pipelined else '')
+                                       if layer_mode
                                        else f'wavenumber shards x{world} + all-gather'),
                        'init_seconds': round(t_init, 3)},
             'roofline': {'bound': 'hbm', 'kernel': dominant_kernel(model.lbl, nlayers_rank),

@@ -51,6 +51,35 @@ def all_to_all_flat(recv, send, group=None):
         dist.all_to_all_single(recv, send, group=group)
 
 
+class _Done:
+    """Stand-in for a collective that has already completed (host-staged rehearsal)."""
+
+    def wait(self):
+        return True
+
+
+def all_gather_flat_async(recv, send, group=None):
+    """Start the all-gather and return its Work: the collective runs on the process group's
+    own stream, the caller's stream goes on and meets it again at `work.wait()`."""
+    if not dist.is_initialized():
+        recv.copy_(send.repeat(recv.numel() // send.numel()))
+        return _Done()
+    if _via_host(group) and send.is_cuda:
+        all_gather_flat(recv, send, group)
+        return _Done()
+    return dist.all_gather_into_tensor(recv, send, group=group, async_op=True)
+
+
+def all_to_all_flat_async(recv, send, group=None):
+    if not dist.is_initialized():                  # single process: the exchange is a copy
+        recv.copy_(send)
+        return _Done()
+    if _via_host(group) and send.is_cuda:
+        all_to_all_flat(recv, send, group)
+        return _Done()
+    return dist.all_to_all_single(recv, send, group=group, async_op=True)
+
+
 def shard_bounds(nwave, world):
     """Contiguous, balanced shards: rank r owns [b[r], b[r+1])."""
     base, rem = divmod(int(nwave), int(world))
@@ -174,6 +203,122 @@ class LayerShardedTransit:
         spec, self.depth, self.ideep = e.transit_spectrum(
             ec_cols, m.raypath, m.radius, m.rstar, m.itop, self.nlayers, m.maxdepth)
         return self.gather(spec)
+
+    # -- the same step, software-pipelined over consecutive spectra (ExchangePipeline) ------
+    def _produce(self, ec_mine):
+        n = len(self.layers)
+        if n:
+            self.model.lbl.extinction(self.temp, self.dens, self.isoz, add=True, out=self.ec[:n])
+
+    def _consume(self, ec_cols):
+        m = self.model
+        spec, self.depth, self.ideep = self.engine.transit_spectrum(
+            ec_cols, m.raypath, m.radius, m.rstar, m.itop, self.nlayers, m.maxdepth)
+        return spec
+
+    def _pipeline(self):
+        if getattr(self, '_pipe', None) is None:
+            self._pipe = ExchangePipeline(self.ec.view(self.lp, self.nwave), self.nlayers,
+                                          self.world, self.rank, self._produce, self._consume,
+                                          self.group)
+        return self._pipe
+
+    def submit(self):
+        """Enqueue one more spectrum; returns the one submitted two calls ago (or None)."""
+        return self._pipeline().submit()
+
+    def flush(self):
+        """Complete the spectra still in flight and return them in order."""
+        return self._pipeline().flush() if getattr(self, '_pipe', None) is not None else []
+
+
+class ExchangePipeline:
+    """produce -> all-to-all -> consume -> all-gather, software-pipelined over consecutive
+    spectra.
+
+    `produce(ec_mine)` fills ec_mine[lp, nwave] (this rank's layers r, r+N, ... over all
+    columns) in place; `consume(ec_cols)` maps ec_cols[nlayers, wcount] (all layers, this
+    rank's columns) to this rank's part of the spectrum, spec[wcount].  submit(i) enqueues,
+    in this order on the caller's stream:
+      A(i)   produce, pack, START all-to-all i                    (the collective's stream)
+      B(i-1) wait all-to-all i-1, consume, START all-gather i-1
+      C(i-2) wait all-gather i-2, unpack -> full spectrum i-2 (returned)
+    so both collectives of a spectrum run beside the production of the next one.  Every
+    rank issues the collectives in the same order (a2a i, ag i-1, a2a i+1, ...).  Buffers are
+    double: a collective works on set i % 2 while set (i+1) % 2 is packed or consumed; set
+    i % 2 is next touched by A(i+2) / B(i+2), enqueued after B(i) / C(i) on the caller's
+    stream, which the collective's stream waits for when the collective is issued."""
+
+    def __init__(self, ec_mine, nlayers, world, rank, produce, consume, group=None):
+        self.ec, self.nlayers, self.world, self.rank = ec_mine, int(nlayers), world, rank
+        self.produce, self.consume, self.group = produce, consume, group
+        self.lp, self.nwave = ec_mine.shape
+        assert self.lp == -(-self.nlayers // world)
+        self.bounds = shard_bounds(self.nwave, world)
+        self.wcount = int(self.bounds[rank + 1] - self.bounds[rank])
+        wp = self.pad = int(np.max(np.diff(self.bounds)))
+        kw = dict(dtype=ec_mine.dtype, device=ec_mine.device)
+        self.send = [torch.zeros((world, self.lp, wp), **kw) for _ in range(2)]
+        self.recv = [torch.zeros((world, self.lp, wp), **kw) for _ in range(2)]
+        self.gsend = [torch.zeros(wp, **kw) for _ in range(2)]
+        self.grecv = [torch.zeros(world * wp, **kw) for _ in range(2)]
+        self.full = [torch.empty(self.nwave, **kw) for _ in range(2)]
+        self.a2a, self.ag = [None, None], [None, None]
+        self.count = 0
+
+    def _stage_a(self, i):
+        self.produce(self.ec)
+        send, ec = self.send[i % 2], self.ec
+        base, rem = divmod(self.nwave, self.world)
+        if rem:
+            send[:rem, :, :base + 1].copy_(
+                ec.as_strided((rem, self.lp, base + 1), (base + 1, self.nwave, 1),
+                              ec.storage_offset()))
+        if base:
+            send[rem:, :, :base].copy_(
+                ec.as_strided((self.world - rem, self.lp, base), (base, self.nwave, 1),
+                              ec.storage_offset() + rem * (base + 1)))
+        self.a2a[i % 2] = all_to_all_flat_async(self.recv[i % 2].view(-1), send.view(-1),
+                                                self.group)
+
+    def _stage_b(self, i):
+        self.a2a[i % 2].wait()
+        # recv[src, j, :] is layer src + world*j
+        ec_cols = self.recv[i % 2].permute(1, 0, 2).reshape(self.lp * self.world, self.pad)
+        spec = self.consume(ec_cols[:self.nlayers, :self.wcount].contiguous())
+        self.gsend[i % 2][:self.wcount].copy_(spec)
+        self.ag[i % 2] = all_gather_flat_async(self.grecv[i % 2], self.gsend[i % 2], self.group)
+
+    def _stage_c(self, i):
+        self.ag[i % 2].wait()
+        full = self.full[i % 2]
+        blocks = self.grecv[i % 2].view(self.world, self.pad)
+        base, rem = divmod(self.nwave, self.world)
+        if rem:
+            full[:rem * (base + 1)].view(rem, base + 1).copy_(blocks[:rem, :base + 1])
+        if base:
+            full[rem * (base + 1):].view(self.world - rem, base).copy_(blocks[rem:, :base])
+        return full
+
+    def submit(self):
+        i = self.count
+        self.count = i + 1
+        self._stage_a(i)
+        if i >= 1:
+            self._stage_b(i - 1)
+        return self._stage_c(i - 2) if i >= 2 else None
+
+    def flush(self):
+        out = []
+        i = self.count                  # A done for 0..i-1, B for 0..i-2, C for 0..i-3
+        if i >= 1:
+            self._stage_b(i - 1)
+        if i >= 2:
+            out.append(self._stage_c(i - 2).clone())
+        if i >= 1:
+            out.append(self._stage_c(i - 1))
+        self.count = 0
+        return out
 
 
 def walker_slice(nwalkers, world, rank):

@@ -154,3 +154,65 @@ def test_walker_replicas_gather(tmp_path):
     want = np.arange(nwalkers * 3, dtype=float).reshape(nwalkers, 3)
     for rank in range(world):
         assert np.array_equal(np.load(tmp_path / f'w{rank}.npy'), want)
+
+
+def _worker_pipeline(rank, world, port, nlayers, nwave, nsteps, tmp):
+    """ExchangePipeline over real (asynchronous) gloo collectives: produce = this rank's layers
+    of a step-dependent matrix, consume = a column-wise weighted sum over all layers."""
+    sys.path.insert(0, ROOT)
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from pyratbay_amd import dist as pbd
+    lp = -(-nlayers // world)
+    rows = np.arange(rank, nlayers, world)
+    weights = torch.arange(1, nlayers + 1, dtype=torch.float64)
+    state = {'step': 0}
+
+    def matrix(step):
+        return (np.arange(nlayers * nwave, dtype=float).reshape(nlayers, nwave) % 97
+                + 1000.0 * step)
+
+    def produce(ec):
+        ec.zero_()
+        ec[:len(rows)] = torch.from_numpy(matrix(state['step'])[rows])
+        state['step'] += 1
+
+    def consume(ec_cols):
+        assert ec_cols.shape[0] == nlayers
+        return (ec_cols * weights[:, None]).sum(0)
+
+    ec = torch.zeros((lp, nwave), dtype=torch.float64)
+    pipe = pbd.ExchangePipeline(ec, nlayers, world, rank, produce, consume)
+    outs = []
+    for _ in range(nsteps):
+        o = pipe.submit()
+        if o is not None:
+            outs.append(o.clone().numpy())
+    outs += [o.clone().numpy() for o in pipe.flush()]
+    # and a second batch through the same (now empty) pipeline
+    for _ in range(2):
+        o = pipe.submit()
+        assert o is None
+    outs += [o.clone().numpy() for o in pipe.flush()]
+    ok = len(outs) == nsteps + 2
+    for k, got in enumerate(outs):
+        want = (matrix(k) * weights.numpy()[:, None]).sum(0)
+        ok = ok and np.array_equal(got, want)
+    np.save(os.path.join(tmp, f'p{rank}.npy'), np.array([ok, len(outs)]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('nlayers,nwave,nsteps', [(7, 101, 5), (8, 64, 1), (5, 33, 2)])
+def test_exchange_pipeline_two_ranks(tmp_path, nlayers, nwave, nsteps):
+    """The software-pipelined layer-sharded step (submit/flush: all-to-all and all-gather of
+    spectrum i beside the production of i+1, double buffers) returns every spectrum, in
+    order, on every rank."""
+    world = 2
+    mp.spawn(_worker_pipeline,
+             args=(world, _free_port(), nlayers, nwave, nsteps, str(tmp_path)),
+             nprocs=world, join=True)
+    for rank in range(world):
+        ok, n = np.load(tmp_path / f'p{rank}.npy')
+        assert ok == 1 and n == nsteps + 2

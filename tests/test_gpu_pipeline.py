@@ -159,6 +159,39 @@ def test_layer_sharded_extinction_equals_single(eng, case, world):
     assert np.array_equal(one.step().cpu().numpy(), want)
 
 
+def test_pipelined_submit_flush_single_process(eng, case):
+    """The software-pipelined form of the layer-sharded step (submit/flush, double buffers,
+    stages A/B/C of consecutive spectra interleaved) returns the same spectra as step(),
+    in order, also when the atmosphere changes between submissions."""
+    from pyratbay_amd import synth
+    from pyratbay_amd.dist import LayerShardedTransit
+    sh = LayerShardedTransit(case, 1, 0)
+    want0 = sh.step().cpu().numpy().copy()
+    atm, iso = case['atm'], case['iso']
+    hot_t = atm['temp'] * 1.04
+    hot_z = synth.partition_function(hot_t)[None, :].repeat(len(iso['isomass']), 0)
+
+    def set_temp(temp, isoz):
+        sh.temp.copy_(eng.dev(temp)[eng.dev(sh.layers).long()])
+        sh.isoz.copy_(eng.dev(isoz)[:, eng.dev(sh.layers).long()])
+
+    set_temp(hot_t, hot_z)
+    want1 = sh.step().cpu().numpy().copy()
+    assert not np.array_equal(want0, want1)
+    set_temp(atm['temp'], iso['isoz'])
+    got = []
+    for k in range(5):
+        set_temp(*((hot_t, hot_z) if k % 2 else (atm['temp'], iso['isoz'])))
+        out = sh.submit()
+        if out is not None:
+            got.append(out.cpu().numpy().copy())
+    got += [o.cpu().numpy().copy() for o in sh.flush()]
+    assert len(got) == 5
+    for k, g_ in enumerate(got):
+        assert np.array_equal(g_, want1 if k % 2 else want0), k
+    assert sh.flush() == []
+
+
 def test_hip_graph_replay(eng, case):
     """The step captured as one HIP graph reproduces the eager spectrum, also after the
     atmosphere buffers were updated in place."""
