@@ -596,6 +596,13 @@ __device__ inline int floor_div_inv(int a, double inv)
 constexpr int kChunkRow = 1024;      // samples per chunk of a long phase row (= kStageRowMax)
 constexpr int kRecLayers = 4;        // layers per thread of k_records (group data loaded once)
 
+// kFmt = where the records of the layers walked in phase order go: 0 the six SoA arrays, 1 the
+// packed 16-byte records, 2 packed records per (group, chunk of a long row); 3 = every layer
+// in position order into 32-byte records (scatter kernel).  Layers of the resident-profile
+// kernel are in position order and always use the SoA arrays.  The two orders are two passes
+// with their own pointer sets (one body instantiated twice): with both sets and every record
+// format live at once the kernel held a third of its scalar state in spilled registers.
+template <int kFmt>
 __global__ __launch_bounds__(kBlock) void k_records(LblArgs a)
 {
     extern __shared__ unsigned long long s_max[];                 // [kRecLayers][nrows]
@@ -607,108 +614,116 @@ __global__ __launch_bounds__(kBlock) void k_records(LblArgs a)
     for (int d = threadIdx.x; d < a.ndop; d += kBlock)
         s_dop[d] = a.doppler[d];
     __syncthreads();
-    // the group's static data, in the order this layer's gather kernel walks the groups
-    // (layers of the resident-profile and scatter kernels: position order)
-    int iso = 0, first = 0, count = 0, iown = 0;
-    double wavn = 0.0, elow = 0.0, gf = 0.0;
-    int loaded = -1;                                              // 0 / 1 = order in registers
-    for (int i = 0; i < kRecLayers; i++) {
-        const int layer = layer0 + i;
-        if (layer >= a.nlayers)
-            break;
-        const int pos = (a.rec32 != nullptr || (a.res_cap > 0 && a.ls_resident[layer])) ? 1 : 0;
-        if (pos != loaded && g < a.ngroups) {                     // wave-uniform
-            iso = (pos ? a.giso : a.rk_iso)[g];
-            first = (pos ? a.gfirst : a.rk_first)[g];
-            count = (pos ? a.gcount : a.rk_count)[g];
-            iown = (pos ? a.giown : a.rk_iown)[g];
-            wavn = (pos ? a.g_lead : a.rk_lwn)[g];                // leader's record
-            elow = (pos ? a.g_lead + a.ngroups : a.rk_elow)[g];
-            gf = (pos ? a.g_lead + 2 * a.ngroups : a.rk_gf)[g];
-        }
-        loaded = pos;
-        double k = 0.0, lmax = 0.0;
-        int ulo = 0, uhi = 0, q = 0, cell = 0, phi = 0, row = -1;
+    auto pass = [&](auto posc) {
+        constexpr bool kPos = decltype(posc)::value;
+        // the group's static data, in the order this pass's gather kernel walks the groups
+        int iso = 0, first = 0, count = 0, iown = 0;
+        double wavn = 0.0, elow = 0.0, gf = 0.0;
         if (g < a.ngroups) {
-            row = a.isoiext[iso];
-            if (row >= 0 && a.add)
-                row = 0;
-            if (row >= 0) {
-                const int64_t li = (int64_t)layer * a.niso + iso;
-                const double temp = a.temp[layer];
-                const double ratio = a.isoratio[iso];
-                const double z = a.li_z[li];
-                k = line_strength(ratio, gf, elow, wavn, temp, z);
-                lmax = k;
-                for (int m = 1; m < count; m++) {
-                    const double kp = line_strength(ratio, a.gf[first + m], a.elow[first + m],
-                                                    a.lwn[first + m], temp, z);
-                    k += kp;
-                    lmax = fmax(lmax, kp);
+            iso = (kPos ? a.giso : a.rk_iso)[g];
+            first = (kPos ? a.gfirst : a.rk_first)[g];
+            count = (kPos ? a.gcount : a.rk_count)[g];
+            iown = (kPos ? a.giown : a.rk_iown)[g];
+            wavn = (kPos ? a.g_lead : a.rk_lwn)[g];                // leader's record
+            elow = (kPos ? a.g_lead + a.ngroups : a.rk_elow)[g];
+            gf = (kPos ? a.g_lead + 2 * a.ngroups : a.rk_gf)[g];
+        }
+        for (int i = 0; i < kRecLayers; i++) {
+            const int layer = layer0 + i;
+            if (layer >= a.nlayers)
+                break;
+            const bool pos = kFmt == 3 || (a.res_cap > 0 && a.ls_resident[layer]);
+            if (pos != kPos)                                          // wave-uniform
+                continue;
+            double k = 0.0, lmax = 0.0;
+            int ulo = 0, uhi = 0, q = 0, cell = 0, phi = 0, row = -1;
+            if (g < a.ngroups) {
+                row = a.isoiext[iso];
+                if (row >= 0 && a.add)
+                    row = 0;
+                if (row >= 0) {
+                    const int64_t li = (int64_t)layer * a.niso + iso;
+                    const double temp = a.temp[layer];
+                    const double ratio = a.isoratio[iso];
+                    const double z = a.li_z[li];
+                    k = line_strength(ratio, gf, elow, wavn, temp, z);
+                    lmax = k;
+                    for (int m = 1; m < count; m++) {
+                        const double kp = line_strength(ratio, a.gf[first + m],
+                                                        a.elow[first + m], a.lwn[first + m],
+                                                        temp, z);
+                        k += kp;
+                        lmax = fmax(lmax, kp);
+                    }
+                    const int ofactor = a.ls_ofactor[layer];
+                    const int scale = a.ls_scale[layer];
+                    const Window w = group_window(a, wavn, iown, a.li_ilor[li], a.li_alphad[li],
+                                                  ofactor, a.ls_dwnstep[layer], a.ls_dnwn[layer],
+                                                  0, a.ndop - 1, s_dop);
+                    // kept samples: minj <= scale*jo < maxj, inside the profile and the grid
+                    const double inv_scale = 1.0 / (double)scale;
+                    ulo = -floor_div_inv(-(int)w.minj, inv_scale);
+                    uhi = -floor_div_inv(-(int)w.maxj, inv_scale);
+                    ulo = max(ulo, -floor_div_inv(w.half - iown, a.inv_osamp));
+                    uhi = min(uhi, floor_div_inv(iown + w.half, a.inv_osamp) + 1);
+                    uhi = min(uhi, a.nwave);
+                    q = floor_div_inv(w.half - iown, a.inv_osamp);
+                    phi = (w.half - iown) - q * a.osamp;
+                    cell = w.cell;
+                    if (uhi < ulo)
+                        uhi = ulo;
                 }
-                const int ofactor = a.ls_ofactor[layer];
-                const int scale = a.ls_scale[layer];
-                const Window w = group_window(a, wavn, iown, a.li_ilor[li], a.li_alphad[li],
-                                              ofactor, a.ls_dwnstep[layer], a.ls_dnwn[layer], 0,
-                                              a.ndop - 1, s_dop);
-                // kept samples: minj <= scale*jo < maxj, inside the profile and the grid
-                const double inv_scale = 1.0 / (double)scale;
-                ulo = -floor_div_inv(-(int)w.minj, inv_scale);
-                uhi = -floor_div_inv(-(int)w.maxj, inv_scale);
-                ulo = max(ulo, -floor_div_inv(w.half - iown, a.inv_osamp));
-                uhi = min(uhi, floor_div_inv(iown + w.half, a.inv_osamp) + 1);
-                uhi = min(uhi, a.nwave);
-                q = floor_div_inv(w.half - iown, a.inv_osamp);
-                phi = (w.half - iown) - q * a.osamp;
-                cell = w.cell;
-                if (uhi < ulo)
-                    uhi = ulo;
-            }
-            const int64_t idx = (int64_t)layer * a.ngroups + g;
-            if (a.rec32) {
-                Rec32 r;
-                r.k = k;
-                r.off = a.pm_base[cell] + (long long)phi * a.pm_stride[cell] + q;
-                r.ulo = ulo;
-                r.uhi = uhi;
-                r.pad[0] = r.pad[1] = 0;
-                a.rec32[idx] = r;
-            } else if (a.rec16 && !pos && a.nch_max > 1) {
-                // one record per chunk of the phase row: the part of the window whose row
-                // coordinates u = sample + q fall into [c0, c0 + kStageRowMax)
-                const int64_t ps = a.ph_start[(int64_t)iso * (a.osamp + 1) + iown % a.osamp];
-                const int64_t pe = a.ph_start[(int64_t)iso * (a.osamp + 1) + iown % a.osamp + 1];
-                const int64_t li = (int64_t)layer * a.niso + iso;
-                const int nch = (min(a.rowcap, a.li_rowmax[li]) + kChunkRow - 1) / kChunkRow;
-                const int64_t lbase = (int64_t)layer * a.ngroups * a.nch_max;
-                const int mlo = ulo + q, mhi = uhi + q;
-                for (int c = 0; c < nch; c++) {
-                    const int c0 = c * kChunkRow;
-                    const int wlo = max(mlo, c0), whi = min(mhi, c0 + kChunkRow);
+                const int64_t idx = (int64_t)layer * a.ngroups + g;
+                if constexpr (kFmt == 3) {
+                    Rec32 r;
+                    r.k = k;
+                    r.off = a.pm_base[cell] + (long long)phi * a.pm_stride[cell] + q;
+                    r.ulo = ulo;
+                    r.uhi = uhi;
+                    r.pad[0] = r.pad[1] = 0;
+                    a.rec32[idx] = r;
+                } else if constexpr (kFmt == 2 && !kPos) {
+                    // one record per chunk of the phase row: the part of the window whose row
+                    // coordinates u = sample + q fall into [c0, c0 + kStageRowMax)
+                    const int64_t ps = a.ph_start[(int64_t)iso * (a.osamp + 1) + iown % a.osamp];
+                    const int64_t pe = a.ph_start[(int64_t)iso * (a.osamp + 1) + iown % a.osamp + 1];
+                    const int64_t li = (int64_t)layer * a.niso + iso;
+                    const int nch = (min(a.rowcap, a.li_rowmax[li]) + kChunkRow - 1) / kChunkRow;
+                    const int64_t lbase = (int64_t)layer * a.ngroups * a.nch_max;
+                    const int mlo = ulo + q, mhi = uhi + q;
+                    for (int c = 0; c < nch; c++) {
+                        const int c0 = c * kChunkRow;
+                        const int wlo = max(mlo, c0), whi = min(mhi, c0 + kChunkRow);
+                        Rec16 r;
+                        r.k = k;
+                        r.ulo = whi > wlo ? wlo - q : ulo;
+                        r.lc = (uint32_t)max(whi - wlo, 0) | ((uint32_t)cell << 12);
+                        a.rec16[lbase + ps * a.nch_max + (int64_t)c * (pe - ps) + (g - ps)] = r;
+                    }
+                } else if constexpr (kFmt == 1 && !kPos) {
                     Rec16 r;
                     r.k = k;
-                    r.ulo = whi > wlo ? wlo - q : ulo;
-                    r.lc = (uint32_t)max(whi - wlo, 0) | ((uint32_t)cell << 12);
-                    a.rec16[lbase + ps * a.nch_max + (int64_t)c * (pe - ps) + (g - ps)] = r;
+                    r.ulo = ulo;
+                    r.lc = (uint32_t)(uhi - ulo) | ((uint32_t)cell << 12);
+                    a.rec16[idx] = r;
+                } else {
+                    a.rec_k[idx] = k;
+                    a.rec_ulo[idx] = ulo;
+                    a.rec_uhi[idx] = uhi;
+                    a.rec_q[idx] = q;
+                    a.rec_cell[idx] = cell;
+                    a.rec_phi[idx] = phi;
                 }
-            } else if (a.rec16 && !pos) {
-                Rec16 r;
-                r.k = k;
-                r.ulo = ulo;
-                r.lc = (uint32_t)(uhi - ulo) | ((uint32_t)cell << 12);
-                a.rec16[idx] = r;
-            } else {
-                a.rec_k[idx] = k;
-                a.rec_ulo[idx] = ulo;
-                a.rec_uhi[idx] = uhi;
-                a.rec_q[idx] = q;
-                a.rec_cell[idx] = cell;
-                a.rec_phi[idx] = phi;
             }
+            if (row >= 0)
+                atomicMax(&s_max[i * a.nrows + row],
+                          (unsigned long long)__double_as_longlong(lmax));
         }
-        if (row >= 0)
-            atomicMax(&s_max[i * a.nrows + row], (unsigned long long)__double_as_longlong(lmax));
-    }
+    };
+    if (kFmt != 3)
+        pass(std::false_type());
+    if (kFmt == 3 || a.res_cap > 0)
+        pass(std::true_type());
     __syncthreads();
     for (int r = threadIdx.x; r < kRecLayers * a.nrows; r += kBlock) {
         const int layer = layer0 + r / a.nrows;
@@ -2474,7 +2489,15 @@ int pb_lbl_extinction(pb_lbl *p, double *ext_d, int64_t wbegin, int64_t wcount,
     PB_LAUNCH_CHECK();
     if (use_records) {
         dim3 grid(pb::div_up(l->ngroups, kBlock), pb::div_up(nlayers, kRecLayers));
-        k_records<<<grid, kBlock, (size_t)kRecLayers * a.nrows * 8 + (size_t)a.ndop * 8, s>>>(a);
+        const size_t rlds = (size_t)kRecLayers * a.nrows * 8 + (size_t)a.ndop * 8;
+        if (a.rec32)
+            k_records<3><<<grid, kBlock, rlds, s>>>(a);
+        else if (a.rec16 && a.nch_max > 1)
+            k_records<2><<<grid, kBlock, rlds, s>>>(a);
+        else if (a.rec16)
+            k_records<1><<<grid, kBlock, rlds, s>>>(a);
+        else
+            k_records<0><<<grid, kBlock, rlds, s>>>(a);
         PB_LAUNCH_CHECK();
     } else if (l->nlines > 0) {
         const int lines_per_block = 4096;
