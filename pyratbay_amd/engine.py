@@ -285,6 +285,46 @@ def transit_spectrum(ec, raypath_packed, radius, rstar, itop, ibottom, maxdepth,
     return spectrum, depth, ideep
 
 
+def patchy_transit_spectrum(ec, ec_cloud, fpatchy, raypath_packed, radius, rstar, itop,
+                            maxdepth, deck_rsurf=None, deck_itop=None):
+    """Patchy clouds, transit geometry (opacity/optic_depth.py:94-121 +
+    pyrat/spectrum.py:350-363): the cloudy atmosphere is ec + ec_cloud (from itop down) with
+    the opaque deck, if any, as its bottom; the clear one is ec over all layers; the spectrum
+    is their fpatchy-weighted mean.  -> (spectrum, clear, cloudy), each [W]."""
+    nlayers = ec.shape[0]
+    ec_cloudy = ec.clone()
+    ec_cloudy[itop:] += ec_cloud[itop:]
+    ibottom = nlayers if deck_rsurf is None else int(deck_itop) + 1
+    cloudy, _, _ = transit_spectrum(ec_cloudy, raypath_packed, radius, rstar, itop, ibottom,
+                                    maxdepth, deck_rsurf, deck_itop)
+    clear, _, _ = transit_spectrum(ec, raypath_packed, radius, rstar, itop, nlayers, maxdepth)
+    return fpatchy * cloudy + (1.0 - fpatchy) * clear, clear, cloudy
+
+
+def patchy_emission_flux(ec, ec_cloud, fpatchy, intervals, wn, temp, mu, weights, itop,
+                         maxdepth, deck_tsurf=None, deck_itop=None):
+    """Patchy clouds, plane-parallel emission (opacity/optic_depth.py:123-136 +
+    pyrat/spectrum.py:366-385).  -> (flux, clear, cloudy), each [W]."""
+    nlayers = ec.shape[0]
+    ec_cloudy = ec.clone()
+    ec_cloudy[itop:] += ec_cloud[itop:]
+    ibottom = nlayers if deck_tsurf is None else int(deck_itop) + 1
+    depth, ideep = plane_parallel_optical_depth(ec_cloudy, intervals, itop, ibottom, maxdepth)
+    cloudy = emission_flux(depth, ideep, wn, temp, mu, weights, itop,
+                           cloud_tsurf=deck_tsurf, cloud_itop=deck_itop)
+    depth, ideep = plane_parallel_optical_depth(ec, intervals, itop, nlayers, maxdepth)
+    # The reference's cloudy pass overwrites row deck_itop of its Planck array with the
+    # cloud-top emission IN PLACE (spectrum/radiative_transfer.py:125-126) and the clear pass
+    # then integrates that same array (pyrat/spectrum.py:380-383): its "clear" atmosphere
+    # emits at the cloud-top temperature in that one layer.  Reproduced, not corrected.
+    temp_clear = temp
+    if deck_tsurf is not None:
+        temp_clear = temp.clone()
+        temp_clear[int(deck_itop)] = float(deck_tsurf)
+    clear = emission_flux(depth, ideep, wn, temp_clear, mu, weights, itop)
+    return fpatchy * cloudy + (1.0 - fpatchy) * clear, clear, cloudy
+
+
 def plane_parallel_optical_depth(ec, intervals, itop, ibottom, maxdepth, depth=None):
     """optic_depth.py:122-130.  Rows below the stopping layer stay zero."""
     nlayers, nwave = ec.shape
