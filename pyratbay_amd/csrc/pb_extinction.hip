@@ -175,6 +175,18 @@ __global__ __launch_bounds__(64) void k_layer_state(LblArgs a)
 {
     __shared__ unsigned long long s_minwidth;
     __shared__ int s_block;          // largest phase-major profile block any isotope can use
+    // the width grids and the divisors are searched serially by one or a few lanes: one
+    // parallel copy into LDS first turns ~40 dependent global loads into LDS reads (the
+    // kernel is on the critical path of every spectrum)
+    extern __shared__ double s_grid[];                 // lorentz[nlor] | doppler[ndop] | divisors
+    double *s_lor = s_grid, *s_dopp = s_grid + a.nlor;
+    int *s_div = reinterpret_cast<int *>(s_dopp + a.ndop);
+    for (int i = threadIdx.x; i < a.nlor; i += 64)
+        s_lor[i] = a.lorentz[i];
+    for (int i = threadIdx.x; i < a.ndop; i += 64)
+        s_dopp[i] = a.doppler[i];
+    for (int i = threadIdx.x; i < a.ndivs; i += 64)
+        s_div[i] = a.divisors[i];
     const int layer = blockIdx.x;
     const double temp = a.temp[layer];
     const double fdop = sqrt(2 * pb::kKB * temp / pb::kAMU) * pb::kSqrtLn2 / pb::kLS;
@@ -199,16 +211,16 @@ __global__ __launch_bounds__(64) void k_layer_state(LblArgs a)
         const double dw = alphad * a.own0;
         const double vw = 0.5346 * alphal + sqrt(alphal * alphal * 0.2166 + dw * dw);
         atomicMin(&s_minwidth, (unsigned long long)__double_as_longlong(vw));
-        const int ilor = pb::nearest_index(a.lorentz, alphal, 0, a.nlor - 1);
+        const int ilor = pb::nearest_index(s_lor, alphal, 0, a.nlor - 1);
         int hmax = 0;
         for (int d = 0; d < a.ndop; d++)
             hmax = max(hmax, a.psize[ilor * a.ndop + d]);
         // the resident kernel stages whole cells: only the Doppler columns that lines on
         // this grid can select matter (one column of margin on both sides)
         {
-            const int dlo = max(0, pb::nearest_index(a.doppler, alphad * a.own0, 0, a.ndop - 1) - 1);
+            const int dlo = max(0, pb::nearest_index(s_dopp, alphad * a.own0, 0, a.ndop - 1) - 1);
             const int dhi = min(a.ndop - 1,
-                                pb::nearest_index(a.doppler, alphad * a.own_last, 0, a.ndop - 1) + 1);
+                                pb::nearest_index(s_dopp, alphad * a.own_last, 0, a.ndop - 1) + 1);
             int used = 0, hlo = INT_MAX, hhi = 0;
             for (int d = dlo; d <= dhi; d++) {
                 used = max(used, a.pm_stride[ilor * a.ndop + d]);
@@ -232,9 +244,9 @@ __global__ __launch_bounds__(64) void k_layer_state(LblArgs a)
         const double minwidth = __longlong_as_double((long long)s_minwidth);
         int d;
         for (d = 1; d < a.ndivs; d++)
-            if (a.divisors[d] * a.ownstep >= 0.5 * minwidth)
+            if (s_div[d] * a.ownstep >= 0.5 * minwidth)
                 break;
-        const int ofactor = a.divisors[d - 1];
+        const int ofactor = s_div[d - 1];
         a.ls_ofactor[layer] = ofactor;
         a.ls_dwnstep[layer] = a.ownstep * ofactor;
         a.ls_dnwn[layer] = 1 + (a.onwn - 1) / ofactor;
@@ -594,7 +606,8 @@ __device__ inline int floor_div_inv(int a, double inv)
 }
 
 constexpr int kChunkRow = 1024;      // samples per chunk of a long phase row (= kStageRowMax)
-constexpr int kRecLayers = 4;        // layers per thread of k_records (group data loaded once)
+constexpr int kRecLayers = 4;        // layers per thread of k_records (group data loaded once);
+                                     // 1 for launches of few layers (multi-GPU ranks)
 
 // kFmt = where the records of the layers walked in phase order go: 0 the six SoA arrays, 1 the
 // packed 16-byte records, 2 packed records per (group, chunk of a long row); 3 = every layer
@@ -602,7 +615,7 @@ constexpr int kRecLayers = 4;        // layers per thread of k_records (group da
 // kernel are in position order and always use the SoA arrays.  The two orders are two passes
 // with their own pointer sets (one body instantiated twice): with both sets and every record
 // format live at once the kernel held a third of its scalar state in spilled registers.
-template <int kFmt>
+template <int kFmt, int kRecLayers>
 __global__ __launch_bounds__(kBlock) void k_records(LblArgs a)
 {
     extern __shared__ unsigned long long s_max[];                 // [kRecLayers][nrows]
@@ -2485,19 +2498,25 @@ int pb_lbl_extinction(pb_lbl *p, double *ext_d, int64_t wbegin, int64_t wcount,
     }
     a.use_records = use_records ? 1 : 0;
 
-    k_layer_state<<<nlayers, 64, 0, s>>>(a);
+    k_layer_state<<<nlayers, 64, ((size_t)a.nlor + a.ndop) * 8 + (size_t)a.ndivs * 4, s>>>(a);
     PB_LAUNCH_CHECK();
     if (use_records) {
-        dim3 grid(pb::div_up(l->ngroups, kBlock), pb::div_up(nlayers, kRecLayers));
-        const size_t rlds = (size_t)kRecLayers * a.nrows * 8 + (size_t)a.ndop * 8;
-        if (a.rec32)
-            k_records<3><<<grid, kBlock, rlds, s>>>(a);
-        else if (a.rec16 && a.nch_max > 1)
-            k_records<2><<<grid, kBlock, rlds, s>>>(a);
-        else if (a.rec16)
-            k_records<1><<<grid, kBlock, rlds, s>>>(a);
-        else
-            k_records<0><<<grid, kBlock, rlds, s>>>(a);
+        // (one layer per thread for launches of few layers measured slower: 10 layers of C2
+        // 49 us against 27 us with four; PB_REC_LAYERS=1 selects it)
+        const int per = getenv("PB_REC_LAYERS") && atoi(getenv("PB_REC_LAYERS")) == 1 ? 1 : kRecLayers;
+        dim3 grid(pb::div_up(l->ngroups, kBlock), pb::div_up(nlayers, per));
+        const size_t rlds = (size_t)per * a.nrows * 8 + (size_t)a.ndop * 8;
+        const int fmt = a.rec32 ? 3 : (a.rec16 && a.nch_max > 1) ? 2 : a.rec16 ? 1 : 0;
+        void (*krec)(LblArgs) =
+            per == 1 ? (fmt == 3   ? k_records<3, 1>
+                        : fmt == 2 ? k_records<2, 1>
+                        : fmt == 1 ? k_records<1, 1>
+                                   : k_records<0, 1>)
+                     : (fmt == 3   ? k_records<3, kRecLayers>
+                        : fmt == 2 ? k_records<2, kRecLayers>
+                        : fmt == 1 ? k_records<1, kRecLayers>
+                                   : k_records<0, kRecLayers>);
+        krec<<<grid, kBlock, rlds, s>>>(a);
         PB_LAUNCH_CHECK();
     } else if (l->nlines > 0) {
         const int lines_per_block = 4096;
