@@ -792,8 +792,14 @@ __global__ __launch_bounds__(NW * 64, 8) void k_ext_staged(LblArgs a)
     unsigned long long *s_segmask =
         reinterpret_cast<unsigned long long *>(s_src + kThreads);        // [NW]
     unsigned *s_m = reinterpret_cast<unsigned *>(s_segmask + NW);        // mlo | mhi << 16
-    unsigned *s_seg = s_m + kThreads;                                    // i0 | i1 << 16
-    int *s_part = reinterpret_cast<int *>(s_seg + kThreads);             // [NW] scan scratch
+    // the segment table takes the place of the window keys, which nothing reads once the
+    // segment starts are known (a barrier lies between the last read and the first write)
+    unsigned *s_seg = s_m;                                               // i0 | i1 << 16
+    // the table cells of this (layer, isotope): one Lorentz row, ndop Doppler columns
+    long long *s_cbase = reinterpret_cast<long long *>(s_m + kThreads);  // [ndop] pm_base
+    int *s_csize = reinterpret_cast<int *>(s_cbase + a.ndop);            // [ndop] psize
+    int *s_cstride = s_csize + a.ndop;                                   // [ndop] pm_stride
+    int *s_part = s_cstride + a.ndop;                                    // [NW] scan scratch
     const int vmax = osamp * a.nch_max;                                  // (phase, chunk) pairs
     int *s_cum = s_part + NW;                                            // [vmax+1]
     int *s_phs = s_cum + (vmax + 1);                                     // [vmax]
@@ -936,6 +942,12 @@ __global__ __launch_bounds__(NW * 64, 8) void k_ext_staged(LblArgs a)
         // candidates of every phase key: [s_phs[p], s_phs[p] + count) in the phase list,
         // then an exclusive scan of the counts (thread t owns a run of `per` phases)
         __syncthreads();
+        const int cell0 = a.li_ilor[li] * a.ndop;      // first cell of the isotope's Lorentz row
+        for (int d = tid; d < a.ndop; d += kThreads) {
+            s_cbase[d] = a.pm_base[cell0 + d];
+            s_csize[d] = a.psize[cell0 + d];
+            s_cstride[d] = a.pm_stride[cell0 + d];
+        }
         {
             const int lim = min(a.rowlds, a.li_rowmax[li]);
             if (lim != rowlim) {                   // wave-uniform
@@ -1058,7 +1070,7 @@ __global__ __launch_bounds__(NW * 64, 8) void k_ext_staged(LblArgs a)
                         ulo = r.ulo;
                         uhi = ulo + (int)(r.lc & 0xfffu);
                         cell = (int)(r.lc >> 12);
-                        const int d = a.psize[cell] - a.ph_iown[gidx];      // half - iown
+                        const int d = s_csize[cell - cell0] - a.ph_iown[gidx];   // half - iown
                         q = floor_div_inv(d, a.inv_osamp);
                         phi = d - q * osamp;
                         q -= c0;                        // row index relative to the chunk
@@ -1079,7 +1091,7 @@ __global__ __launch_bounds__(NW * 64, 8) void k_ext_staged(LblArgs a)
                         qoff = (int)(q + t0) * 8;       // tile sample j reads row[j + q + t0]
                         if (kDma)
                             qoff -= ((ulo + q) & 1) * 8;  // the image starts at an even sample
-                        src = a.pm_base[cell] + (long long)phi * a.pm_stride[cell] + c0;
+                        src = s_cbase[cell - cell0] + (long long)phi * s_cstride[cell - cell0] + c0;
                         mwin = (unsigned)(ulo + q) | ((unsigned)(uhi + q) << 16);
                     } else {
                         k = 0.0;
@@ -2382,7 +2394,8 @@ int pb_lbl_extinction(pb_lbl *p, double *ext_d, int64_t wbegin, int64_t wcount,
     const int nch_max = (int)pb::div_up((int64_t)a.rowcap, (int64_t)kChunkRow);
     a.nch_max = std::max(1, nch_max);
     a.rowlds = (std::min(a.rowcap, kStageRowMax) + 1) & ~1;     // even: 16-byte aligned buffers
-    const size_t lds_fixed = (size_t)kStagedThreads * (16 + 8 + 4 + 4) + kStagedWaves * 12 +
+    const size_t lds_fixed = (size_t)kStagedThreads * (16 + 8 + 4) + kStagedWaves * 12 +
+                             (size_t)a.ndop * 16 +
                              (size_t)(2 * v->osamp * a.nch_max + 1) * 4 + 64;
     bool dma = true;                     // rows by LDS-DMA (k_ext_staged); PB_STAGE_DMA=0: via registers
     if (const char *e = getenv("PB_STAGE_DMA"))
