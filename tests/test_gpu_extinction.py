@@ -276,3 +276,52 @@ def test_staged_variants_agree(eng, monkeypatch):
             got = run(PB_STAGE_S=2, PB_STAGE_SPLIT=split, PB_STAGE_DMA=dma)
             assert np.array_equal(got == 0, base == 0)
             np.testing.assert_allclose(got, base, rtol=1e-13)
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_random_configurations(eng, orc, seed):
+    """Randomly drawn grids, oversampling factors, profile extents, cutoffs, line densities
+    and shard windows: the staged kernel (LDS-DMA rows; odd and even window starts, ragged
+    last tiles, rows from a few to a few thousand samples, chunked rows) and the global gather
+    agree with each other and, on three layers, with the oracle."""
+    from pyratbay_amd import synth
+    rng = np.random.default_rng(1000 + seed)
+    nwave = int(rng.integers(3, 6000))
+    nlayers = int(rng.integers(1, 7))
+    nlines = int(rng.integers(1, 40000))
+    niso = int(rng.integers(1, 4))
+    wnosamp = int(rng.choice([6, 12, 24, 60]))
+    extent = float(rng.choice([8.0, 40.0, 150.0, 600.0]))
+    cutoff = float(rng.choice([0.0, 0.5, 3.0, 30.0]))
+    wnstep = float(rng.choice([0.01, 0.05, 0.2]))
+    case = synth.lbl_case(nwave, nlayers, nlines, wnstep=wnstep, wnosamp=wnosamp, nlor=12,
+                          ndop=6, extent=extent, cutoff=cutoff, niso=niso, seed=seed)
+    g, atm, ln, iso, vg = (case[k] for k in ('grid', 'atm', 'lines', 'iso', 'voigt'))
+    vt = eng.VoigtTable.build(vg['lorentz'], vg['doppler'], vg['size'], g['ownstep'], wnosamp)
+    ll = eng.LineList(ln['lwn'], ln['elow'], ln['gf'], ln['lid'], niso, g['own'])
+    lbl = eng.LBL(vt, ll, g['wn'], g['divisors'], atm['mol_radius'], atm['mol_mass'],
+                  iso['isoimol'], iso['isomass'], iso['isoratio'], iso['isoiext'],
+                  vg['cutoff'], 1e-30, max_layers=nlayers)
+    t, d, z = eng.dev(atm['temp']), eng.dev(atm['dens']), eng.dev(iso['isoz'])
+    a = int(rng.integers(0, g['nwave']))
+    b = int(rng.integers(a, g['nwave'])) + 1
+    out = {}
+    for mode in ('global', 'staged'):
+        lbl.set_gather_mode(mode)
+        out[mode] = host(lbl.extinction(t, d, z, add=True))
+        out[mode + '_shard'] = host(lbl.extinction(t, d, z, add=True, wbegin=a, wcount=b - a))
+        assert np.array_equal(out[mode + '_shard'], out[mode][:, :, a:b]), mode
+    assert np.array_equal(out['staged'] == 0, out['global'] == 0)
+    np.testing.assert_allclose(out['staged'], out['global'], rtol=1e-12)
+    profile = vt.flat()
+    for layer in sorted(set([0, nlayers // 2, nlayers - 1])):
+        want = np.zeros((1, g['nwave']))
+        orc.extinction(want, profile, vt.size, vt.index, vg['lorentz'], vg['doppler'],
+                       g['wn'], g['own'], g['divisors'], atm['dens'][layer],
+                       atm['mol_radius'], atm['mol_mass'], iso['isoimol'], iso['isomass'],
+                       iso['isoratio'], iso['isoz'][:, layer].copy(), iso['isoiext'],
+                       ln['lwn'], ln['elow'], ln['gf'], ln['lid'], vg['cutoff'], 1e-30,
+                       atm['temp'][layer], 0, 1, 0)
+        got = out['staged'][layer]
+        assert np.array_equal(got == 0, want == 0), layer
+        np.testing.assert_allclose(got, want, rtol=RTOL)
