@@ -204,3 +204,50 @@ def test_loglike_matches_reference_formula(eng):
     np.testing.assert_allclose(got[ok], want[ok], rtol=1e-13)
     one = eng.loglike(eng.dev(model[0]), eng.dev(data), eng.dev(uncert)).cpu().numpy()
     assert one.shape == (1,) and one[0] == got[0]
+
+
+@pytest.mark.parametrize('seed', range(8))
+def test_random_rt_configurations(eng, orc, seed):
+    """Randomly drawn column problems -- layers, columns (narrow grids take the 4-rows-per-
+    thread transit kernels, wide ones the 16-row form), top layer, maximum depth, with and
+    without an opaque cloud deck -- through the fused and the two-call transit forms and the
+    plane-parallel emission path, against the oracle."""
+    rng = np.random.default_rng(500 + seed)
+    L = int(rng.integers(2, 90))
+    W = int(rng.choice([1, 63, 700, 40000]))
+    c = cases.column_case(seed=seed + 77, nlayers=L, nwave=W)
+    itop = int(rng.integers(0, max(1, L // 3)))
+    maxdepth = float(rng.choice([0.3, 10.0, np.inf]))
+    deck_itop = int(rng.integers(itop + 1, L)) if rng.random() < 0.5 and L - itop > 2 else None
+    ibottom = L if deck_itop is None else deck_itop + 1
+    radius, ec = c['radius'], c['ec']
+    rsurf = tsurf = None
+    if deck_itop is not None:
+        f = float(rng.uniform(0.05, 0.95))          # cloud top between two layers
+        rsurf = radius[deck_itop - 1] + f * (radius[deck_itop] - radius[deck_itop - 1])
+        tsurf = c['temp'][deck_itop - 1] + f * (c['temp'][deck_itop] - c['temp'][deck_itop - 1])
+    # transit
+    want_d, want_i = orc.optical_depth_transit(ec, radius, itop, ibottom, maxdepth)
+    want = orc.transmission_deck(want_d, radius, c['rstar'], want_i, itop, rsurf, deck_itop)
+    path = eng.dev(eng.pack_raypath(eng.transit_path(radius, itop), itop))
+    spec, depth, ideep = eng.transit_spectrum(eng.dev(ec), path, eng.dev(radius), c['rstar'],
+                                              itop, ibottom, maxdepth, rsurf, deck_itop)
+    assert np.array_equal(host(ideep), want_i)
+    np.testing.assert_allclose(host(depth), want_d, rtol=RTOL)
+    np.testing.assert_allclose(host(spec), want, rtol=RTOL)
+    depth2, ideep2 = eng.optical_depth_transit(eng.dev(ec), path, itop, ibottom, maxdepth)
+    spec2 = eng.transmission(depth2, ideep2, eng.dev(radius), itop, c['rstar'], rsurf, deck_itop)
+    assert np.array_equal(host(spec2), host(spec))
+    # plane-parallel emission
+    h = -orc.ediff(radius)
+    wd, wi = np.zeros((L, W)), np.full(W, L - 1, np.int32)
+    orc.plane_parallel_optical_depth(wd, wi, ec, h, maxdepth, itop, ibottom)
+    weights = np.pi * np.diff(np.sin(np.radians([0, 10, 30, 50, 70, 90]))**2)
+    want_f = orc.emission_deck(wd, wi, c['wn'], c['temp'], c['mu'], weights, itop, tsurf,
+                               deck_itop)
+    d3, i3 = eng.plane_parallel_optical_depth(eng.dev(ec), eng.dev(h), itop, ibottom, maxdepth)
+    assert np.array_equal(host(i3), wi)
+    np.testing.assert_allclose(host(d3), wd, rtol=RTOL)
+    flux = eng.emission_flux(d3, i3, eng.dev(c['wn']), eng.dev(c['temp']), eng.dev(c['mu']),
+                             eng.dev(weights), itop, cloud_tsurf=tsurf, cloud_itop=deck_itop)
+    np.testing.assert_allclose(host(flux), want_f, rtol=RTOL)
