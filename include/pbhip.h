@@ -154,6 +154,14 @@ int pb_interp_ec(double *extinction_d, const double *etable_d, const double *tta
                  const double *temperatures_d, const double *density_d, int nmol,
                  int ntemp, int nlayers, int nwave, int lay1, int lay2, int per_mol,
                  void *stream);
+/* Same, but the rows lay1 <= k < min(lay2,nlayers) are ASSIGNED (= 0 + the sum) instead of
+ * accumulated into: for callers that would zero the array first (the retrieval loop,
+ * opacity/line_sampling.py:438-456 after `self.ec = np.zeros(...)`): saves that pass and
+ * the read of `extinction`. */
+int pb_interp_ec_set(double *extinction_d, const double *etable_d, const double *ttable_d,
+                     const double *temperatures_d, const double *density_d, int nmol,
+                     int ntemp, int nlayers, int nwave, int lay1, int lay2, int per_mol,
+                     void *stream);
 
 /* =========================================================================
  * Optical depth

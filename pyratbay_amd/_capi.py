@@ -50,6 +50,7 @@ _PROTOS = {
     'pb_lbl_timing_end': [vp, C.POINTER(f64), C.POINTER(i32)],
     'pb_lbl_destroy': [vp],
     'pb_interp_ec': [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp],
+    'pb_interp_ec_set': [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp],
     'pb_optdepth': [vp, vp, i64, vp, i32, f64, vp, i32, i32, vp],
     'pb_optical_depth_transit': [vp, vp, vp, vp, i32, i32, f64, i32, i32, vp],
     'pb_transit_spectrum': [vp, vp, vp, vp, vp, vp, f64, i32, i32, f64, i32, i32, vp],

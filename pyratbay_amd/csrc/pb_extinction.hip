@@ -1781,6 +1781,9 @@ __global__ __launch_bounds__(kBlock) void k_ext_linterp(LblArgs a)
 // _extcoeff.interp_ec / interp_ec_per_mol (src_c/_extcoeff.c:367-472)
 // grid (wavenumber blocks, layers, per_mol ? nmol : 1)
 // ---------------------------------------------------------------------------
+// kAssign: ext = sum instead of ext += sum (a caller that would zero ext first saves that
+// pass and the read: 128 MB of 768 at the C5 shape)
+template <bool kAssign>
 __global__ __launch_bounds__(kBlock) void k_interp_ec(
     double *ext, const double *etable, const double *ttable, const double *temps,
     const double *density, int nmol, int ntemp, int nlayers, int nwave, int lay1,
@@ -1803,9 +1806,10 @@ __global__ __launch_bounds__(kBlock) void k_interp_ec(
         const double d = density[(int64_t)k * nmol + j];
         const double lo = etable[(((int64_t)j * ntemp + tlo) * nlayers + k) * nwave + i];
         const double hi = etable[(((int64_t)j * ntemp + thi) * nlayers + k) * nwave + i];
-        ext[((int64_t)j * nlayers + k) * nwave + i] += lo * (w_lo * d) + hi * (w_hi * d);
+        double *e = ext + ((int64_t)j * nlayers + k) * nwave + i;
+        *e = (kAssign ? 0.0 : *e) + (lo * (w_lo * d) + hi * (w_hi * d));
     } else {
-        double acc = ext[(int64_t)k * nwave + i];
+        double acc = kAssign ? 0.0 : ext[(int64_t)k * nwave + i];
         for (int j = 0; j < nmol; j++) {
             const double d = density[(int64_t)k * nmol + j];
             const double lo = etable[(((int64_t)j * ntemp + tlo) * nlayers + k) * nwave + i];
@@ -2749,9 +2753,10 @@ void pb_lbl_destroy(pb_lbl *p)
     delete p;
 }
 
-int pb_interp_ec(double *extinction_d, const double *etable_d, const double *ttable_d,
-                 const double *temperatures_d, const double *density_d, int nmol, int ntemp,
-                 int nlayers, int nwave, int lay1, int lay2, int per_mol, void *stream)
+static int interp_ec_launch(bool assign, double *extinction_d, const double *etable_d,
+                            const double *ttable_d, const double *temperatures_d,
+                            const double *density_d, int nmol, int ntemp, int nlayers,
+                            int nwave, int lay1, int lay2, int per_mol, void *stream)
 {
     PB_REQUIRE(nmol >= 1 && ntemp >= 2 && nlayers >= 1 && nwave >= 0,
                "pb_interp_ec: bad shape (needs >= 2 table temperatures)");
@@ -2763,11 +2768,32 @@ int pb_interp_ec(double *extinction_d, const double *etable_d, const double *tta
     PB_REQUIRE(extinction_d && etable_d && ttable_d && temperatures_d && density_d,
                "pb_interp_ec: null pointer");
     dim3 grid(pb::div_up(nwave, kBlock), lay2 - lay1, per_mol ? nmol : 1);
-    k_interp_ec<<<grid, kBlock, 0, pb::as_stream(stream)>>>(
-        extinction_d, etable_d, ttable_d, temperatures_d, density_d, nmol, ntemp, nlayers,
-        nwave, lay1, per_mol ? 1 : 0);
+    if (assign)
+        k_interp_ec<true><<<grid, kBlock, 0, pb::as_stream(stream)>>>(
+            extinction_d, etable_d, ttable_d, temperatures_d, density_d, nmol, ntemp, nlayers,
+            nwave, lay1, per_mol ? 1 : 0);
+    else
+        k_interp_ec<false><<<grid, kBlock, 0, pb::as_stream(stream)>>>(
+            extinction_d, etable_d, ttable_d, temperatures_d, density_d, nmol, ntemp, nlayers,
+            nwave, lay1, per_mol ? 1 : 0);
     PB_LAUNCH_CHECK();
     return PB_OK;
+}
+
+int pb_interp_ec(double *extinction_d, const double *etable_d, const double *ttable_d,
+                 const double *temperatures_d, const double *density_d, int nmol, int ntemp,
+                 int nlayers, int nwave, int lay1, int lay2, int per_mol, void *stream)
+{
+    return interp_ec_launch(false, extinction_d, etable_d, ttable_d, temperatures_d, density_d,
+                            nmol, ntemp, nlayers, nwave, lay1, lay2, per_mol, stream);
+}
+
+int pb_interp_ec_set(double *extinction_d, const double *etable_d, const double *ttable_d,
+                     const double *temperatures_d, const double *density_d, int nmol, int ntemp,
+                     int nlayers, int nwave, int lay1, int lay2, int per_mol, void *stream)
+{
+    return interp_ec_launch(true, extinction_d, etable_d, ttable_d, temperatures_d, density_d,
+                            nmol, ntemp, nlayers, nwave, lay1, lay2, per_mol, stream);
 }
 
 }  // extern "C"

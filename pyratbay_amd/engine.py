@@ -410,9 +410,13 @@ def intensity(tau, ideep, planck, mu, rtop):
     return out
 
 
-def interp_ec(extinction, etable, ttable, temperatures, density, lay1, lay2, per_mol=False):
+def interp_ec(extinction, etable, ttable, temperatures, density, lay1, lay2, per_mol=False,
+              assign=False):
+    """_extcoeff.interp_ec[_per_mol]: accumulates into `extinction`; assign=True writes the
+    rows lay1..lay2 instead (no need to zero them first)."""
     nmol, ntemp, nlayers, nwave = etable.shape
-    call('pb_interp_ec', _ptr(extinction), _ptr(etable), _ptr(ttable), _ptr(temperatures),
+    call('pb_interp_ec_set' if assign else 'pb_interp_ec', _ptr(extinction), _ptr(etable),
+         _ptr(ttable), _ptr(temperatures),
          _ptr(density), nmol, ntemp, nlayers, nwave, int(lay1), int(lay2), int(per_mol),
          _stream())
     return extinction
@@ -630,8 +634,8 @@ class TableSpectrum:
         (pyrat/opacity.py:206-257: every model adds to the same ec)."""
         self.temp = temp if isinstance(temp, torch.Tensor) else dev(temp)
         dens = dens if isinstance(dens, torch.Tensor) else dev(dens)
-        self.ec.zero_()
-        interp_ec(self.ec, self.etable, self.ttable, self.temp, dens, 0, self.nlayers)
+        interp_ec(self.ec, self.etable, self.ttable, self.temp, dens, 0, self.nlayers,
+                  assign=True)
         if self.continuum is not None:
             self.continuum.add(self.ec, self.temp.cpu().numpy(), continuum_density)
         if self.rt_path == 'transit':

@@ -185,6 +185,18 @@ def test_interp_ec_golden(eng, golden):
     m = torch.zeros((nmol, nlayers, nwave), dtype=torch.float64, device='cuda')
     eng.interp_ec(m, et, tt, te, de, 0, nlayers + 3, per_mol=True)
     np.testing.assert_allclose(host(m), g['per_mol'], rtol=RTOL)
+    # the assigning form: same values as accumulating into zeros, whatever the rows held,
+    # and rows outside [lay1, lay2) untouched
+    junk = torch.full((nlayers, nwave), 7.5, dtype=torch.float64, device='cuda')
+    eng.interp_ec(junk, et, tt, te, de, 2, 5, assign=True)
+    want = g['part'].copy()
+    want[:2] = 7.5
+    want[5:] = 7.5
+    assert np.array_equal(host(junk)[:2], want[:2]) and np.array_equal(host(junk)[5:], want[5:])
+    assert np.array_equal(host(junk)[2:5], host(b)[2:5])
+    mj = torch.full((nmol, nlayers, nwave), -3.0, dtype=torch.float64, device='cuda')
+    eng.interp_ec(mj, et, tt, te, de, 0, nlayers, per_mol=True, assign=True)
+    assert np.array_equal(host(mj), host(m))
 
 
 def test_loglike_matches_reference_formula(eng):
