@@ -2,22 +2,30 @@
 """Headline benchmark: transmission spectra per second at 1e5 wavenumbers x 80 layers
 (BASELINE.json configs[1]: 1e5 synthetic lines, transit geometry).
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--workload c2|c2-1e6|c3|c4|c5|small]
 
 One step = one pass of the hot path over the synthetic workload with every input
 resident in HBM: LBL extinction (all layers) -> transit optical depth -> transmission
 spectrum (the 'extinction' + 'odepth' + 'spectrum' stages of Pyrat.run(),
-pyratbay/pyrat/pyrat_obj.py:203-214).  With N > 1 the spectrum is sharded over
-wavenumber, one rank per GPU, and re-assembled with an RCCL all-gather (strong
-scaling: the total work per step is fixed).  Rank 0 prints ONE JSON line.
+pyratbay/pyrat/pyrat_obj.py:203-214).  With N > 1 the work is sharded, one rank per
+GPU (see pyratbay_amd/dist.py), and the spectrum is re-assembled with an RCCL
+all-gather (strong scaling: the total work per step is fixed).  Rank 0 prints ONE
+JSON line.
 
-The oracle / compiled reference is used only for the `cpu_baseline` leg (and never
-inside the timed region).
+The oracle / compiled reference is used only for the `cpu_baseline` legs, never inside a
+timed GPU region.  The CPU legs run in worker processes that are started BEFORE this
+process touches the GPU (a process that has initialised HIP is never forked or exec'd);
+they mirror the reference's own parallel form: one process per layer over min(cores - 1,
+nlayers) workers (pyrat/line_by_line.py:232-246, clamp at pyrat/argum.py:60-66).
 """
 import argparse
+import hashlib
 import json
 import os
+import shutil
+import subprocess
 import sys
+import tempfile
 import time
 
 import numpy as np
@@ -25,8 +33,9 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+C4_SPECIES = ('H2', 'He', 'H2O', 'CO', 'CO2', 'CH4')
+C4_VMR = (0.85, 0.149, 4e-4, 5e-4, 1e-7, 1e-4)
 WORKLOADS = {
-    # name: (nwave, nlayers, nlines, wnstep, niso)
     'c2': dict(nwave=100001, nlayers=80, nlines=100000, wnstep=0.05, niso=1,
                label='1e5 wavenumbers x 80 layers, 1e5 synthetic lines, transit'),
     'c2-1e6': dict(nwave=100001, nlayers=80, nlines=1000000, wnstep=0.05, niso=1,
@@ -36,52 +45,140 @@ WORKLOADS = {
     'c3': dict(nwave=1000001, nlayers=80, nlines=1000000, wnstep=0.005, niso=4,
                rt_path='emission',
                label='1e6 wavenumbers x 80 layers, 1e6-line 4-isotope list, emission'),
+    # BASELINE.json configs[3]; on one GPU this is its single-GPU form, with --gpus N the
+    # wavenumber-sharded form the config names
+    'c4': dict(nwave=1000001, nlayers=120, nlines=1000000, wnstep=0.005, niso=4,
+               species=C4_SPECIES, vmr=C4_VMR, line_species=('H2O', 'CO', 'CO2', 'CH4'),
+               label='1e6 wavenumbers x 120 layers, 4 species x 1e6 lines, transit'),
 }
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+LDS_PEAK_TBS = 150.0      # MI355X_MICROARCH.md: ds_read_b64/b128 aggregate, every CU streaming
+NORTH_STAR = 'c2-1e6'     # north_star's >= 50x target configuration
 
 
-def cpu_baseline(case, voigt, budget_layers=8, gpu_ec=None, gpu_spectrum=None,
-                 rt_path='transit'):
-    """Reference CPU path on a bounded sample: `budget_layers` of the layers through the
-    unmodified reference _extcoeff.extinction (oracle/_ref; falls back to the oracle's
-    C restatement), extrapolated to all layers, plus the full optical-depth and
-    transmission stages.  Single thread (the reference holds the GIL)."""
-    from oracle import oracle as orc, ref
-    g, atm, ln, iso, vg = (case[k] for k in ('grid', 'atm', 'lines', 'iso', 'voigt'))
-    nlayers = atm['nlayers']
-    size = voigt.size.astype(np.int64)
-    index = voigt.index.astype(np.int64)
-    profile = voigt.flat()
+def make_case(w):
+    from pyratbay_amd import synth
+    kw = {k: w[k] for k in ('species', 'vmr', 'line_species') if k in w}
+    return synth.lbl_case(w['nwave'], w['nlayers'], w['nlines'], wnstep=w['wnstep'],
+                          niso=w['niso'], seed=42, **kw)
+
+
+# ---------------------------------------------------------------------------------------
+# CPU reference legs (test infrastructure; nothing here is on the product path)
+# ---------------------------------------------------------------------------------------
+EXT_KEYS = ('profile', 'size', 'index', 'lorentz', 'doppler', 'wn', 'own', 'divisors', 'dens',
+            'mol_radius', 'mol_mass', 'isoimol', 'isomass', 'isoratio', 'isoz', 'isoiext',
+            'lwn', 'elow', 'gf', 'lid', 'temp')
+
+
+def _ext_module():
+    """(kind, extinction function, integer dtype) of the CPU implementation timed."""
+    from oracle import ref
     if ref.available():
-        kind = 'reference'
-        ext_fn = ref.module('_extcoeff').extinction
-        int_t = np.int64
-    else:
-        kind = 'port'
-        ext_fn = orc.extinction
-        int_t = np.int32
-    layers = np.unique(np.linspace(0, nlayers - 1, budget_layers).round().astype(int))
-    ec = np.zeros((nlayers, g['nwave']))
-    t_ext = 0.0
+        return 'reference', ref.module('_extcoeff').extinction, np.int64
+    from oracle import oracle as orc
+    return 'port', orc.extinction, np.int32
+
+
+def _run_layers(arr, layers, ec_out, scal):
+    """_extcoeff.extinction for the given layers, one call per layer like
+    pyrat/extinction.py:170-213; returns seconds per layer."""
+    kind, ext_fn, int_t = _ext_module()
+    ints = {k: np.ascontiguousarray(arr[k]).astype(int_t)
+            for k in ('size', 'index', 'divisors', 'isoimol', 'isoiext', 'lid')}
+    times = []
     for layer in layers:
-        row = np.zeros((1, g['nwave']))
+        row = np.zeros((1, arr['wn'].shape[0]))
         t0 = time.perf_counter()
-        ext_fn(row, profile, size.astype(int_t), index.astype(int_t), vg['lorentz'],
-               vg['doppler'], g['wn'], g['own'], g['divisors'].astype(int_t),
-               atm['dens'][layer], atm['mol_radius'], atm['mol_mass'],
-               iso['isoimol'].astype(int_t), iso['isomass'], iso['isoratio'],
-               iso['isoz'][:, layer].copy(), iso['isoiext'].astype(int_t), ln['lwn'],
-               ln['elow'], ln['gf'], ln['lid'].astype(int_t), vg['cutoff'], case['ethresh'],
-               atm['temp'][layer], 0, 1, 0)
-        t_ext += time.perf_counter() - t0
-        ec[layer] = row[0]
-    # fill the layers that were not sampled so that the later stages see realistic columns
-    for layer in range(nlayers):
-        if layer not in layers:
-            near = layers[np.argmin(np.abs(layers - layer))]
-            ec[layer] = ec[near] * atm['press'][layer] / atm['press'][near]
+        ext_fn(row, arr['profile'], ints['size'], ints['index'], arr['lorentz'],
+               arr['doppler'], arr['wn'], arr['own'], ints['divisors'], arr['dens'][layer],
+               arr['mol_radius'], arr['mol_mass'], ints['isoimol'], arr['isomass'],
+               arr['isoratio'], np.ascontiguousarray(arr['isoz'][:, layer]), ints['isoiext'],
+               arr['lwn'], arr['elow'], arr['gf'], ints['lid'], scal['cutoff'],
+               scal['ethresh'], float(arr['temp'][layer]), 0, 1, 0)
+        times.append(time.perf_counter() - t0)
+        ec_out[layer] = row[0]
+    return kind, times
+
+
+def cpu_worker():
+    """Worker process of the all-cores leg: waits on stdin for {"dir", "layers", ...} jobs.
+    Never imports torch or touches the GPU."""
+    for line in sys.stdin:
+        job = json.loads(line)
+        if job.get('quit'):
+            break
+        d = job['dir']
+        arr = {k: np.load(os.path.join(d, k + '.npy'), mmap_mode='r') for k in EXT_KEYS}
+        ec = np.load(os.path.join(d, 'ec.npy'), mmap_mode='r+')
+        t0 = time.perf_counter()
+        kind, times = _run_layers(arr, job['layers'], ec, job['scal'])
+        ec.flush()
+        print(json.dumps({'kind': kind, 'times': times,
+                          'wall': time.perf_counter() - t0}), flush=True)
+
+
+class CpuPool:
+    """min(cores - 1, nlayers) worker processes, started before any GPU call."""
+
+    def __init__(self, nworkers):
+        self.procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__),
+                                        '--cpu-worker'], stdin=subprocess.PIPE,
+                                       stdout=subprocess.PIPE, text=True, cwd=ROOT)
+                      for _ in range(nworkers)]
+
+    def run(self, d, nlayers, scal):
+        """Every layer once, layers dealt round-robin (deep = slow layers spread evenly);
+        returns (wall seconds, kind)."""
+        n = min(len(self.procs), nlayers)
+        shares = [list(range(w, nlayers, n)) for w in range(n)]
+        t0 = time.perf_counter()
+        for p, layers in zip(self.procs, shares):
+            p.stdin.write(json.dumps({'dir': d, 'layers': layers, 'scal': scal}) + '\n')
+            p.stdin.flush()
+        replies = [json.loads(p.stdout.readline()) for p, _ in zip(self.procs, shares)]
+        wall = time.perf_counter() - t0
+        return wall, replies[0]['kind'], n
+
+    def close(self):
+        for p in self.procs:
+            try:
+                p.stdin.write(json.dumps({'quit': True}) + '\n')
+                p.stdin.flush()
+                p.stdin.close()
+            except Exception:
+                pass
+        for p in self.procs:
+            try:
+                p.wait(timeout=10)
+            except Exception:
+                p.kill()
+
+
+def cpu_model():
+    try:
+        for line in open('/proc/cpuinfo'):
+            if line.startswith('model name'):
+                return line.split(':', 1)[1].strip()
+    except OSError:
+        pass
+    return 'unknown'
+
+
+def host_cores():
+    try:
+        return len(os.sched_getaffinity(0))
+    except AttributeError:
+        return os.cpu_count() or 1
+
+
+def rest_of_path(case, ec, rt_path):
+    """optical depth + spectrum stages on the CPU (reference modules when built)."""
+    from oracle import oracle as orc, ref
+    g, atm = case['grid'], case['atm']
+    nlayers = atm['nlayers']
     t0 = time.perf_counter()
-    if kind == 'reference':
+    if ref.available():
         t = ref.module('_trapezoid')
         raypath = orc.transit_path(atm['radius'], 0)
         depth = np.zeros_like(ec)
@@ -91,35 +188,88 @@ def cpu_baseline(case, voigt, budget_layers=8, gpu_ec=None, gpu_spectrum=None,
         ideep[ideep < 0] = nlayers - 1
         h = np.ediff1d(atm['radius'])
         integ = np.exp(-depth) * np.expand_dims(atm['radius'], 1)
-        spec = t.trapezoid2D(integ, h, (ideep).astype(np.intc))
+        spec = t.trapezoid2D(integ, h, ideep.astype(np.intc))
         spec = (atm['radius'][0]**2 + 2 * spec) / atm['rstar']**2
     else:
         depth, ideep = orc.optical_depth_transit(ec, atm['radius'], 0, nlayers,
                                                  case['maxdepth'])
         spec = orc.transmission(depth, atm['radius'], atm['rstar'], ideep, 0)
-    t_rest = time.perf_counter() - t0
-    seconds = t_ext * nlayers / len(layers) + t_rest
-    # full-size parity evidence: the GPU's ec rows (and, when every layer was computed on
-    # the CPU, the final spectrum) against the CPU reference on the same inputs
+    return spec, time.perf_counter() - t0
+
+
+def cpu_legs(case, voigt, pool, budget_layers, gpu_ec, gpu_spectrum, rt_path):
+    """The reference CPU path on the same inputs: (a) one core, `budget_layers` sampled
+    layers through _extcoeff.extinction, extrapolated to all layers; (b) all cores, every
+    layer, one process per layer over the pool (wall clock); both + the optical-depth and
+    spectrum stages on one core.  Returns (cpu_baseline, cpu_baseline_allcores)."""
+    g, atm, ln, iso, vg = (case[k] for k in ('grid', 'atm', 'lines', 'iso', 'voigt'))
+    nlayers, nwave = atm['nlayers'], g['nwave']
+    arr = dict(profile=voigt.flat(), size=voigt.size, index=voigt.index,
+               lorentz=vg['lorentz'], doppler=vg['doppler'], wn=g['wn'], own=g['own'],
+               divisors=g['divisors'], dens=atm['dens'], mol_radius=atm['mol_radius'],
+               mol_mass=atm['mol_mass'], isoimol=iso['isoimol'], isomass=iso['isomass'],
+               isoratio=iso['isoratio'], isoz=iso['isoz'], isoiext=iso['isoiext'],
+               lwn=ln['lwn'], elow=ln['elow'], gf=ln['gf'], lid=ln['lid'], temp=atm['temp'])
+    scal = dict(cutoff=float(vg['cutoff']), ethresh=float(case['ethresh']))
+    # (a) one core, in this process
+    layers = np.unique(np.linspace(0, nlayers - 1, budget_layers).round().astype(int))
+    ec1 = np.zeros((nlayers, nwave))
+    kind, times = _run_layers(arr, [int(x) for x in layers], ec1, scal)
+    t_ext1 = float(np.sum(times)) * nlayers / len(layers)
+    # (b) all cores: arrays shared through files the workers map
+    allcores = None
+    ec = ec1
+    if pool is not None and len(pool.procs) > 0:
+        base = '/dev/shm' if os.path.isdir('/dev/shm') else None
+        d = tempfile.mkdtemp(prefix='pb_cpu_', dir=base)
+        try:
+            for k in EXT_KEYS:
+                np.save(os.path.join(d, k + '.npy'), np.ascontiguousarray(arr[k]))
+            np.save(os.path.join(d, 'ec.npy'), np.zeros((nlayers, nwave)))
+            wall, kind_all, nused = pool.run(d, nlayers, scal)
+            ec = np.load(os.path.join(d, 'ec.npy'))
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+        allcores = dict(wall=wall, kind=kind_all, workers=nused)
+    else:
+        for layer in range(nlayers):           # fill so the later stages see real columns
+            if layer not in layers:
+                near = layers[np.argmin(np.abs(layers - layer))]
+                ec[layer] = ec[near] * atm['press'][layer] / atm['press'][near]
+    spec, t_rest = rest_of_path(case, ec, rt_path)
+    note = ('' if rt_path == 'transit' else
+            f'; NB the transit depth/transmission stages were timed in place of the {rt_path} '
+            'ones (extinction is >95 % of either)')
     parity = None
     if gpu_ec is not None:
-        got, want = gpu_ec[layers], ec[layers]
+        cmp_layers = np.arange(nlayers) if allcores else layers
+        got, want = gpu_ec[cmp_layers], ec[cmp_layers]
         nz = want != 0
         parity = {'ec_max_rel_err': float(np.max(np.abs(got[nz] / want[nz] - 1))),
                   'ec_zero_pattern_equal': bool(np.array_equal(got == 0, want == 0)),
-                  'layers_compared': int(len(layers))}
-        if gpu_spectrum is not None and len(layers) == nlayers:
+                  'layers_compared': int(len(cmp_layers))}
+        if gpu_spectrum is not None and allcores:
             parity['spectrum_max_rel_err'] = float(np.max(np.abs(gpu_spectrum / spec - 1)))
-    return dict(value=1.0 / seconds, unit='spectra/s', cores=1, kind=kind, parity=parity,
-                sample=(f'{len(layers)} of {nlayers} layers through extinction '
-                        f'({t_ext:.2f} s), extrapolated x{nlayers / len(layers):.1f}; full '
-                        f'optical depth + transmission ({t_rest:.2f} s); '
-                        f'{seconds:.2f} s per spectrum'
-                        + ('' if rt_path == 'transit' else
-                           '; NB the transit depth/transmission stages were timed in place of '
-                           f'the {rt_path} ones (extinction is >95 % of either)')))
+    s1 = t_ext1 + t_rest
+    one = dict(value=1.0 / s1, unit='spectra/s', cores=1, kind=kind, parity=parity,
+               seconds_per_spectrum=s1,
+               sample=(f'{len(layers)} of {nlayers} layers through _extcoeff.extinction '
+                       f'({np.sum(times):.2f} s), x{nlayers / len(layers):.2f} to all layers; '
+                       f'full optical depth + transmission ({t_rest:.2f} s)' + note))
+    many = None
+    if allcores:
+        sa = allcores['wall'] + t_rest
+        many = dict(value=1.0 / sa, unit='spectra/s', cores=allcores['workers'],
+                    kind=allcores['kind'], seconds_per_spectrum=sa, cpu=cpu_model(),
+                    host_cores=host_cores(),
+                    sample=(f'all {nlayers} layers, one process per layer over '
+                            f'{allcores["workers"]} workers (the reference\'s ncpu fork model, '
+                            f'wall {allcores["wall"]:.2f} s) + optical depth + transmission '
+                            f'on one core ({t_rest:.2f} s)' + note))
+    return one, many
 
 
+# ---------------------------------------------------------------------------------------
 def dominant_kernel(lbl, nlayers):
     """Name of the gather kernel that did the work of the last call: when the automatic mode
     also launched the resident-profile kernel, say which layers it actually took."""
@@ -135,22 +285,64 @@ def dominant_kernel(lbl, nlayers):
     return name
 
 
+def measured_traffic(workload):
+    """HBM bytes per launch of the dominant kernel from the PMC passes of tools/pmc_traffic.sh
+    -- used only when that file was produced with THIS build of libpbhip.so (hash match);
+    otherwise null: a stale constant is worse than none."""
+    tfile = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
+    so = os.path.join(ROOT, 'pyratbay_amd', 'libpbhip.so')
+    try:
+        rec = json.load(open(tfile))
+        sha = hashlib.sha256(open(so, 'rb').read()).hexdigest()
+        if rec.get('libpbhip_sha256') != sha:
+            return None
+        return rec.get(workload, {}).get('hbm_bytes_per_launch')
+    except Exception:
+        return None
+
+
+def timed_steps(run_steps, steps, warmup, lbl, world, dist, sync, device_for_reduce):
+    run_steps(warmup)
+    lbl.timing_begin(steps)
+    sync()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    run_steps(steps)
+    sync()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    gather_ms, launches = lbl.timing_end()
+    if world > 1:
+        import torch
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=device_for_reduce)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    return elapsed, gather_ms, launches
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=3)
-    ap.add_argument('--workload', default='c2', choices=sorted(WORKLOADS))
+    ap.add_argument('--workload', default='c2', choices=sorted(WORKLOADS) + ['c5'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--shard', default='layers', choices=['layers', 'wavenumber'],
-                    help='multi-GPU decomposition (see pyratbay_amd/dist.py)')
-    ap.add_argument("--cpu-layers", type=int, default=80)
+    ap.add_argument('--no-north-star', action='store_true',
+                    help='skip the 1e6-line leg of the default c2 run')
+    ap.add_argument('--shard', default=None, choices=['layers', 'wavenumber'],
+                    help='multi-GPU decomposition (see pyratbay_amd/dist.py); default: '
+                         'wavenumber for c4 (as BASELINE.json names it), layers otherwise')
+    ap.add_argument('--cpu-layers', type=int, default=None,
+                    help='layers of the one-core CPU leg (default: all at c2, 16 otherwise)')
+    ap.add_argument('--cpu-worker', action='store_true', help=argparse.SUPPRESS)
     args = ap.parse_args()
-
-    import torch
-    import torch.distributed as dist
-    from pyratbay_amd import engine, synth
-    from pyratbay_amd.dist import SpectrumGather, LayerShardedTransit
+    if args.cpu_worker:
+        return cpu_worker()
+    if args.workload == 'c5':
+        from tools import bench_c5
+        return bench_c5.main(args)
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
@@ -158,23 +350,37 @@ def main():
     if world != args.gpus:
         raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with '
                          'python -m torch.distributed.run --nproc-per-node N bench.py --gpus N')
+    w = WORKLOADS[args.workload]
+    if args.shard is None:
+        args.shard = 'wavenumber' if args.workload == 'c4' else 'layers'
+    # CPU workers first: this process has not touched the GPU yet
+    pool = None
+    want_cpu = world == 1 and not args.no_cpu_baseline
+    if want_cpu:
+        pool = CpuPool(max(1, min(host_cores() - 1, w['nlayers'])))
+
+    import torch
+    import torch.distributed as dist
+    from pyratbay_amd import engine
+    from pyratbay_amd.dist import SpectrumGather, LayerShardedTransit
+
     # PB_REHEARSE=1: every rank on GPU 0 with gloo (collectives staged through the host) --
     # only to rehearse the N>1 code path on a one-GPU box; never a benchmark setting
     rehearse = os.environ.get('PB_REHEARSE') == '1'
     if rehearse:
         local_rank = 0
     torch.cuda.set_device(local_rank)
+    backend = None
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        backend = 'gloo' if rehearse else 'nccl'
         if rehearse:
             dist.init_process_group('gloo', rank=rank, world_size=world)
         else:
             dist.init_process_group('nccl', rank=rank, world_size=world,
                                     device_id=torch.device('cuda', local_rank))
 
-    w = WORKLOADS[args.workload]
-    case = synth.lbl_case(w['nwave'], w['nlayers'], w['nlines'], wnstep=w['wnstep'],
-                          niso=w['niso'], seed=42)
+    case = make_case(w)
     nwave, nlayers = case['grid']['nwave'], case['atm']['nlayers']
     rt_path = w.get('rt_path', 'transit')
     layer_mode = world > 1 and args.shard == 'layers' and rt_path == 'transit'
@@ -215,22 +421,21 @@ def main():
             out = step()
         return [out]
 
-    run_steps(args.warmup)
-    model.lbl.timing_begin(args.steps)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    t0 = time.perf_counter()
-    run_steps(args.steps)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    gather_ms, launches = model.lbl.timing_end()
-    if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device='cpu' if rehearse else 'cuda')
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+    elapsed, gather_ms, launches = timed_steps(
+        run_steps, args.steps, args.warmup, model.lbl, world, dist, torch.cuda.synchronize,
+        'cpu' if rehearse else 'cuda')
+    # N > 1: also the un-pipelined per-spectrum latency (one spectrum complete before the
+    # next starts), so that the pipelined throughput is not mistaken for it
+    latency_ms = None
+    if pipelined:
+        def one_at_a_time(k):
+            out = None
+            for _ in range(k):
+                out = step()
+            return [out]
+        el2, _, _ = timed_steps(one_at_a_time, args.steps, 1, model.lbl, world, dist,
+                                torch.cuda.synchronize, 'cpu' if rehearse else 'cuda')
+        latency_ms = 1e3 * el2 / args.steps
     if os.environ.get('PB_DUMP_SPECTRUM'):
         np.save(f"{os.environ['PB_DUMP_SPECTRUM']}.rank{rank}.npy",
                 run_steps(3)[-1].cpu().numpy())
@@ -238,22 +443,39 @@ def main():
     if rank == 0:
         ms_per_step = 1e3 * elapsed / args.steps
         value = args.steps / elapsed
-        # dominant kernel: the extinction gather (k_ext_staged or k_ext_resample, see
-        # roofline.kernel).  Algorithmic bytes per launch = the part of
-        # SURVEY 8(d)'s per-spectrum figure that this kernel moves: read the line list
-        # once (26 B/line), write ec once (8 B per layer x sample of the shard).
+        # dominant kernel: the extinction gather (roofline.kernel).  Algorithmic bytes per
+        # launch = the part of SURVEY 8(d)'s per-spectrum figure that this kernel moves: read
+        # the line list once (26 B/line), write ec once (8 B per layer x sample of the shard).
         n_lines = model.lines.nlines
         kernel_bytes = 26.0 * n_lines + 8.0 * nlayers_rank * wcount
         path_bytes = 26.0 * n_lines + 32.0 * nlayers * nwave + 8.0 * nwave
         kernel_ms = gather_ms / max(launches, 1)
         achieved = kernel_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
-        traffic = None
-        tfile = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
-        if world == 1 and os.path.exists(tfile):     # measured for the single-GPU launch only
-            try:
-                traffic = json.load(open(tfile)).get(args.workload, {}).get('hbm_bytes_per_launch')
-            except Exception:
-                traffic = None
+        roof = {'bound': 'hbm', 'kernel': dominant_kernel(model.lbl, nlayers_rank),
+                'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                'frac': achieved / HBM_PEAK_GBS,
+                'traffic': measured_traffic(args.workload) if world == 1 else None,
+                'kernel_ms': kernel_ms, 'kernel_bytes': kernel_bytes,
+                'path_bytes_per_spectrum': path_bytes, 'path_GBps': path_bytes * value / 1e9}
+        # what the gather kernel IS bound by: every profile sample it multiplies is one 8-byte
+        # LDS read (zero lanes around a row included) -- counted on the device from the record
+        # windows of the last launch
+        work = model.lbl.last_work()
+        if work is not None and kernel_ms > 0:
+            lds_tbps = work['fma_lanes_issued'] * 8.0 / (kernel_ms * 1e-3) / 1e12
+            roof['binding'] = {'bound': 'lds', 'achieved_TBps': lds_tbps,
+                               'peak_TBps': LDS_PEAK_TBS, 'frac': lds_tbps / LDS_PEAK_TBS,
+                               'fma_lanes_useful': work['fma_lanes_useful'],
+                               'fma_lanes_issued': work['fma_lanes_issued'],
+                               'f64_fma_TFLOPs': 2.0 * work['fma_lanes_useful'] /
+                               (kernel_ms * 1e-3) / 1e12}
+        if world == 1:
+            par = 'single GPU'
+        elif layer_mode:
+            par = (f'layer-sharded extinction x{world} + all-to-all + wavenumber-sharded RT + '
+                   'all-gather' + (', consecutive spectra pipelined' if pipelined else ''))
+        else:
+            par = f'wavenumber shards x{world} + all-gather'
         out = {
             'metric': 'spectra/sec (1e5 wavenumbers x 80 layers)',
             'value': value, 'unit': 'spectra/s', 'n_gpus': world, 'steps': args.steps,
@@ -263,30 +485,67 @@ def main():
                        'nlines': n_lines, 'wnosamp': case['grid']['wnosamp'],
                        'voigt_grid': 'nlor=100 ndop=50 extent=300 cutoff=25',
                        'voigt_table_bytes': int(model.voigt.device_bytes),
-                       'parallelism': ('single GPU' if world == 1 else
-                                       f'layer-sharded extinction x{world} + all-to-all + '
-                                       'wavenumber-sharded RT + all-gather' +
-                                       (', consecutive spectra pipelined' if pipelined else '')
-                                       if layer_mode
-                                       else f'wavenumber shards x{world} + all-gather'),
+                       'parallelism': par, 'backend': backend,
+                       'ranks': dist.get_world_size() if world > 1 else 1,
                        'init_seconds': round(t_init, 3)},
-            'roofline': {'bound': 'hbm', 'kernel': dominant_kernel(model.lbl, nlayers_rank),
-                         'achieved': achieved,
-                         'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                         'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
-                         'kernel_ms': kernel_ms, 'kernel_bytes': kernel_bytes,
-                         'path_bytes_per_spectrum': path_bytes,
-                         'path_GBps': path_bytes * value / 1e9},
+            'roofline': roof,
         }
-        if world == 1 and not args.no_cpu_baseline:
-            out['cpu_baseline'] = cpu_baseline(
-                case, model.voigt, args.cpu_layers, gpu_ec=model.ec.cpu().numpy()[:, 0],
+        if latency_ms is not None:
+            out['config']['unpipelined_ms_per_spectrum'] = latency_ms
+        if want_cpu:
+            budget = args.cpu_layers or (nlayers if args.workload in ('c2', 'small') else 16)
+            one, many = cpu_legs(
+                case, model.voigt, pool, budget, gpu_ec=model.ec.cpu().numpy()[:, 0],
                 gpu_spectrum=model.spectrum.cpu().numpy() if rt_path == 'transit' else None,
                 rt_path=rt_path)
+            out['cpu_baseline'] = one
+            if many:
+                out['cpu_baseline_allcores'] = many
+            # north_star's target: >= 50x over the reference CPU _extcoeff + optical-depth
+            # path on a 1e6-line / 1e5-wavenumber / 80-layer transmission spectrum at 1 GPU
+            if args.workload == 'c2' and not args.no_north_star:
+                out['north_star_target'] = north_star_leg(model, pool, args)
         print(json.dumps(out), flush=True)
+    if pool is not None:
+        pool.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def north_star_leg(c2_model, pool, args):
+    """The 1e6-line x 1e5-wavenumber x 80-layer transit spectrum: GPU step time, and the
+    reference on the same box (one core on 16 sampled layers, all cores on every layer)."""
+    import torch
+    from pyratbay_amd import engine
+    w = WORKLOADS[NORTH_STAR]
+    case = make_case(w)
+    # same grid and width grids as c2: the Voigt table is shared
+    model = engine.LBLSpectrum(case, rt_path='transit', voigt=c2_model.voigt)
+    steps = 10
+    for _ in range(2):
+        model.run()
+    model.lbl.timing_begin(steps)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        model.run()
+    torch.cuda.synchronize()
+    gpu_s = (time.perf_counter() - t0) / steps
+    gather_ms, launches = model.lbl.timing_end()
+    one, many = cpu_legs(case, model.voigt, pool, 16, gpu_ec=model.ec.cpu().numpy()[:, 0],
+                         gpu_spectrum=model.spectrum.cpu().numpy(), rt_path='transit')
+    leg = {'workload': w['label'], 'gpu_ms_per_spectrum': 1e3 * gpu_s,
+           'gpu_spectra_per_s': 1.0 / gpu_s, 'kernel': model.lbl.last_gather_kernel,
+           'kernel_ms': gather_ms / max(launches, 1),
+           'cpu_baseline': one, 'cpu_baseline_allcores': many,
+           'speedup_vs_1core': one['seconds_per_spectrum'] / gpu_s,
+           'target_speedup': 50.0}
+    if many:
+        leg['speedup_vs_allcores'] = many['seconds_per_spectrum'] / gpu_s
+    leg['target_met'] = bool(min(leg['speedup_vs_1core'],
+                                 leg.get('speedup_vs_allcores', np.inf)) >= 50.0)
+    return leg
 
 
 if __name__ == '__main__':

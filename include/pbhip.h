@@ -135,6 +135,11 @@ int pb_lbl_last_state(pb_lbl *p, int32_t *ofactor_h, double *kmax_h, int nlayers
  * profile block each layer can select (block_h[nlayers]).  Synchronises the stream. */
 int pb_lbl_last_layer_kinds(pb_lbl *p, int32_t *resident_h, int32_t *block_h, int nlayers,
                             void *stream);
+/* Work of the last pb_lbl_extinction call, counted on the device from its per-(layer, group)
+ * records: work[0] = profile samples multiplied (the FMAs _extcoeff.c:302-307 keeps after
+ * resampling), work[1] = lanes the LDS-staged kernels issue for them (256-sample spans),
+ * work[2] = live records.  All -1 when the last launch kept no packed records. */
+int pb_lbl_last_work(pb_lbl *p, int64_t work[3], void *stream);
 /* Per-launch timing of the gather kernel with HIP events on the call's stream:
  * begin() arms up to max_launches start/stop pairs, every following
  * pb_lbl_extinction records one pair around its gather launch, end() returns the summed

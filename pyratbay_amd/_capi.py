@@ -46,6 +46,7 @@ _PROTOS = {
     'pb_lbl_extinction': [vp, vp, i64, i64, vp, vp, vp, i64, i64, i32, i32, vp],
     'pb_lbl_last_state': [vp, vp, vp, i32, i32, vp],
     'pb_lbl_last_layer_kinds': [vp, vp, vp, i32, vp],
+    'pb_lbl_last_work': [vp, C.POINTER(i64 * 3), vp],
     'pb_lbl_timing_begin': [vp, i32],
     'pb_lbl_timing_end': [vp, C.POINTER(f64), C.POINTER(i32)],
     'pb_lbl_destroy': [vp],

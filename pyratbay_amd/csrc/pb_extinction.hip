@@ -1306,6 +1306,48 @@ __global__ __launch_bounds__(NW * 64, 8) void k_ext_staged(LblArgs a)
 }
 
 // ---------------------------------------------------------------------------
+// Work of the last launch, counted from its packed records (bench.py's roofline.binding):
+// out[0] = profile samples multiplied (sum of the live records' windows inside the shard),
+// out[1] = lanes the staged kernels issue for them (every 256-sample span a window touches,
+// spans aligned to the shard start), out[2] = live records.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_work_stats(LblArgs a, unsigned long long *out)
+{
+    const int64_t n = (int64_t)a.nlayers * a.ngroups;
+    unsigned long long useful = 0, issued = 0, live = 0;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n;
+         i += (int64_t)gridDim.x * kBlock) {
+        const int layer = (int)(i / a.ngroups);
+        const int64_t g = i - (int64_t)layer * a.ngroups;
+        const int iext = a.isoiext[a.ph_iso[g]];
+        if (iext < 0)
+            continue;
+        const int row = a.add ? 0 : iext;
+        const double kthresh =
+            a.ethresh * __longlong_as_double((long long)a.kmax_bits[(int64_t)layer * a.nrows + row]);
+        const Rec16 r = a.rec16[i];
+        const int64_t lo = max((int64_t)r.ulo, a.wbegin) - a.wbegin;
+        const int64_t hi = min((int64_t)r.ulo + (int64_t)(r.lc & 0xfffu), a.wbegin + a.wcount) -
+                           a.wbegin;
+        if (r.k < kthresh || hi <= lo)
+            continue;
+        useful += (unsigned long long)(hi - lo);
+        issued += (unsigned long long)(((hi - 1) / kStageSpan - lo / kStageSpan + 1) * kStageSpan);
+        live++;
+    }
+    for (int d = 32; d >= 1; d >>= 1) {
+        useful += __shfl_down(useful, d);
+        issued += __shfl_down(issued, d);
+        live += __shfl_down(live, d);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(&out[0], useful);
+        atomicAdd(&out[1], issued);
+        atomicAdd(&out[2], live);
+    }
+}
+
+// ---------------------------------------------------------------------------
 // 3a''. Resident-profile gather (constant-step grid), for layers whose profiles are narrow:
 // the WHOLE phase-major block of a table cell (osamp rows of a few tens of samples,
 // <= res_cap doubles) is copied into LDS once per (workgroup, isotope, cell), and then
@@ -1877,6 +1919,8 @@ struct pb_lbl {
     // optional per-launch timing of the gather kernel (bench.py's roofline figure)
     std::vector<hipEvent_t> ev;      // start/stop pairs
     int ev_used = 0;
+    LblArgs last_args;               // arguments of the last launch (pb_lbl_last_work)
+    bool last_packed = false;        // ... whose records are packed, one per (layer, group)
 };
 
 extern "C" {
@@ -2637,6 +2681,8 @@ int pb_lbl_extinction(pb_lbl *p, double *ext_d, int64_t wbegin, int64_t wcount,
             k_ext_resample<1, 4><<<grid, kBlock, 0, s>>>(a);
     }
     PB_LAUNCH_CHECK();
+    p->last_args = a;
+    p->last_packed = a.rec16 != nullptr && a.nch_max == 1;
     if (timed) {
         PB_HIP(hipEventRecord(p->ev[p->ev_used + 1], s));
         p->ev_used += 2;
@@ -2704,6 +2750,32 @@ int pb_lbl_last_layer_kinds(pb_lbl *p, int32_t *resident_h, int32_t *block_h, in
         PB_HIP(hipMemcpy(resident_h, p->ls_resident, (size_t)nlayers * 4, hipMemcpyDeviceToHost));
     if (block_h)
         PB_HIP(hipMemcpy(block_h, p->ls_block, (size_t)nlayers * 4, hipMemcpyDeviceToHost));
+    return PB_OK;
+}
+
+int pb_lbl_last_work(pb_lbl *p, int64_t work[3], void *stream)
+{
+    PB_REQUIRE(p && work, "pb_lbl_last_work: null pointer");
+    work[0] = work[1] = work[2] = -1;
+    if (!p->last_packed)
+        return PB_OK;                 // not counted for this kernel / record format
+    hipStream_t s = pb::as_stream(stream);
+    unsigned long long *d = nullptr;
+    PB_HIP(hipMalloc(&d, 3 * sizeof(unsigned long long)));
+    hipError_t e = hipMemsetAsync(d, 0, 3 * sizeof(unsigned long long), s);
+    if (e == hipSuccess) {
+        k_work_stats<<<1024, kBlock, 0, s>>>(p->last_args, d);
+        e = hipGetLastError();
+    }
+    unsigned long long h[3] = {0, 0, 0};
+    if (e == hipSuccess)
+        e = hipMemcpyAsync(h, d, sizeof(h), hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess)
+        e = hipStreamSynchronize(s);
+    (void)hipFree(d);
+    PB_HIP(e);
+    for (int i = 0; i < 3; i++)
+        work[i] = (int64_t)h[i];
     return PB_OK;
 }
 

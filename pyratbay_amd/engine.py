@@ -207,6 +207,16 @@ class LBL:
         call('pb_lbl_timing_end', self._h, C.byref(ms), C.byref(n))
         return ms.value, n.value
 
+    def last_work(self):
+        """{fma_lanes_useful, fma_lanes_issued, live_records} of the last call, counted on the
+        device (pb_lbl_last_work); None when that launch kept no packed records."""
+        w = (C.c_int64 * 3)()
+        call('pb_lbl_last_work', self._h, C.byref(w), _stream())
+        if w[0] < 0:
+            return None
+        return dict(fma_lanes_useful=int(w[0]), fma_lanes_issued=int(w[1]),
+                    live_records=int(w[2]))
+
     def last_state(self, nlayers, rows):
         ofactor = np.zeros(nlayers, np.int32)
         kmax = np.zeros((nlayers, rows))

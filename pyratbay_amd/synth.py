@@ -148,29 +148,51 @@ def synthetic_atmosphere(nlayers, species=('H2', 'He', 'H2O'), vmr=(0.85, 0.149,
 def lbl_case(nwave_target, nlayers, nlines, *, wnlow=4000.0, wnstep=0.05, wnosamp=None,
              niso=1, nlor=100, ndop=50, extent=300.0, cutoff=25.0, dlratio=0.1,
              seed=42, species=('H2', 'He', 'H2O'), vmr=(0.85, 0.149, 4e-4),
-             line_species_index=2, iso_masses=None, ptop=1e-6, pbottom=1e2):
+             line_species_index=2, iso_masses=None, ptop=1e-6, pbottom=1e2,
+             line_species=None):
     """Everything the LBL hot path needs for one synthetic spectrum.
 
     The line-carrying species is species[line_species_index]; its `niso` isotopes
-    have masses m, m+1, ... and the HITEMP-style ratios of SURVEY.md section 8d."""
+    have masses m, m+1, ... and the HITEMP-style ratios of SURVEY.md section 8d.
+
+    line_species = tuple of species names (BASELINE config 4: several line lists at
+    once): every one of them carries `nlines` lines (seed + its position) and `niso`
+    isotopes; the isotopes are numbered species-major, the line list is the
+    concatenation of the per-species lists (each sorted by isotope, then wavenumber --
+    the order in which line_by_line.py:298-482 concatenates its TLI files) and
+    isoiext[i] = position of the isotope's species, so that add=0 gives one extinction
+    row per species (pyrat/extinction.py:170-213, _extcoeff.c:203-226,265-272)."""
     wnhigh = wnlow + (nwave_target - 1) * wnstep
     grid = spectral_grid(wnlow, wnhigh + 0.5 * wnstep, wnstep, wnosamp)
     atm = synthetic_atmosphere(nlayers, species, vmr, ptop=ptop, pbottom=pbottom)
-    lines = synthetic_lines(nlines, grid['wn'][0], grid['wn'][-1], niso, seed)
-    m0 = atm['mol_mass'][line_species_index]
-    if iso_masses is None:
-        iso_masses = m0 + np.arange(niso)
-    ratios = np.array((0.997, 2e-3, 4e-4, 3e-4)[:niso]) if niso > 1 else np.array([1.0])
+    if line_species is None:
+        carriers = [line_species_index]
+    else:
+        carriers = [list(species).index(s) for s in line_species]
+        assert iso_masses is None, 'iso_masses applies to a single line species'
+    base_ratios = np.array((0.997, 2e-3, 4e-4, 3e-4)[:niso]) if niso > 1 else np.array([1.0])
+    parts, isoimol, isomass, isoratio, isoiext = [], [], [], [], []
+    for k, imol in enumerate(carriers):
+        ln = synthetic_lines(nlines, grid['wn'][0], grid['wn'][-1], niso, seed + k)
+        ln['lid'] = ln['lid'] + np.int32(k * niso)
+        parts.append(ln)
+        m0 = atm['mol_mass'][imol]
+        isoimol += [imol] * niso
+        isomass += list(m0 + np.arange(niso)) if iso_masses is None else list(iso_masses)
+        isoratio += list(base_ratios)
+        isoiext += [k] * niso
+    lines = {key: np.concatenate([p[key] for p in parts]) for key in ('lwn', 'elow', 'gf', 'lid')}
+    ntot = niso * len(carriers)
     iso = dict(
-        isoimol=np.full(niso, line_species_index, np.int32),
-        isomass=np.asarray(iso_masses, float),
-        isoratio=ratios,
-        isoiext=np.zeros(niso, np.int32),
-        isoz=partition_function(atm['temp'])[None, :].repeat(niso, 0),  # [niso, L]
+        isoimol=np.asarray(isoimol, np.int32),
+        isomass=np.asarray(isomass, float),
+        isoratio=np.asarray(isoratio, float),
+        isoiext=np.asarray(isoiext, np.int32),
+        isoz=partition_function(atm['temp'])[None, :].repeat(ntot, 0),  # [niso, L]
     )
     lorentz, doppler = voigt_widths(
-        grid['wn'], atm['press'], np.array([m0]),
-        np.array([atm['mol_radius'][line_species_index]]), nlor, ndop)
+        grid['wn'], atm['press'], atm['mol_mass'][carriers], atm['mol_radius'][carriers],
+        nlor, ndop)
     size = voigt_sizes(lorentz, doppler, extent, cutoff, grid['ownstep'],
                        grid['onwave'], dlratio)
     voigt = dict(lorentz=lorentz, doppler=doppler, size=size, extent=extent,

@@ -1,0 +1,217 @@
+"""BASELINE.json's configurations on the HIP path, inside `pytest -m gpu`.
+
+* C4's structure at reduced size: four line-carrying species, several isotopes each, one
+  extinction row per species (add=0: per-row kmax / ethresh, _extcoeff.c:203-226,265-272) and
+  the summed form (add=1, pyrat/extinction.py:170-213), every gather kernel, against the oracle.
+* C2, C3 and C4 at FULL size: size-independent properties of the HIP path (wavenumber shards
+  concatenate bit for bit, two runs are bitwise equal, the LDS-staged and the global gather
+  agree to 1e-12) plus oracle parity on sampled layers (the oracle's C restatement of
+  _extcoeff.extinction on one host core; a few seconds per layer).
+
+Tolerance as in test_gpu_extinction.py: rtol 1e-10 against the oracle on every non-zero
+sample and an identical zero pattern."""
+import time
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-10
+
+C4_SPECIES = ('H2', 'He', 'H2O', 'CO', 'CO2', 'CH4')
+C4_VMR = (0.85, 0.149, 4e-4, 5e-4, 1e-7, 1e-4)
+C4_LINES = ('H2O', 'CO', 'CO2', 'CH4')
+
+
+@pytest.fixture(scope='module')
+def eng():
+    from pyratbay_amd import engine
+    engine.require_gpu()
+    return engine
+
+
+def host(t):
+    return t.cpu().numpy()
+
+
+def oracle_rows(orc, case, vt, profile, layer, add, ethresh=1e-30):
+    g, atm, ln, iso, vg = (case[k] for k in ('grid', 'atm', 'lines', 'iso', 'voigt'))
+    rows = 1 if add else int(iso['isoiext'].max()) + 1
+    want = np.zeros((rows, g['nwave']))
+    orc.extinction(want, profile, vt.size, vt.index, vg['lorentz'], vg['doppler'], g['wn'],
+                   g['own'], g['divisors'], atm['dens'][layer], atm['mol_radius'],
+                   atm['mol_mass'], iso['isoimol'], iso['isomass'], iso['isoratio'],
+                   iso['isoz'][:, layer].copy(), iso['isoiext'], ln['lwn'], ln['elow'],
+                   ln['gf'], ln['lid'], vg['cutoff'], ethresh, atm['temp'][layer], 0,
+                   int(add), 0)
+    return want
+
+
+def plan(eng, case, max_layers):
+    g, atm, ln, iso, vg = (case[k] for k in ('grid', 'atm', 'lines', 'iso', 'voigt'))
+    vt = eng.VoigtTable.build(vg['lorentz'], vg['doppler'], vg['size'], g['ownstep'],
+                              g['wnosamp'])
+    ll = eng.LineList(ln['lwn'], ln['elow'], ln['gf'], ln['lid'], len(iso['isomass']),
+                      g['own'])
+    lbl = eng.LBL(vt, ll, g['wn'], g['divisors'], atm['mol_radius'], atm['mol_mass'],
+                  iso['isoimol'], iso['isomass'], iso['isoratio'], iso['isoiext'],
+                  vg['cutoff'], case['ethresh'], max_layers=max_layers)
+    return vt, ll, lbl
+
+
+def check(got, want, what):
+    assert np.array_equal(got == 0, want == 0), f'{what}: zero pattern differs'
+    nz = want != 0
+    worst = float(np.max(np.abs(got[nz] / want[nz] - 1))) if nz.any() else 0.0
+    np.testing.assert_allclose(got, want, rtol=RTOL, err_msg=what)
+    return worst
+
+
+# ---------------------------------------------------------------------------
+# C4's structure, reduced size
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize('gather', ['global', 'staged', 'resident', 'scatter', 'auto'])
+@pytest.mark.parametrize('ethresh', [1e-30, 1e-4])
+def test_four_species_vs_oracle(eng, orc, gather, ethresh):
+    from pyratbay_amd import synth
+    case = synth.lbl_case(6001, 7, 9000, wnosamp=24, nlor=18, ndop=9, extent=80.0,
+                          cutoff=3.0, niso=3, seed=31, species=C4_SPECIES, vmr=C4_VMR,
+                          line_species=C4_LINES)
+    iso, atm = case['iso'], case['atm']
+    assert list(iso['isoiext']) == [0] * 3 + [1] * 3 + [2] * 3 + [3] * 3
+    vt, ll, lbl = plan(eng, case, 7)
+    lbl.set_gather_mode(gather)
+    lbl.set_ethresh(ethresh)
+    t, d, z = eng.dev(atm['temp']), eng.dev(atm['dens']), eng.dev(iso['isoz'])
+    profile = vt.flat()
+    worst = 0.0
+    for add in (False, True):
+        ext = host(lbl.extinction(t, d, z, add=add))
+        assert ext.shape == (7, 1 if add else 4, case['grid']['nwave'])
+        for layer in range(7):
+            want = oracle_rows(orc, case, vt, profile, layer, add, ethresh)
+            worst = max(worst, check(ext[layer], want, f'{gather} add={add} layer {layer}'))
+        if not add:
+            # every species row is populated and they differ (per-row kmax and density)
+            assert all(np.any(ext[:, r] != 0) for r in range(4))
+            # per-row maxima: the strongest in-range line of each species
+            _, kmax = lbl.last_state(7, 4)
+            assert np.all(kmax > 0) and len(np.unique(kmax[3])) == 4
+    print(f'4 species {gather} ethresh={ethresh}: max rel err vs oracle = {worst:.2e}')
+
+
+def test_four_species_shards_and_rows(eng, orc):
+    """add=0 rows of a 4-species list: shards concatenate, a species switched off
+    (isoiext = -1) leaves the other rows untouched."""
+    from pyratbay_amd import synth
+    case = synth.lbl_case(5001, 4, 12000, wnosamp=24, nlor=18, ndop=9, extent=80.0,
+                          cutoff=3.0, niso=2, seed=32, species=C4_SPECIES, vmr=C4_VMR,
+                          line_species=C4_LINES)
+    iso, atm = case['iso'], case['atm']
+    vt, ll, lbl = plan(eng, case, 4)
+    t, d, z = eng.dev(atm['temp']), eng.dev(atm['dens']), eng.dev(iso['isoz'])
+    for gather in ('staged', 'global'):
+        lbl.set_isoiext(iso['isoiext'])
+        lbl.set_gather_mode(gather)
+        full = host(lbl.extinction(t, d, z, add=False))
+        parts = [host(lbl.extinction(t, d, z, add=False, wbegin=a, wcount=b - a))
+                 for a, b in ((0, 1111), (1111, 4096), (4096, 5001))]
+        assert np.array_equal(np.concatenate(parts, axis=2), full), gather
+        off = iso['isoiext'].copy()
+        off[2:4] = -1                                      # CO off
+        lbl.set_isoiext(off)
+        part = host(lbl.extinction(t, d, z, add=False))
+        assert np.all(part[:, 1] == 0)
+        assert np.array_equal(part[:, [0, 2, 3]], full[:, [0, 2, 3]]), gather
+
+
+# ---------------------------------------------------------------------------
+# full-size configurations
+# ---------------------------------------------------------------------------
+FULL = {
+    # BASELINE.json configs[1]
+    'c2': dict(args=(100001, 80, 100000), kw=dict(wnstep=0.05, niso=1), layers=(0, 41, 79)),
+    # configs[2]: 1e6 wavenumbers, 1e6-line 4-isotope list
+    'c3': dict(args=(1000001, 80, 1000000), kw=dict(wnstep=0.005, niso=4), layers=(3, 76)),
+    # configs[3]: 1e6 wavenumbers x 120 layers, 4 species x 1e6 lines (single-GPU form)
+    'c4': dict(args=(1000001, 120, 1000000),
+               kw=dict(wnstep=0.005, niso=4, species=C4_SPECIES, vmr=C4_VMR,
+                       line_species=C4_LINES), layers=(10, 112)),
+}
+
+
+@pytest.mark.parametrize('name', ['c2', 'c3', 'c4'])
+def test_full_size_config(eng, orc, name, monkeypatch):
+    import torch
+    from pyratbay_amd import synth
+    cfg = FULL[name]
+    t0 = time.time()
+    case = synth.lbl_case(*cfg['args'], seed=42, **cfg['kw'])
+    g, atm, iso = case['grid'], case['atm'], case['iso']
+    nl, nw = atm['nlayers'], g['nwave']
+    vt, ll, lbl = plan(eng, case, nl)
+    t, d, z = eng.dev(atm['temp']), eng.dev(atm['dens']), eng.dev(iso['isoz'])
+    print(f'{name}: W={nw} L={nl} lines={ll.nlines} groups={ll.ngroups} '
+          f'isotopes={len(iso["isomass"])} set-up {time.time() - t0:.1f} s')
+
+    # (1) default kernel choice, twice: bitwise equal
+    full = lbl.extinction(t, d, z, add=True)
+    kernel = lbl.last_gather_kernel
+    again = lbl.extinction(t, d, z, add=True)
+    assert torch.equal(full, again), 'two runs differ'
+    del again
+    assert kernel.endswith('k_ext_staged'), kernel
+
+    # (2) wavenumber shards (8 uneven ones, as an 8-GPU run would cut them) with the same
+    # kernel and the same phase split forced (the split of a launch is a performance choice
+    # that changes the association of the per-sample sums): bit for bit
+    # the full-grid result
+    lbl.set_gather_mode('staged')
+    monkeypatch.setenv('PB_STAGE_SPLIT', '1')
+    ref_staged = lbl.extinction(t, d, z, add=True)
+    bounds = np.linspace(0, nw, 9).astype(int)
+    bounds[3] += 1717                                       # uneven, not tile-aligned
+    for a, b in zip(bounds[:-1], bounds[1:]):
+        part = lbl.extinction(t, d, z, add=True, wbegin=int(a), wcount=int(b - a))
+        assert torch.equal(part, ref_staged[:, :, a:b]), f'shard [{a},{b}) differs'
+        del part
+
+    monkeypatch.delenv('PB_STAGE_SPLIT')
+    # (3) staged vs global gather: same terms, different association
+    lbl.set_gather_mode('global')
+    glob = lbl.extinction(t, d, z, add=True)
+    assert lbl.last_gather_kernel.endswith('k_ext_resample')
+    assert torch.equal(glob == 0, ref_staged == 0)
+    rel = ((glob - ref_staged).abs() / ref_staged.abs().clamp_min(1e-300)).max().item()
+    assert rel <= 1e-12, rel
+    assert torch.equal(full == 0, ref_staged == 0)
+    rel_default = ((full - ref_staged).abs() / ref_staged.abs().clamp_min(1e-300)).max().item()
+    assert rel_default <= 1e-12, rel_default
+    del glob
+
+    # (4) oracle parity on sampled layers, full size
+    profile = vt.flat()
+    ec = host(full[list(cfg['layers'])])
+    worst = 0.0
+    for i, layer in enumerate(cfg['layers']):
+        t1 = time.time()
+        want = oracle_rows(orc, case, vt, profile, layer, True)
+        worst = max(worst, check(ec[i], want, f'{name} layer {layer}'))
+        print(f'{name}: layer {layer} oracle {time.time() - t1:.1f} s')
+    print(f'{name}: kernel {kernel}; shards exact; staged vs global {rel:.1e}; '
+          f'max rel err vs oracle on layers {cfg["layers"]} = {worst:.2e}')
+
+    if name == 'c4':
+        # one row per species on a few layers: per-row maxima, rows sum to the add=1 result
+        sub = [10, 60, 112]
+        lbl.set_gather_mode('auto')
+        ts, ds, zs = t[sub].contiguous(), d[sub].contiguous(), z[:, sub].contiguous()
+        rows = lbl.extinction(ts, ds, zs, add=False)
+        assert rows.shape == (3, 4, nw)
+        dens_rows = torch.stack([d[sub][:, 2 + r] for r in range(4)], dim=1)   # [3, 4]
+        total = (rows * dens_rows[:, :, None]).sum(dim=1)
+        want = full[sub][:, 0]
+        relr = ((total - want).abs() / want.abs().clamp_min(1e-300)).max().item()
+        assert relr <= 1e-12, relr
+        want0 = oracle_rows(orc, case, vt, profile, 10, False)
+        check(host(rows[0]), want0, 'c4 add=0 layer 10')
