@@ -39,6 +39,9 @@
 
 #include "pb_common.h"
 #include "pb_internal.h"
+#include "pb_ext_args.h"
+
+using namespace pbx;
 
 namespace {
 
@@ -51,114 +54,6 @@ constexpr int kTile = 4 * kWaveSpan;             // output samples per workgroup
 constexpr int kRecs = 4;                         // records in flight per wavefront trip
 static_assert(kTile <= kPmPad, "table padding must cover one tile");
 static_assert(kTile < 65536, "window coordinates are packed in 16 bits");
-
-// Record of the scatter kernel: everything one wavefront needs about a (layer, group) pair,
-// read with ONE scalar load.
-struct __attribute__((aligned(32))) Rec32 {
-    double k;            // co-added strength (before threshold / density)
-    long long off;       // table element read by output sample 0 (row start + q)
-    int ulo, uhi;        // window on the global output grid
-    int pad[2];
-};
-
-// Record of the staged kernel: 16 bytes per (layer, phase-sorted group).  The window end, the
-// row offset q and the phase follow from ulo, len, the cell's half-width and the group's
-// fine index (ph_iown), so they are not stored.
-struct __attribute__((aligned(16))) Rec16 {
-    double k;            // co-added strength (before threshold / density)
-    int32_t ulo;         // window start on the global output grid
-    uint32_t lc;         // window length (12 bits) | table cell << 12
-};
-
-struct LblArgs {
-    // Voigt table
-    const double *pm;
-    const double *flat;
-    const int64_t *pm_base;
-    const int32_t *pm_stride;
-    const int32_t *psize;
-    const int32_t *pindex;
-    const double *doppler;
-    const double *lorentz;
-    int ndop, nlor, osamp;
-    // lines and groups
-    const double *lwn, *elow, *gf;
-    const int32_t *lid;
-    const int32_t *gfirst, *gcount, *giown;
-    const int64_t *iso_gstart;
-    // the same groups sorted by (isotope, iown mod osamp, iown) for the staged kernel
-    const int32_t *ph_first, *ph_count, *ph_iown;
-    const int64_t *ph_start;          // [niso*(osamp+1)+1]
-    // coarse position index of the phase-sorted list: ph_bin[(iso*osamp + p)*(nbins+1) + b] =
-    // first entry of (iso, p) at or after fine position b * kBinSamples * osamp
-    const int32_t *ph_bin;
-    int ph_nbins;
-    int rowcap;                       // longest phase row of the table (samples)
-    int rowlds;                       // longest row (or row chunk) a staged LDS buffer holds
-    const int32_t *ph_iso;            // isotope of every phase-sorted group
-    const int32_t *giso;              // isotope of every position-sorted group
-    // group list that k_records walks (phase-sorted or position-sorted) and whether the
-    // gather kernel reads records (1) or derives them itself (0: resolution mode)
-    const int32_t *rk_first, *rk_count, *rk_iown, *rk_iso;
-    const double *rk_lwn, *rk_elow, *rk_gf;   // the leader line of every group, same order
-    const double *g_lead;             // leader lines in position order [3][ngroups]
-    int use_records;
-    int64_t ngroups;
-    // resident-profile kernel: which layers it computes, its LDS capacity (doubles, 0 = off)
-    // and, per isotope, the first position-sorted group at or after every output sample
-    int32_t *ls_resident;
-    int32_t *ls_block;                // largest phase-major profile block of the layer (doubles)
-    int res_cap;
-    const int32_t *gs_start;          // [niso][nwave+1]
-    // scatter kernel: one 32-byte record per (layer, position-sorted group)
-    struct Rec32 *rec32;
-    // staged kernel: packed records of the layers it computes (null: SoA records)
-    Rec16 *rec16;
-    // long phase rows (> kStageRowMax samples) are cut into nch_max chunks of kStageRowMax
-    // samples; every (group, chunk) then has its own packed record and the gather kernel
-    // treats (phase, chunk) as a phase of its own.  Layout of a layer's records:
-    // [phase p][chunk k][position] = ps*nch_max + k*cnt_p + (g - ps).  1 = no chunking.
-    int nch_max;
-    // staged kernel, small launches: the phases of a tile are split between nsplit workgroups
-    // (see the kernel's block decoding); split 0 writes ext, the others part[split-1][layer][row][sample]
-    int nsplit;
-    double *part;
-    // per (layer, phase-sorted group) records written by k_records [nlayers][ngroups]
-    double *rec_k;                    // co-added strength (before threshold / density)
-    int32_t *rec_ulo, *rec_uhi;       // window on the global output grid
-    int32_t *rec_q;                   // row index = output sample + q
-    int32_t *rec_cell, *rec_phi;      // table cell and phase row
-    double inv_osamp;
-    int64_t nlines;
-    // static species data
-    const double *molrad, *molmass;
-    const int32_t *isoimol, *isoiext;
-    const double *isomass, *isoratio;
-    const int32_t *divisors;
-    int nmol, niso, ndivs;
-    // per-call inputs
-    const double *temp, *dens, *isoz;
-    int64_t z_iso_stride, z_layer_stride;
-    // layer state (workspace)
-    int32_t *ls_ofactor, *ls_scale;
-    int64_t *ls_dnwn;
-    double *ls_dwnstep;
-    double *li_alphad, *li_dens, *li_z;
-    int32_t *li_ilor, *li_hmax;
-    int32_t *li_rowmax;               // longest phase row the (layer, isotope) can select
-    int32_t *li_hlo, *li_hhi;         // smallest / largest profile half-width it can select
-    unsigned long long *kmax_bits;
-    // grid
-    const double *wn;
-    double own0, own_last, ownstep, wnstep, wn0;
-    int64_t onwn;
-    double cutoff, ethresh;
-    int add, nrows, nlayers, nwave;
-    int64_t wbegin, wcount;
-    int ntiles;
-    int experiment;      // diagnostics only (PB_EXPERIMENT): 1 = every record reads one slice
-    double *ext;
-};
 
 // Line strength divided by the abundance (_extcoeff.c:219-224), same operation order.
 __device__ inline double line_strength(double ratio, double gf, double elow, double wavn,
@@ -303,19 +198,6 @@ __global__ __launch_bounds__(kBlock) void k_kmax(LblArgs a, int lines_per_block)
 // ---------------------------------------------------------------------------
 // helpers for the gather kernels
 // ---------------------------------------------------------------------------
-__device__ inline int64_t lower_bound_i32(const int32_t *a, int64_t lo, int64_t hi, int64_t v)
-{
-    // first index in [lo,hi) with a[idx] >= v
-    while (lo < hi) {
-        int64_t mid = (lo + hi) >> 1;
-        if (a[mid] < v)
-            lo = mid + 1;
-        else
-            hi = mid;
-    }
-    return lo;
-}
-
 __device__ inline double bcast(double v, int lane)
 {
     int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
@@ -598,13 +480,6 @@ __global__ __launch_bounds__(NW * 64) void k_ext_resample(LblArgs a)
 // the global grid -- is computed ONCE here (coalesced, no workgroup synchronisation) and
 // streamed by the gather kernel; the per-row maximum strength (k_kmax) is fused in.
 // ---------------------------------------------------------------------------
-// floor(a / d) for |a| < 2^31 and 0 < d < 2^20, with inv = 1.0/d: (a + 0.5)/d is never an
-// integer, so the product cannot round across one.
-__device__ inline int floor_div_inv(int a, double inv)
-{
-    return (int)floor(((double)a + 0.5) * inv);
-}
-
 constexpr int kChunkRow = 1024;      // samples per chunk of a long phase row (= kStageRowMax)
 constexpr int kRecLayers = 4;        // layers per thread of k_records (group data loaded once);
                                      // 1 for launches of few layers (multi-GPU ranks)
@@ -760,10 +635,6 @@ __global__ __launch_bounds__(kBlock) void k_records(LblArgs a)
 // A lane owns the samples rlo + 64*c + lane (c < 4*G); a wavefront tests a record's
 // window against groups of 4 chunks with scalar compares.
 // ---------------------------------------------------------------------------
-constexpr int kBinSamples = 256;     // output samples per bin of the phase-list position index
-constexpr int kStagePad = 256;       // zero samples on either side of a staged row
-constexpr int kStageSpan = 256;      // samples per wavefront and sub-tile (4 chunks of 64)
-constexpr int kStageRowMax = 1024;   // longest phase row the kernel stages
 
 // NW wavefronts per workgroup, S sub-tiles of NW*256 samples each (tile = S*NW*256); one
 // record per thread per batch.
@@ -1919,6 +1790,16 @@ struct pb_lbl {
     // optional per-launch timing of the gather kernel (bench.py's roofline figure)
     std::vector<hipEvent_t> ev;      // start/stop pairs
     int ev_used = 0;
+    // round-staged gather (pb_rounds.hip): per-unit capacities (cached per launch geometry)
+    // and the visit-record / segment / header lists
+    int64_t *unit_cap = nullptr;
+    int64_t cap_key[5] = {-1, -1, -1, -1, -1};   // wbegin, wcount, tile, nsplit, total
+    VRec *vrec = nullptr;
+    VSeg *vseg = nullptr;
+    int32_t *vrnd = nullptr;
+    size_t vrec_alloc = 0;            // entries
+    UnitHdr *uhdr = nullptr;
+    size_t uhdr_alloc = 0;
     LblArgs last_args;               // arguments of the last launch (pb_lbl_last_work)
     bool last_packed = false;        // ... whose records are packed, one per (layer, group)
 };
@@ -2280,6 +2161,8 @@ int pb_lbl_create(pb_lbl **out, pb_voigt *voigt, pb_lines *lines, const double *
             p->gather_mode = 3;
         else if (e && !strcmp(e, "scatter"))
             p->gather_mode = 4;
+        else if (e && !strcmp(e, "rounds"))
+            p->gather_mode = 5;
         const char *t = getenv("PB_STAGE_THRESHOLD");
         if (t)
             p->stage_threshold = atof(t);
@@ -2306,7 +2189,7 @@ int pb_lbl_set_isoiext(pb_lbl *p, const int32_t *isoiext_h)
 
 int pb_lbl_set_gather_mode(pb_lbl *p, int mode)
 {
-    PB_REQUIRE(p && mode >= 0 && mode <= 4, "pb_lbl_set_gather_mode: mode must be 0..4");
+    PB_REQUIRE(p && mode >= 0 && mode <= 5, "pb_lbl_set_gather_mode: mode must be 0..5");
     p->gather_mode = mode;
     return PB_OK;
 }
@@ -2487,7 +2370,9 @@ int pb_lbl_extinction(pb_lbl *p, double *ext_d, int64_t wbegin, int64_t wcount,
     if (const char *e = getenv("PB_STAGE_SPLIT"))
         nsplit = std::max(1, std::min(8, atoi(e)));
     const bool enough_blocks = pb::div_up(wcount, S * sub) * (int64_t)nlayers * nsplit >= 750;
-    const bool staged = can_stage && (p->gather_mode == 2 ||
+    // round-staged kernel (pb_rounds.hip): rows of one piece (<= 1024 samples), packed records
+    const bool rounds = can_stage && a.nch_max == 1 && packable && p->gather_mode == 5;
+    const bool staged = can_stage && (p->gather_mode == 2 || rounds ||
                                       (p->gather_mode == 0 && enough_blocks &&
                                        per_phase >= p->stage_threshold));
     const bool use_records = !p->resolution && l->ngroups > 0;
@@ -2589,7 +2474,7 @@ int pb_lbl_extinction(pb_lbl *p, double *ext_d, int64_t wbegin, int64_t wcount,
     const bool timed = p->ev_used + 2 <= (int)p->ev.size();
     if (timed)
         PB_HIP(hipEventRecord(p->ev[p->ev_used], s));
-    p->last_gather = scatter ? 4 : (p->resolution ? 3 : staged ? 2 : 1) + (resident ? 8 : 0);
+    p->last_gather = scatter ? 4 : (p->resolution ? 3 : rounds ? 5 : staged ? 2 : 1) + (resident ? 8 : 0);
     if (scatter) {
         int T = 512;
         if (const char *e = getenv("PB_SCATTER_T"))
@@ -2621,6 +2506,122 @@ int pb_lbl_extinction(pb_lbl *p, double *ext_d, int64_t wbegin, int64_t wcount,
         a.ntiles = pb::div_up(wcount, kBlock);
         dim3 grid((unsigned)(8 * a.ntiles * layer_groups), a.nrows);
         k_ext_linterp<<<grid, kBlock, 0, s>>>(a);
+    } else if (rounds) {
+        // geometry: 16 wavefronts x 2 spans of 256 samples (tile 8192, two LDS buffers of 8192
+        // samples, one workgroup per CU) or 8 x 2 (tile 4096, buffers of 4096, two per CU)
+        int geom = 2;
+        if (const char *e = getenv("PB_ROUNDS_GEOM"))
+            geom = std::max(0, std::min(7, atoi(e)));
+        int T = 0;
+        rounds_geometry(geom, &T, &a.rbuf);
+        a.rtile = T;
+        a.ntiles = pb::div_up(wcount, T);
+        int rsplit = (int)std::min<int64_t>(
+            8, pb::div_up((int64_t)(per_phase >= 64.0 ? 4000 : 1000),
+                          std::max<int64_t>(1, (int64_t)a.ntiles * nlayers)));
+        if (const char *e = getenv("PB_STAGE_SPLIT"))
+            rsplit = std::max(1, std::min(8, atoi(e)));
+        {
+            const int64_t plane = (int64_t)nlayers * a.nrows * wcount * 8;
+            while (rsplit > 1 && (rsplit - 1) * plane > ((int64_t)1 << 30))
+                rsplit--;
+        }
+        a.nsplit = rsplit;
+        if (rsplit > 1) {
+            const size_t need = (size_t)(rsplit - 1) * nlayers * a.nrows * wcount * 8;
+            if (need > p->part_bytes) {
+                (void)hipFree(p->part);
+                p->part = nullptr;
+                p->part_bytes = 0;
+                if (hipMalloc(&p->part, need) != hipSuccess) {
+                    pb::set_error("pb_lbl_extinction: cannot allocate %zu B of partial sums", need);
+                    return PB_ERR_NOMEM;
+                }
+                p->part_bytes = need;
+            }
+            a.part = p->part;
+        }
+        // the largest distance from which a group can reach a tile, over all layers
+        int64_t hmax_all = 0;
+        for (int32_t h : v->psize)
+            hmax_all = std::max<int64_t>(hmax_all, h);
+        int64_t reachmax = hmax_all;
+        if (a.cutoff > 0.0)
+            reachmax = std::min(reachmax, (int64_t)(a.cutoff / a.ownstep) + 2 * (int64_t)v->osamp + 2);
+        reachmax += 2 * (int64_t)v->osamp;
+        a.reachmax = reachmax;
+        const int nunits = a.ntiles * rsplit;
+        if (p->cap_key[0] != wbegin || p->cap_key[1] != wcount || p->cap_key[2] != T ||
+            p->cap_key[3] != rsplit) {
+            // capacity of every unit: the groups (any isotope) within reach of its tile
+            std::vector<int64_t> cap((size_t)nunits + 1, 0);
+            for (int t = 0; t < a.ntiles; t++) {
+                const int64_t t0 = wbegin + (int64_t)t * T;
+                const int64_t tend = std::min(t0 + T, wbegin + wcount);
+                const int64_t flo = t0 * v->osamp - reachmax, fhi = (tend - 1) * v->osamp + reachmax;
+                int64_t n = 0;
+                for (int i = 0; i < p->niso; i++) {
+                    const int32_t *b = l->h_giown.data() + l->iso_gstart[i];
+                    const int32_t *e = l->h_giown.data() + l->iso_gstart[i + 1];
+                    n += std::upper_bound(b, e, (int32_t)std::min<int64_t>(fhi, INT_MAX)) -
+                         std::lower_bound(b, e, (int32_t)std::max<int64_t>(flo, INT_MIN));
+                }
+                n = (n + 3) & ~(int64_t)3;
+                for (int z = 0; z < rsplit; z++)
+                    cap[(size_t)t * rsplit + z + 1] = n;
+            }
+            for (int u = 0; u < nunits; u++)
+                cap[(size_t)u + 1] += cap[(size_t)u];
+            PB_HIP(hipStreamSynchronize(s));       // an earlier call may still read the lists
+            (void)hipFree(p->unit_cap);
+            p->unit_cap = nullptr;
+            PB_HIP(hipMalloc(&p->unit_cap, cap.size() * 8));
+            PB_HIP(hipMemcpy(p->unit_cap, cap.data(), cap.size() * 8, hipMemcpyHostToDevice));
+            p->cap_key[0] = wbegin;
+            p->cap_key[1] = wcount;
+            p->cap_key[2] = T;
+            p->cap_key[3] = rsplit;
+            p->cap_key[4] = cap.back();
+        }
+        const size_t nent = (size_t)nlayers * a.nrows * (size_t)p->cap_key[4] + 4;
+        if (nent > p->vrec_alloc) {
+            PB_HIP(hipStreamSynchronize(s));
+            (void)hipFree(p->vrec);
+            (void)hipFree(p->vseg);
+            (void)hipFree(p->vrnd);
+            p->vrec = nullptr;
+            p->vseg = nullptr;
+            p->vrnd = nullptr;
+            p->vrec_alloc = 0;
+            if (hipMalloc(&p->vrec, nent * 16) != hipSuccess ||
+                hipMalloc(&p->vseg, nent * 16) != hipSuccess ||
+                hipMalloc(&p->vrnd, nent * 4) != hipSuccess) {
+                pb::set_error("pb_lbl_extinction: cannot allocate %zu B of visit records", nent * 32);
+                return PB_ERR_NOMEM;
+            }
+            p->vrec_alloc = nent;
+        }
+        const size_t nhdr = (size_t)nlayers * a.nrows * nunits;
+        if (nhdr > p->uhdr_alloc) {
+            PB_HIP(hipStreamSynchronize(s));
+            (void)hipFree(p->uhdr);
+            p->uhdr = nullptr;
+            PB_HIP(hipMalloc(&p->uhdr, nhdr * 16));
+            p->uhdr_alloc = nhdr;
+        }
+        a.unit_cap = p->unit_cap;
+        a.vrec = p->vrec;
+        a.vseg = p->vseg;
+        a.vrnd = p->vrnd;
+        a.uhdr = p->uhdr;
+        int rc = rounds_launch(a, geom, s);
+        if (rc != PB_OK)
+            return rc;
+        if (rsplit > 1) {
+            const int64_t n = (int64_t)nlayers * a.nrows * wcount;
+            k_combine_parts<<<(unsigned)pb::div_up(n, kBlock), kBlock, 0, s>>>(ext_d, p->part,
+                                                                             rsplit - 1, n);
+        }
     } else if (staged) {
         a.nsplit = nsplit;
         if (nsplit > 1) {
@@ -2810,6 +2811,11 @@ void pb_lbl_destroy(pb_lbl *p)
     (void)hipFree(p->li_hlo);
     (void)hipFree(p->li_hhi);
     (void)hipFree(p->kmax_bits);
+    (void)hipFree(p->unit_cap);
+    (void)hipFree(p->vrec);
+    (void)hipFree(p->vseg);
+    (void)hipFree(p->vrnd);
+    (void)hipFree(p->uhdr);
     (void)hipFree(p->ph_first);
     (void)hipFree(p->ph_count);
     (void)hipFree(p->ph_iown);

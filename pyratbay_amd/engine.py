@@ -168,7 +168,7 @@ class LBL:
     def set_ethresh(self, ethresh):
         call('pb_lbl_set_ethresh', self._h, float(ethresh))
 
-    GATHER = {'auto': 0, 'global': 1, 'staged': 2, 'resident': 3, 'scatter': 4}
+    GATHER = {'auto': 0, 'global': 1, 'staged': 2, 'resident': 3, 'scatter': 4, 'rounds': 5}
 
     def set_gather_mode(self, mode):
         """'auto' | 'global' | 'staged' | 'resident' (see pbhip.h: pb_lbl_set_gather_mode)."""
@@ -179,7 +179,7 @@ class LBL:
         m = C.c_int(0)
         call('pb_lbl_last_gather_mode', self._h, C.byref(m))
         base = {0: None, 1: 'k_ext_resample', 2: 'k_ext_staged', 3: 'k_ext_linterp',
-                4: 'k_ext_scatter'}[m.value & 7]
+                4: 'k_ext_scatter', 5: 'k_ext_rounds'}[m.value & 7]
         return 'k_ext_resident+' + base if m.value & 8 else base
 
     def extinction(self, temp, dens, isoz, add=True, out=None, wbegin=0, wcount=None):

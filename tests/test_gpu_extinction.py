@@ -46,7 +46,7 @@ def build(eng, c, resolution, table_from_oracle, orc, ethresh=1e-30, cutoff=None
 
 @pytest.mark.parametrize('mode,gather', [('step', 'global'), ('step', 'staged'),
                                          ('step', 'resident'), ('step', 'scatter'),
-                                         ('step', 'auto'),
+                                         ('step', 'rounds'), ('step', 'auto'),
                                          ('res', 'auto')])
 @pytest.mark.parametrize('own_table', [False, True])
 def test_g2_extinction_golden(eng, golden, orc, mode, own_table, gather):
@@ -83,7 +83,7 @@ def test_g2_extinction_golden(eng, golden, orc, mode, own_table, gather):
     assert ll.nadd > 0
     want_kernel = {'global': ('k_ext_resample',), 'staged': ('k_ext_staged',),
                    'resident': ('k_ext_resident+k_ext_resample',),
-                   'scatter': ('k_ext_scatter',),
+                   'scatter': ('k_ext_scatter',), 'rounds': ('k_ext_rounds',),
                    'auto': ('k_ext_linterp',) if mode == 'res' else
                            ('k_ext_resident+k_ext_resample', 'k_ext_resident+k_ext_staged')}[gather]
     assert lbl.last_gather_kernel in want_kernel
@@ -122,7 +122,7 @@ def test_groups_match_oracle_counters(eng, orc):
     assert np.all(kmax > 0)
 
 
-@pytest.mark.parametrize('gather', ['global', 'staged', 'resident', 'scatter'])
+@pytest.mark.parametrize('gather', ['global', 'staged', 'resident', 'scatter', 'rounds'])
 @pytest.mark.parametrize('nwave,nlines,niso', [(2, 1, 1), (65, 40, 1), (1025, 3000, 2),
                                                (4097, 20000, 4), (9001, 60000, 2)])
 def test_synthetic_cases_vs_oracle(eng, orc, nwave, nlines, niso, gather):
@@ -158,7 +158,7 @@ def test_synthetic_cases_vs_oracle(eng, orc, nwave, nlines, niso, gather):
     print(f'W={nwave} N={nlines} {gather}: max rel err vs oracle (same table) = {worst:.2e}')
 
 
-@pytest.mark.parametrize('gather', ['global', 'staged', 'resident', 'scatter'])
+@pytest.mark.parametrize('gather', ['global', 'staged', 'resident', 'scatter', 'rounds'])
 def test_wavenumber_shards_concatenate(eng, orc, gather):
     """Shards [wbegin, wbegin+wcount) of the global grid reproduce the full spectrum
     bit for bit (no exchange between shards)."""
@@ -306,13 +306,15 @@ def test_random_configurations(eng, orc, seed):
     a = int(rng.integers(0, g['nwave']))
     b = int(rng.integers(a, g['nwave'])) + 1
     out = {}
-    for mode in ('global', 'staged'):
+    for mode in ('global', 'staged', 'rounds'):
         lbl.set_gather_mode(mode)
         out[mode] = host(lbl.extinction(t, d, z, add=True))
         out[mode + '_shard'] = host(lbl.extinction(t, d, z, add=True, wbegin=a, wcount=b - a))
         assert np.array_equal(out[mode + '_shard'], out[mode][:, :, a:b]), mode
     assert np.array_equal(out['staged'] == 0, out['global'] == 0)
     np.testing.assert_allclose(out['staged'], out['global'], rtol=1e-12)
+    assert np.array_equal(out['rounds'] == 0, out['global'] == 0)
+    np.testing.assert_allclose(out['rounds'], out['global'], rtol=1e-12)
     profile = vt.flat()
     for layer in sorted(set([0, nlayers // 2, nlayers - 1])):
         want = np.zeros((1, g['nwave']))

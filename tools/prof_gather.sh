@@ -1,0 +1,16 @@
+#!/bin/bash
+# usage: tools/prof_gather.sh <tag> <workload> [steps] -- rocprofv3 kernel stats of one configuration
+# (environment selects the gather kernel); prints the top kernels
+tag=$1; wl=${2:-c2}; steps=${3:-5}
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+out=gpurun_out/prof_$tag
+rm -rf $out; mkdir -p $out
+rocprofv3 --kernel-trace --stats --output-format csv -d $out -- python tools/bench_stages.py $wl $steps > $out/run.log 2>&1
+f=$(find $out -name '*kernel_stats.csv' | head -1)
+python - "$f" <<'PY'
+import csv, sys
+rows = list(csv.DictReader(open(sys.argv[1])))
+rows.sort(key=lambda r: -float(r['TotalDurationNs']))
+for r in rows[:8]:
+    print(f"{r['Name'][:70]:70s} calls {r['Calls']:>5s} avg {float(r['AverageNs'])/1e3:9.1f} us  {float(r['Percentage']):5.1f}%")
+PY
