@@ -321,6 +321,42 @@ int pb_band_integrate(double *bandflux_d, const double *spectrum_d, const double
                       const double *response_d, const int64_t *response_offset_d,
                       int nbands, int64_t wbegin, int64_t wcount, void *stream);
 
+/* =========================================================================
+ * Walker-batched retrieval path (BASELINE config 5): one launch per stage for nwalkers models,
+ * no per-walker host work.  Reference inner loop: pyratbay/pyrat/pyrat_obj.py:225-385.
+ * ========================================================================= */
+/* atmosphere.transit_path (pyratbay/atmosphere/atmosphere.py:782-802) on the device:
+ * radius_d[nwalkers,nlayers] -> raypath_d[nwalkers, n(n-1)/2], n = nlayers - itop, the packed
+ * lower triangle pb_optical_depth_transit takes. */
+int pb_transit_path(double *raypath_d, const double *radius_d, int itop, int nlayers,
+                    int nwalkers, void *stream);
+/* interp_ec (src_c/_extcoeff.c:367-418), assigning form, for a batch: temps_d[nwalkers,nlayers],
+ * density_d[nwalkers,nlayers,nmol] -> ec_d[nwalkers,nlayers,nwave].  The table is read once per
+ * chunk of walkers.  work_d: nwalkers*nlayers*20 bytes of device scratch.  nmol <= 8. */
+int pb_interp_ec_batch(double *ec_d, const double *etable_d, const double *ttable_d,
+                       const double *temps_d, const double *density_d, void *work_d, int nmol,
+                       int ntemp, int nlayers, int nwave, int nwalkers, void *stream);
+/* optic_depth.py:103-112 + radiative_transfer.py:57-71 (no cloud deck) for a batch:
+ * ec_d[nwalkers,nlayers,nwave], raypath_d[nwalkers, n(n-1)/2], radius_d[nwalkers,nlayers] ->
+ * spectrum_d[nwalkers,nwave]; depth_d[nwalkers,nlayers,nwave] and ideep_d[nwalkers,nwave] are
+ * optional (NULL: not stored). */
+int pb_transit_spectrum_batch(double *spectrum_d, double *depth_d, int32_t *ideep_d,
+                              const double *ec_d, const double *raypath_d,
+                              const double *radius_d, double rstar, int itop, int ibottom,
+                              double maxdepth, int nlayers, int nwave, int nwalkers,
+                              void *stream);
+/* PassBand.integrate for a batch of full-grid spectra: bandflux_d[nwalkers,nbands]
+ * (x heights_d[b] when given). */
+int pb_band_integrate_batch(double *bandflux_d, const double *spectrum_d, const double *wn_d,
+                            const int32_t *band_start_d, const int32_t *band_count_d,
+                            const double *response_d, const int64_t *response_offset_d,
+                            const double *heights_d, int nbands, int nwave, int nwalkers,
+                            void *stream);
+/* eval()'s reject path (pyrat_obj.py:302-320, 378-380): walkers with a temperature outside
+ * [tmin, tmax] get bandflux = +inf. */
+int pb_reject_walkers(double *bandflux_d, const double *temps_d, double tmin, double tmax,
+                      int nlayers, int nbands, int nwalkers, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

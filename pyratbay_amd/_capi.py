@@ -52,6 +52,11 @@ _PROTOS = {
     'pb_lbl_destroy': [vp],
     'pb_interp_ec': [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp],
     'pb_interp_ec_set': [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp],
+    'pb_transit_path': [vp, vp, i32, i32, i32, vp],
+    'pb_interp_ec_batch': [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp],
+    'pb_transit_spectrum_batch': [vp, vp, vp, vp, vp, vp, f64, i32, i32, f64, i32, i32, i32, vp],
+    'pb_band_integrate_batch': [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp],
+    'pb_reject_walkers': [vp, vp, f64, f64, i32, i32, i32, vp],
     'pb_optdepth': [vp, vp, i64, vp, i32, f64, vp, i32, i32, vp],
     'pb_optical_depth_transit': [vp, vp, vp, vp, i32, i32, f64, i32, i32, vp],
     'pb_transit_spectrum': [vp, vp, vp, vp, vp, vp, f64, i32, i32, f64, i32, i32, vp],
@@ -112,10 +117,22 @@ def lib():
             fn.argtypes = args
             fn.restype = _RESTYPES.get(name, C.c_int)
         _lib = handle
+        global _owner_pid
+        _owner_pid = os.getpid()
     return _lib
 
 
+_owner_pid = None
+
+
 def call(name, *args):
+    # The reference parallelises with fork (pyrat/line_by_line.py:232-246, ncpu > 1).  A
+    # forked child of a process that has initialised HIP cannot use the GPU (and on this
+    # platform must not try): fail loudly instead of hanging or faulting.
+    if _owner_pid is not None and os.getpid() != _owner_pid:
+        raise PbError(f'{name}: called in a forked child (pid {os.getpid()}) of the process '
+                      f'that initialised the GPU (pid {_owner_pid}); the HIP path needs '
+                      'ncpu = 1 -- it batches all layers in one call instead of forking')
     fn = getattr(lib(), name)
     rc = fn(*args)
     if name not in _NO_CHECK and rc != PB_OK:

@@ -8,7 +8,15 @@
 // src_c/_blackbody.c:35-130, src_c/_simpson.c:167-203, src_c/cutils.c:27-42 and the
 // Python loops pyratbay/opacity/optic_depth.py:103-112,
 // pyratbay/spectrum/radiative_transfer.py:57-71, pyratbay/pyrat/spectrum.py:366-377.
+#include <cstdlib>
+
 #include "pb_common.h"
+
+int pb_transit_fused_launch(double *depth_d, int32_t *ideep_d, double *spectrum_d,
+                            const double *ec_d, const double *raypath_d, const double *radius_d,
+                            int64_t npath, double rstar, int itop, int ibottom, double maxdepth,
+                            int nlayers, int nwave, int nwalkers, int deck_row, double rsurf,
+                            hipStream_t s);
 
 namespace {
 
@@ -664,6 +672,19 @@ static int transit_launch(double *depth_d, int32_t *ideep_d, double *spectrum_d,
     const int nrow = nlayers - itop;
     PB_REQUIRE(nrow == 1 || raypath_d, "%s: null raypath", who);
     PB_REQUIRE(!spectrum_d || radius_d, "%s: null radius", who);
+    // radiative_transfer.py:63: the deck matters only when it lies below the top layer
+    const int deck_row0 = deck_itop > itop ? deck_itop - itop : -1;
+    // One spectrum: two kernels (tau for every row with grid.y over blocks of impact parameters,
+    // then the early exit): a single grid of columns has too few wavefronts for the fused
+    // one-pass kernel of pb_batch.hip (C2: 155 us fused against 97 us), which is what the
+    // walker-batched path uses.  PB_TRANSIT=fused|split forces one form (tests compare them).
+    const char *mode = getenv("PB_TRANSIT");
+    const bool fused = mode ? !strcmp(mode, "fused") : nwave >= (1 << 21);
+    if (fused)
+        return pb_transit_fused_launch(depth_d, ideep_d, spectrum_d, ec_d, raypath_d, radius_d,
+                                       ((int64_t)nrow * (nrow - 1)) / 2, rstar, itop, ibottom,
+                                       maxdepth, nlayers, nwave, 1, deck_row0, deck_rsurf,
+                                       pb::as_stream(stream));
     const bool narrow = nwave <= kNarrowColumns;
     const int rows = narrow ? kRowsPerThreadNarrow : kRowsPerThread;
     const int threads = narrow ? 64 : kBlock;

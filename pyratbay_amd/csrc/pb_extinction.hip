@@ -1710,6 +1710,12 @@ __global__ __launch_bounds__(kBlock) void k_interp_ec(
     int tlo = pb::nearest_index(ttable, t, 0, ntemp - 1);
     if (t < ttable[tlo] || tlo == ntemp - 1)
         tlo--;
+    // A temperature below the table makes the reference read ttable[-1] and etable at a
+    // negative offset (_extcoeff.c:394-398; its callers reject such models first,
+    // line_sampling.py:426-427).  Here the bracket is clamped -- in-range results are
+    // unchanged, an out-of-range layer extrapolates from the first interval -- so a
+    // caller that forgot the check gets numbers instead of a GPU fault.
+    tlo = max(tlo, 0);
     const int thi = tlo + 1;
     const double span = ttable[thi] - ttable[tlo];
     const double w_lo = (ttable[thi] - t) / span;

@@ -191,6 +191,16 @@ class LayerShardedTransit:
         self.buffers = (torch.zeros((world, self.lp, wp), dtype=torch.float64, device='cuda'),
                         torch.empty((world, self.lp, wp), dtype=torch.float64, device='cuda'))
         self.lbl = self.model.lbl
+        self._idx = idx
+
+    def set_atmosphere(self, temp, dens, isoz, radius=None):
+        """New atmosphere for the next step()/submit(): forwards to the model (radius, ray
+        paths, full-grid state) and refreshes this rank's layer slices IN PLACE, so the
+        pipeline's buffers and any captured pointers stay valid."""
+        self.model.set_atmosphere(temp, dens, isoz, radius)
+        self.temp.copy_(self.model.temp[self._idx])
+        self.dens.copy_(self.model.dens[self._idx])
+        self.isoz.copy_(self.model.isoz[:, self._idx])
 
     def step(self):
         m, e = self.model, self.engine

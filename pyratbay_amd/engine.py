@@ -265,6 +265,47 @@ def pack_raypath(raypath, itop):
     return np.concatenate(rows) if rows else np.empty(0)
 
 
+def transit_path_device(radius, itop=0):
+    """atmosphere.transit_path on the device: radius[L] or [nw, L] (device) -> packed lower
+    triangle [n(n-1)/2] or [nw, n(n-1)/2], n = L - itop (pb_transit_path)."""
+    rad = radius if radius.dim() == 2 else radius.view(1, -1)
+    nw, nlayers = rad.shape
+    n = nlayers - itop
+    out = torch.empty((nw, (n * (n - 1)) // 2), dtype=torch.float64, device=rad.device)
+    call('pb_transit_path', _ptr(out), _ptr(rad.contiguous()), int(itop), nlayers, nw, _stream())
+    return out if radius.dim() == 2 else out[0]
+
+
+def interp_ec_batch(etable, ttable, temps, dens, out=None):
+    """interp_ec for a batch of walkers (assigning): temps[nw, L], dens[nw, L, S] ->
+    ec[nw, L, W]; the table is read once per chunk of walkers."""
+    nmol, ntemp, nlayers, nwave = etable.shape
+    nw = temps.shape[0]
+    assert temps.shape == (nw, nlayers) and dens.shape == (nw, nlayers, nmol)
+    if out is None:
+        out = torch.empty((nw, nlayers, nwave), dtype=torch.float64, device=etable.device)
+    work = torch.empty(nw * nlayers * 20 // 8 + 8, dtype=torch.float64, device=etable.device)
+    call('pb_interp_ec_batch', _ptr(out), _ptr(etable), _ptr(ttable), _ptr(temps.contiguous()),
+         _ptr(dens.contiguous()), _ptr(work), nmol, ntemp, nlayers, nwave, nw, _stream())
+    return out
+
+
+def transit_spectrum_batch(ec, raypath, radius, rstar, itop, ibottom, maxdepth,
+                           want_depth=False):
+    """optical depth + transmission for a batch: ec[nw, L, W], raypath[nw, npath],
+    radius[nw, L] -> spectrum[nw, W] (and depth[nw, L, W], ideep[nw, W] when asked for)."""
+    nw, nlayers, nwave = ec.shape
+    spectrum = torch.empty((nw, nwave), dtype=torch.float64, device=ec.device)
+    depth = ideep = None
+    if want_depth:
+        depth = torch.empty_like(ec)
+        ideep = torch.empty((nw, nwave), dtype=torch.int32, device=ec.device)
+    call('pb_transit_spectrum_batch', _ptr(spectrum), _ptr(depth), _ptr(ideep), _ptr(ec),
+         _ptr(raypath), _ptr(radius), float(rstar), int(itop), int(ibottom), float(maxdepth),
+         nlayers, nwave, nw, _stream())
+    return (spectrum, depth, ideep) if want_depth else spectrum
+
+
 # --------------------------------------------------------------------------
 # Column stages (device tensors in, device tensors out)
 # --------------------------------------------------------------------------
@@ -459,6 +500,16 @@ class PassBands:
              self.nbands, int(wbegin), int(wcount), _stream())
         return self.partial
 
+    def integrate_batch(self, spectra, out=None):
+        """Band fluxes (heights applied) of full-grid spectra[nw, W] -> [nw, nbands]."""
+        nw, nwave = spectra.shape
+        if out is None:
+            out = torch.empty((nw, self.nbands), dtype=torch.float64, device=spectra.device)
+        call('pb_band_integrate_batch', _ptr(out), _ptr(spectra), _ptr(self.wn),
+             _ptr(self.start), _ptr(self.count), _ptr(self.response), _ptr(self.offset),
+             _ptr(self.heights), self.nbands, nwave, nw, _stream())
+        return out
+
 
 # --------------------------------------------------------------------------
 # Whole-path model: the three timed stages of Pyrat.run() (pyrat_obj.py:203-214)
@@ -496,7 +547,9 @@ class LBLSpectrum:
                        atm['mol_mass'], iso['isoimol'], iso['isomass'], iso['isoratio'],
                        iso['isoiext'], vg['cutoff'], case['ethresh'],
                        max_layers=self.nlayers)
-        # atmosphere state, resident
+        # atmosphere state, resident (+ the host copy of the temperatures that the continuum
+        # terms take their per-layer factors from)
+        self.temp_host = np.array(atm['temp'], float)
         self.temp = dev(atm['temp'])
         self.dens = dev(atm['dens'])
         self.isoz = dev(iso['isoz'])
@@ -527,10 +580,20 @@ class LBLSpectrum:
                               device='cuda')
         self.depth = self.ideep = self.spectrum = None
 
-    def set_atmosphere(self, temp, dens, isoz, radius=None):
+    def set_atmosphere(self, temp, dens, isoz, radius=None, continuum_density=None):
+        """New temperature / number-density / partition-function (and radius) profiles for the
+        next run().  With a Continuum attached pass its number densities {species: n[L]} too:
+        every opacity term of the next run then sees the SAME atmosphere."""
+        self.temp_host = np.array(temp.cpu().numpy() if isinstance(temp, torch.Tensor) else temp,
+                                  float)
         self.temp.copy_(dev(temp))
         self.dens.copy_(dev(dens))
         self.isoz.copy_(dev(isoz))
+        if continuum_density is not None:
+            self.continuum_density = continuum_density
+        elif self.continuum is not None:
+            raise _capi.PbError('set_atmosphere: this model has continuum terms, pass their '
+                                'number densities (continuum_density) with the new atmosphere')
         if radius is not None:
             self.radius.copy_(dev(radius))
             if self.rt_path == 'transit':
@@ -543,7 +606,7 @@ class LBLSpectrum:
         self.lbl.extinction(self.temp, self.dens, self.isoz, add=True, out=self.ec,
                             wbegin=self.wbegin, wcount=self.wcount)
         if self.continuum is not None:
-            self.continuum.add(self.ec.view(self.nlayers, self.wcount), self.case['atm']['temp'],
+            self.continuum.add(self.ec.view(self.nlayers, self.wcount), self.temp_host,
                                self.continuum_density)
         return self.ec
 
@@ -642,12 +705,21 @@ class TableSpectrum:
         line_sampling.py:426-427), dens[L, nspec] (molecules cm-3) -> spectrum[W].
         With a Continuum attached, continuum_density = {species: n[L]} feeds its terms
         (pyrat/opacity.py:206-257: every model adds to the same ec)."""
+        temp_host = None if isinstance(temp, torch.Tensor) else np.asarray(temp, float)
+        if temp_host is not None and (np.any(temp_host < self.tmin) or
+                                      np.any(temp_host > self.tmax)):
+            raise ValueError(f'temperature outside the {self.tmin:.1f}-{self.tmax:.1f} '
+                             'K range of the table (the reference rejects such a model, '
+                             'line_sampling.py:426-427)')
         self.temp = temp if isinstance(temp, torch.Tensor) else dev(temp)
         dens = dens if isinstance(dens, torch.Tensor) else dev(dens)
         interp_ec(self.ec, self.etable, self.ttable, self.temp, dens, 0, self.nlayers,
                   assign=True)
         if self.continuum is not None:
-            self.continuum.add(self.ec, self.temp.cpu().numpy(), continuum_density)
+            # the continuum's per-layer factors are prepared on the host: hand it host
+            # temperatures when the caller has them (no device -> host copy in the loop)
+            self.continuum.add(self.ec, temp_host if temp_host is not None
+                               else self.temp.cpu().numpy(), continuum_density)
         if self.rt_path == 'transit':
             self.spectrum, self.depth, self.ideep = transit_spectrum(
                 self.ec, self.raypath, self.radius, self.rstar, self.itop, self.nlayers,
@@ -659,19 +731,36 @@ class TableSpectrum:
                                           self.weights, self.itop)
         return self.spectrum
 
-    def eval_bands(self, temps, dens, bands):
+    def eval_bands(self, temps, dens, bands, radius=None, chunk=64):
         """Batched-walker evaluation (the inner loop of a retrieval, pyrat_obj.py:225-385
         without the parameter mapping): temps[nw, L], dens[nw, L, nspec] device tensors,
-        bands: PassBands on this model's grid -> bandflux[nw, nbands].  Walkers whose
-        temperatures leave the table's range get inf, like eval()'s reject path
+        optional per-walker radius[nw, L] (the hydrostatic profile changes with every model),
+        bands: PassBands on this model's grid -> bandflux[nw, nbands].  Every stage is ONE
+        launch per chunk of walkers -- interp_ec, transit_path, optical depth + transmission,
+        band integration -- with no per-walker Python and no host synchronisation.  Walkers
+        whose temperatures leave the table's range get +inf, like eval()'s reject path
         (pyrat_obj.py:302-320, 378-380)."""
+        assert self.rt_path == 'transit' and self.continuum is None, \
+            'eval_bands: transit geometry on sampled cross sections'
         nw = temps.shape[0]
         out = torch.empty((nw, bands.nbands), dtype=torch.float64, device='cuda')
-        ok = ((temps >= self.tmin) & (temps <= self.tmax)).all(dim=1).cpu().numpy()
-        for w in range(nw):
-            if not ok[w]:
-                out[w] = float('inf')
-                continue
-            spec = self.eval(temps[w], dens[w])
-            out[w] = bands.partial_integrate(spec) * bands.heights
+        if radius is None:
+            radius = self.radius.view(1, -1)
+        shared_radius = radius.shape[0] == 1
+        path1 = transit_path_device(radius[0], self.itop).view(1, -1) if shared_radius else None
+        for w0 in range(0, nw, chunk):
+            w1 = min(w0 + chunk, nw)
+            n = w1 - w0
+            ec = interp_ec_batch(self.etable, self.ttable, temps[w0:w1], dens[w0:w1])
+            if shared_radius:
+                rad = radius.expand(n, -1).contiguous()
+                path = path1.expand(n, -1).contiguous()
+            else:
+                rad = radius[w0:w1].contiguous()
+                path = transit_path_device(rad, self.itop)
+            spectra = transit_spectrum_batch(ec, path, rad, self.rstar, self.itop, self.nlayers,
+                                             self.maxdepth)
+            bands.integrate_batch(spectra, out[w0:w1])
+        call('pb_reject_walkers', _ptr(out), _ptr(temps.contiguous()), self.tmin, self.tmax,
+             self.nlayers, bands.nbands, nw, _stream())
         return out

@@ -1,0 +1,183 @@
+"""Walker-batched retrieval path (BASELINE config 5) and the fused transit column kernel, through
+the C ABI, against the oracle.  Reference inner loop: pyratbay/pyrat/pyrat_obj.py:225-385 ->
+opacity/line_sampling.py:394-463, atmosphere/atmosphere.py:782-802, opacity/optic_depth.py:103-112,
+spectrum/radiative_transfer.py:57-71, spectrum/spec_tools.py:193-233.  Tolerance 1e-12."""
+import numpy as np
+import pytest
+
+import cases
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-12
+
+
+@pytest.fixture(scope='module')
+def eng():
+    from pyratbay_amd import engine
+    engine.require_gpu()
+    return engine
+
+
+def host(t):
+    return t.cpu().numpy()
+
+
+def hydro_radius(rng, nlayers, scale):
+    """A smooth, strictly decreasing radius profile, different for every walker."""
+    base = np.linspace(8.0e9, 7.0e9, nlayers)
+    return base * (1.0 + scale * rng.uniform(-1, 1)) + np.linspace(0, 1, nlayers) * 2e7 * rng.uniform(-1, 1)
+
+
+def test_transit_path_device(eng, orc):
+    rng = np.random.default_rng(2)
+    nw, L = 5, 37
+    radius = np.array([hydro_radius(rng, L, 0.02) for _ in range(nw)])
+    for itop in (0, 3):
+        got = host(eng.transit_path_device(eng.dev(radius), itop))
+        for w in range(nw):
+            want = eng.pack_raypath(eng.transit_path(radius[w], itop), itop)
+            assert np.array_equal(got[w], want), (itop, w)
+            want_o = eng.pack_raypath(orc.transit_path(radius[w], itop), itop)
+            assert np.array_equal(got[w], want_o)
+
+
+def test_interp_ec_batch_vs_single_and_oracle(eng, orc):
+    rng = np.random.default_rng(4)
+    nmol, ntemp, L, W, nw = 4, 7, 9, 1500, 37
+    ttable = np.linspace(300.0, 3000.0, ntemp)
+    etable = 10.0**rng.uniform(-30, -20, (nmol, ntemp, L, W))
+    temps = rng.uniform(300.0, 3000.0, (nw, L))
+    temps[0] = ttable[rng.integers(0, ntemp, L)]          # exactly on nodes
+    temps[1] = 300.0
+    temps[2] = 3000.0
+    temps[3, :] = np.linspace(640, 660, L)                # one bracket
+    dens = 10.0**rng.uniform(8, 18, (nw, L, nmol))
+    et, tt = eng.dev(etable), eng.dev(ttable)
+    got = host(eng.interp_ec_batch(et, tt, eng.dev(temps), eng.dev(dens)))
+    import torch
+    for w in range(nw):
+        one = torch.full((L, W), 3.3, dtype=torch.float64, device='cuda')
+        eng.interp_ec(one, et, tt, eng.dev(temps[w]), eng.dev(dens[w]), 0, L, assign=True)
+        assert np.array_equal(got[w], host(one)), w         # same arithmetic, bit for bit
+    for w in (0, 1, 2, 3, 17, 36):
+        want = np.zeros((L, W))
+        orc.interp_ec(want, etable, ttable, temps[w], dens[w], 0, L)
+        np.testing.assert_allclose(got[w], want, rtol=RTOL)
+    # 6 species (the 8-register instantiation)
+    etable6 = 10.0**rng.uniform(-30, -20, (6, ntemp, L, 300))
+    dens6 = 10.0**rng.uniform(8, 18, (5, L, 6))
+    got6 = host(eng.interp_ec_batch(eng.dev(etable6), tt, eng.dev(temps[:5]), eng.dev(dens6)))
+    for w in range(5):
+        want = np.zeros((L, 300))
+        orc.interp_ec(want, etable6, ttable, temps[w], dens6[w], 0, L)
+        np.testing.assert_allclose(got6[w], want, rtol=RTOL)
+
+
+@pytest.mark.parametrize('itop,ibottom,maxdepth', [(0, None, 10.0), (2, None, 10.0),
+                                                   (0, 19, 10.0), (1, None, np.inf)])
+def test_transit_spectrum_batch_vs_oracle(eng, orc, itop, ibottom, maxdepth):
+    rng = np.random.default_rng(7)
+    c = cases.column_case(seed=9, nlayers=24, nwave=700)
+    L, W, nw = c['nlayers'], c['nwave'], 6
+    ibottom = L if ibottom is None else ibottom
+    ecs = np.array([c['ec'] * 10.0**rng.uniform(-1, 1) for _ in range(nw)])
+    radius = np.array([np.sort(c['radius'] * (1 + 0.01 * rng.uniform(-1, 1)))[::-1]
+                       for _ in range(nw)])
+    rad_d = eng.dev(radius)
+    path = eng.transit_path_device(rad_d, itop)
+    spec, depth, ideep = eng.transit_spectrum_batch(eng.dev(ecs), path, rad_d, c['rstar'], itop,
+                                                    ibottom, maxdepth, want_depth=True)
+    only = eng.transit_spectrum_batch(eng.dev(ecs), path, rad_d, c['rstar'], itop, ibottom,
+                                      maxdepth)
+    assert np.array_equal(host(only), host(spec))
+    for w in range(nw):
+        wd, wi = orc.optical_depth_transit(ecs[w], radius[w], itop, ibottom, maxdepth)
+        ws = orc.transmission(wd, radius[w], c['rstar'], wi, itop)
+        assert np.array_equal(host(ideep[w]), wi)
+        np.testing.assert_allclose(host(depth[w]), wd, rtol=RTOL, atol=0)
+        np.testing.assert_allclose(host(spec[w]), ws, rtol=RTOL)
+
+
+def test_fused_transit_equals_split(eng):
+    """The fused column kernel against the two-kernel form it replaced (a separate process so
+    that PB_TRANSIT=split is read afresh): same depth, ideep, spectrum bits."""
+    import subprocess
+    import sys
+    code = '''
+import numpy as np, sys
+sys.path.insert(0, "tests")
+import cases
+from pyratbay_amd import engine as eng
+c = cases.column_case(seed=5, nlayers=40, nwave=3000)
+out = {}
+for itop, ib in ((0, 40), (3, 31)):
+    path = eng.dev(eng.pack_raypath(eng.transit_path(c["radius"], itop), itop))
+    s, d, i = eng.transit_spectrum(eng.dev(c["ec"]), path, eng.dev(c["radius"]), c["rstar"], itop, ib, 10.0)
+    out[f"s{itop}"], out[f"d{itop}"], out[f"i{itop}"] = s.cpu().numpy(), d.cpu().numpy(), i.cpu().numpy()
+np.savez(sys.argv[1], **out)
+'''
+    import os
+    import tempfile
+    with tempfile.TemporaryDirectory() as tmp:
+        res = {}
+        for mode in ('fused', 'split'):
+            env = dict(os.environ, PB_TRANSIT=mode)
+            f = os.path.join(tmp, mode + '.npz')
+            subprocess.run([sys.executable, '-c', code, f], check=True, env=env,
+                           cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+            res[mode] = dict(np.load(f))
+        for k in res['fused']:
+            assert np.array_equal(res['fused'][k], res['split'][k]), k
+
+
+def test_eval_bands_64_walkers_vs_oracle(eng, orc):
+    """A 64-walker batch with per-walker radius profiles: band fluxes against the oracle chain
+    interp_ec -> transit_path -> optical depth -> transmission -> trapezoid, out-of-range
+    temperatures rejected with +inf, and the batch equals the single-walker eval() bit for bit."""
+    from pyratbay_amd import synth
+    rng = np.random.default_rng(21)
+    nspec, ntemp, L, W, nw = 4, 10, 20, 3001, 64
+    g = synth.spectral_grid(4000.0, 4000.0 + (W - 1) * 0.05 + 0.01, 0.05, 12)
+    wn = g['wn']
+    ttable = np.linspace(300.0, 3000.0, ntemp)
+    press = np.logspace(-6, 2, L)
+    etable = 10.0**rng.uniform(-27, -21, (nspec, ntemp, L, 1)) * \
+        10.0**rng.uniform(-1, 1, (nspec, 1, 1, W))
+    base_radius = np.linspace(8.0e9, 7.0e9, L)
+    rstar = 8.8e10
+    model = eng.TableSpectrum(etable, ttable, wn, base_radius, rstar)
+    bands = []
+    for lo, hi in ((20, 900), (800, 2100), (2000, 2990)):
+        resp = np.exp(-np.linspace(-1.5, 1.5, hi - lo)**2)
+        bands.append((lo, resp, 1.0 / np.trapezoid(resp, wn[lo:hi])))
+    pb = eng.PassBands(wn, bands)
+    temps = 1500.0 * (1 + 0.1 * rng.uniform(-1, 1, (nw, 1))) * np.linspace(0.8, 1.2, L)
+    dens = (press / temps)[:, :, None] * 7.2e21 * 10.0**rng.uniform(-7, -3, (nw, 1, nspec))
+    radius = np.array([hydro_radius(rng, L, 0.01) for _ in range(nw)])
+    temps[5, 7] = 3000.5                                   # above the table
+    temps[40, 0] = 299.0                                   # below the table
+    temps[41, 3] = np.nan
+    got = host(model.eval_bands(eng.dev(temps), eng.dev(dens), pb, radius=eng.dev(radius),
+                                chunk=24))
+    for w in (5, 40, 41):
+        assert np.all(np.isinf(got[w])) and np.all(got[w] > 0)
+    ok = [w for w in range(nw) if w not in (5, 40, 41)]
+    assert np.all(np.isfinite(got[ok]))
+    for w in ok[::5]:
+        ec = np.zeros((L, W))
+        orc.interp_ec(ec, etable, ttable, temps[w], dens[w], 0, L)
+        depth, ideep = orc.optical_depth_transit(ec, radius[w], 0, L, 10.0)
+        spec = orc.transmission(depth, radius[w], rstar, ideep, 0)
+        want = [np.trapezoid(spec[s:s + len(r)] * r, wn[s:s + len(r)]) * h for s, r, h in bands]
+        np.testing.assert_allclose(got[w], want, rtol=1e-11)
+    # the batch and the one-walker path do the same arithmetic
+    for w in (0, 33):
+        model.set_radius(radius[w])
+        spec = model.eval(temps[w], eng.dev(dens[w]))
+        one = host(pb.partial_integrate(spec) * pb.heights)
+        np.testing.assert_allclose(got[w], one, rtol=1e-13)
+    # shared radius (the model's own): one ray-path table for the whole batch
+    model.set_radius(base_radius)
+    got2 = host(model.eval_bands(eng.dev(temps[:8]), eng.dev(dens[:8]), pb))
+    spec = model.eval(temps[1], eng.dev(dens[1]))
+    np.testing.assert_allclose(got2[1], host(pb.partial_integrate(spec) * pb.heights), rtol=1e-13)

@@ -236,3 +236,62 @@ def test_lbl_with_continuum(eng, case, orc):
     want = orc.transmission(depth, atm['radius'], float(atm['rstar']), ideep, 0)
     np.testing.assert_allclose(spectrum, want, rtol=1e-11)
     assert np.all(spectrum >= plain.spectrum.cpu().numpy())
+
+
+def test_set_atmosphere_with_continuum(eng, case, orc):
+    """A new atmosphere reaches EVERY opacity term: after set_atmosphere() the continuum is
+    evaluated at the new temperatures and densities too (oracle: Rayleigh x n_H2 +
+    Lecavelier x nominal density(p, T_new) on top of the LBL rows of the new atmosphere)."""
+    from pyratbay_amd import continuum as ct, synth, _capi
+    from oracle import continuum as oc
+    g, atm, iso = case['grid'], case['atm'], case['iso']
+    wn = g['wn']
+    pressure = np.logspace(-6, 2, atm['nlayers'])
+    lec = ct.Lecavelier(pressure, wn=wn)
+    lec.calc_cross_section([1.0, -3.0])
+    cont = ct.Continuum(wn, pressure, [ct.Kurucz(wn, 'H2'), lec])
+    n_h2 = pressure * ct.BAR / (ct.K * atm['temp']) * 0.85
+    model = eng.LBLSpectrum(case, rt_path='transit', continuum=cont,
+                            continuum_density={'H2': n_h2})
+    model.run()
+    temp = atm['temp'] * 1.07
+    dens = atm['dens'] / 1.07
+    isoz = synth.partition_function(temp)[None, :].repeat(len(iso['isomass']), 0)
+    n_h2_new = pressure * ct.BAR / (ct.K * temp) * 0.85
+    with pytest.raises(_capi.PbError):
+        model.set_atmosphere(temp, dens, isoz)          # continuum densities are required
+    model.set_atmosphere(temp, dens, isoz, continuum_density={'H2': n_h2_new})
+    spectrum = model.run().cpu().numpy()
+    plain = eng.LBLSpectrum(case, rt_path='transit', voigt=model.voigt, lines=model.lines)
+    plain.set_atmosphere(temp, dens, isoz)
+    plain.run()
+    want_ec = (plain.ec.cpu().numpy()[:, 0]
+               + oc.rayleigh_cross_section(wn, 'H2') * n_h2_new[:, None]
+               + oc.lecavelier_cross_section(wn, [1.0, -3.0])
+               * oc.nominal_density(pressure, temp)[:, None])
+    np.testing.assert_allclose(model.ec.cpu().numpy()[:, 0], want_ec, rtol=1e-12)
+    depth, ideep = orc.optical_depth_transit(want_ec, atm['radius'], 0, atm['nlayers'],
+                                             case['maxdepth'])
+    want = orc.transmission(depth, atm['radius'], float(atm['rstar']), ideep, 0)
+    np.testing.assert_allclose(spectrum, want, rtol=1e-11)
+
+
+def test_layer_sharded_set_atmosphere(eng, case):
+    """dist.LayerShardedTransit.set_atmosphere refreshes the rank's layer slices: two
+    alternating atmospheres give what a fresh single-GPU model gives for each."""
+    from pyratbay_amd import synth
+    from pyratbay_amd.dist import LayerShardedTransit
+    atm, iso = case['atm'], case['iso']
+    sh = LayerShardedTransit(case, 1, 0)
+    base = sh.step().cpu().numpy().copy()
+    temp = atm['temp'] * 0.93
+    dens = atm['dens'] / 0.93
+    isoz = synth.partition_function(temp)[None, :].repeat(len(iso['isomass']), 0)
+    ref = eng.LBLSpectrum(case, rt_path='transit', voigt=sh.model.voigt, lines=sh.model.lines)
+    ref.set_atmosphere(temp, dens, isoz)
+    want = ref.run().cpu().numpy()
+    for _ in range(2):
+        sh.set_atmosphere(temp, dens, isoz)
+        assert np.array_equal(sh.step().cpu().numpy(), want)
+        sh.set_atmosphere(atm['temp'], atm['dens'], iso['isoz'])
+        assert np.array_equal(sh.step().cpu().numpy(), base)

@@ -1,0 +1,292 @@
+#!/usr/bin/env python3
+"""BASELINE config 5: retrieval inner loop on sampled cross sections -- 1e4 pyrat.eval() calls at
+1e5 wavenumbers x 80 layers, batched walkers (bench.py --workload c5 [--gpus N]).
+
+One step = one batch of BATCH walkers through interp_ec -> transit_path -> optical depth +
+transmission -> band integration (TableSpectrum.eval_bands: one launch per stage per batch).
+With N > 1 the walkers of every batch are dealt to the ranks (replicas of the table)
+and the band fluxes are all-gathered.  Synthetic inputs: S=4 species, 10 table
+temperatures 300-3000 K, cross sections 10**U(-30,-20) smooth in T, parameter vectors within
++-10 % of a base T / abundance vector, seed 7, per-walker hydrostatic radius.
+
+CPU legs (reference interp_ec + optdepth + trapezoid2D from oracle/_ref, else the oracle's port):
+one core on a few evals, and all cores with one eval per worker at a time (walkers are
+independent, the way the reference's sampler parallelises them).  Workers start before the GPU
+is touched.
+"""
+import json
+import os
+import shutil
+import subprocess
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+BATCH = 64
+NSPEC, NTEMP, NLAYERS, NWAVE = 4, 10, 80, 100001
+HBM_PEAK_GBS = 8000.0
+
+
+def inputs(nwave=NWAVE, nlayers=NLAYERS):
+    from pyratbay_amd import synth
+    rng = np.random.default_rng(7)
+    grid = synth.spectral_grid(4000.0, 4000.0 + (nwave - 1) * 0.05 + 0.025, 0.05, 180)
+    atm = synth.synthetic_atmosphere(
+        nlayers, ('H2', 'He', 'H2O', 'CO', 'CO2', 'CH4'), (0.85, 0.149, 4e-4, 5e-4, 1e-7, 1e-4))
+    ttable = np.linspace(300.0, 3000.0, NTEMP)
+    # smooth in T, rough in wavenumber, rising with pressure
+    base = rng.uniform(-30.0, -20.0, (NSPEC, 1, 1, grid['nwave']))
+    slope = rng.uniform(-1.0, 1.0, (NSPEC, 1, 1, 1)) * (ttable[None, :, None, None] / 3000.0)
+    etable = 10.0**np.clip(base + slope + 0.1 * np.log10(atm['press'])[None, None, :, None],
+                           -30.0, -20.0)
+    nb = 24
+    edges = np.linspace(100, grid['nwave'] - 100, nb + 1).astype(int)
+    bands = []
+    for lo, hi in zip(edges[:-1], edges[1:]):
+        resp = np.ones(hi - lo)
+        bands.append((int(lo), resp, 1.0 / np.trapezoid(resp, grid['wn'][lo:hi])))
+    return dict(grid=grid, atm=atm, ttable=ttable, etable=etable, bands=bands)
+
+
+def walkers(inp, n, seed):
+    """temps[n, L], dens[n, L, S], radius[n, L] within +-10 % of the base model."""
+    rng = np.random.default_rng(seed)
+    atm = inp['atm']
+    temps = atm['temp'][None, :] * (1.0 + 0.1 * rng.uniform(-1, 1, (n, 1)))
+    scale = 10.0**(0.0414 * rng.uniform(-1, 1, (n, 1, NSPEC)))          # +-10 % abundances
+    dens = atm['dens'][None, :, 2:2 + NSPEC] * scale * (atm['temp'][None, :, None] / temps[:, :, None])
+    radius = atm['radius'][None, :] * (1.0 + 0.02 * (temps[:, :1] / atm['temp'][0] - 1.0))
+    return temps, dens, radius
+
+
+# ------------------------------------------------------------------ CPU reference legs
+def cpu_eval(arr, temps, dens, radius, rstar, bands, wn):
+    from oracle import oracle as orc, ref
+    L, W = temps.shape[0], wn.shape[0]
+    ec = np.zeros((L, W))
+    if ref.available():
+        kind = 'reference'
+        ref.module('_extcoeff').interp_ec(ec, arr['etable'], arr['ttable'], temps, dens, 0, L)
+        t = ref.module('_trapezoid')
+        raypath = orc.transit_path(radius, 0)
+        depth = np.zeros_like(ec)
+        ideep = np.full(W, -1, np.intc)
+        for r in range(L):
+            depth[r] = t.optdepth(ec[0:r + 1], raypath[r], 10.0, ideep, r)
+        ideep[ideep < 0] = L - 1
+        integ = np.exp(-depth) * np.expand_dims(radius, 1)
+        spec = t.trapezoid2D(integ, np.ediff1d(radius), ideep.astype(np.intc))
+        spec = (radius[0]**2 + 2 * spec) / rstar**2
+    else:
+        kind = 'port'
+        orc.interp_ec(ec, arr['etable'], arr['ttable'], temps, dens, 0, L)
+        depth, ideep = orc.optical_depth_transit(ec, radius, 0, L, 10.0)
+        spec = orc.transmission(depth, radius, rstar, ideep, 0)
+    flux = np.array([np.trapezoid(spec[s:s + len(r)] * r, wn[s:s + len(r)]) * h
+                     for s, r, h in bands])
+    return kind, flux
+
+
+def cpu_worker():
+    for line in sys.stdin:
+        job = json.loads(line)
+        if job.get('quit'):
+            break
+        d = job['dir']
+        arr = {k: np.load(os.path.join(d, k + '.npy'), mmap_mode='r')
+               for k in ('etable', 'ttable', 'temps', 'dens', 'radius', 'wn')}
+        bands = [(int(s), np.ones(int(c)), float(h)) for s, c, h in job['bands']]
+        t0 = time.perf_counter()
+        out = []
+        for w in job['walkers']:
+            kind, flux = cpu_eval(arr, np.array(arr['temps'][w]), np.array(arr['dens'][w]),
+                                  np.array(arr['radius'][w]), job['rstar'], bands, arr['wn'])
+            out.append(flux.tolist())
+        print(json.dumps({'kind': kind, 'wall': time.perf_counter() - t0, 'flux': out}),
+              flush=True)
+
+
+def main(args):
+    if getattr(args, 'cpu_worker', False):
+        return cpu_worker()
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus:
+        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}')
+    want_cpu = world == 1 and not args.no_cpu_baseline
+    procs = []
+    if want_cpu:
+        try:
+            ncores = len(os.sched_getaffinity(0))
+        except AttributeError:
+            ncores = os.cpu_count() or 1
+        nworkers = max(1, min(ncores - 1, 32))
+        procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), '--cpu-worker'],
+                                  stdin=subprocess.PIPE, stdout=subprocess.PIPE, text=True,
+                                  cwd=ROOT) for _ in range(nworkers)]
+
+    import torch
+    import torch.distributed as dist
+    from pyratbay_amd import engine
+    from pyratbay_amd.dist import walker_slice, gather_walkers
+    rehearse = os.environ.get('PB_REHEARSE') == '1'
+    torch.cuda.set_device(0 if rehearse else local_rank)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        if rehearse:
+            dist.init_process_group('gloo', rank=rank, world_size=world)
+        else:
+            dist.init_process_group('nccl', rank=rank, world_size=world,
+                                    device_id=torch.device('cuda', local_rank))
+    inp = inputs()
+    g, atm = inp['grid'], inp['atm']
+    nwave, nlayers = g['nwave'], atm['nlayers']
+    t0 = time.perf_counter()
+    model = engine.TableSpectrum(inp['etable'], inp['ttable'], g['wn'], atm['radius'],
+                                 atm['rstar'])
+    pb = engine.PassBands(g['wn'], inp['bands'])
+    steps = args.steps if args.steps != 20 else 157        # default: 1e4 evals in batches of 64
+    nbatch_distinct = 4
+    batches = []
+    for b in range(nbatch_distinct):
+        temps, dens, radius = walkers(inp, BATCH, 700 + b)
+        a, e = walker_slice(BATCH, world, rank)
+        batches.append(tuple(engine.dev(x[a:e]) for x in (temps, dens, radius)))
+    torch.cuda.synchronize()
+    t_init = time.perf_counter() - t0
+
+    def step(i):
+        temps, dens, radius = batches[i % nbatch_distinct]
+        flux = model.eval_bands(temps, dens, pb, radius=radius, chunk=BATCH)
+        return gather_walkers(flux, BATCH, world, rank) if world > 1 else flux
+
+    for i in range(args.warmup):
+        out = step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        out = step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device='cpu' if rehearse else 'cuda')
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    if rank == 0:
+        evals = steps * BATCH
+        value = evals / elapsed
+        # dominant kernel: k_interp_ec_batch, timed alone with events on the launch stream
+        temps, dens, radius = batches[0]
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        engine.interp_ec_batch(model.etable, model.ttable, temps, dens)
+        reps = 10
+        ev0.record()
+        for _ in range(reps):
+            engine.interp_ec_batch(model.etable, model.ttable, temps, dens)
+        ev1.record()
+        torch.cuda.synchronize()
+        nloc = temps.shape[0]
+        kernel_ms = ev0.elapsed_time(ev1) / reps
+        kb = (16.0 * NSPEC + 8.0) * nlayers * nwave * nloc       # two T-slices read, ec written
+        achieved = kb / (kernel_ms * 1e-3) / 1e9
+        path_bytes = (16.0 * NSPEC + 32.0) * nlayers * nwave + 8.0 * nwave
+        out_json = {
+            'metric': 'pyrat.eval() calls/sec (1e5 wavenumbers x 80 layers, sampled cross sections)',
+            'value': value, 'unit': 'evals/s', 'n_gpus': world, 'steps': steps,
+            'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / steps,
+            'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None, 'dtype': 'f64',
+            'data': 'synthetic',
+            'config': {'workload': f'MCMC retrieval inner loop: {evals} eval() calls at 1e5 '
+                                   'wavenumbers x 80 layers, batched walkers',
+                       'batch': BATCH, 'nspec': NSPEC, 'ntemp': NTEMP, 'nbands': len(inp['bands']),
+                       'table_bytes': int(model.etable.numel() * 8),
+                       'parallelism': 'single GPU' if world == 1 else
+                       f'walker replicas x{world} + all-gather of band fluxes',
+                       'init_seconds': round(t_init, 3)},
+            'roofline': {'bound': 'hbm', 'kernel': 'k_interp_ec_batch<4>', 'achieved': achieved,
+                         'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
+                         'traffic': None, 'kernel_ms': kernel_ms, 'kernel_bytes': kb,
+                         'note': 'algorithmic bytes = per walker two table slices of every species '
+                                 '+ the ec row written (SURVEY 8d); walkers of a chunk that share '
+                                 'a temperature bracket share the slices, so the bytes actually '
+                                 'moved are fewer and frac can exceed 1',
+                         'path_bytes_per_eval': path_bytes, 'path_GBps': path_bytes * value / 1e9},
+        }
+        if want_cpu:
+            out_json.update(cpu_legs(inp, procs, step(0).cpu().numpy()))
+        print(json.dumps(out_json), flush=True)
+    for p in procs:
+        try:
+            p.stdin.write(json.dumps({'quit': True}) + '\n')
+            p.stdin.flush()
+            p.wait(timeout=10)
+        except Exception:
+            p.kill()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_legs(inp, procs, gpu_flux_last):
+    g, atm = inp['grid'], inp['atm']
+    n1 = 8
+    nall = max(len(procs), 1) * 2
+    temps, dens, radius = walkers(inp, max(n1, nall), 700)     # = the GPU's first batch
+    arr = dict(etable=inp['etable'], ttable=inp['ttable'])
+    t0 = time.perf_counter()
+    flux1 = []
+    for w in range(n1):
+        kind, f = cpu_eval(arr, temps[w], dens[w], radius[w], atm['rstar'], inp['bands'], g['wn'])
+        flux1.append(f)
+    s1 = (time.perf_counter() - t0) / n1
+    res = {'cpu_baseline': dict(value=1.0 / s1, unit='evals/s', cores=1, kind=kind,
+                                seconds_per_eval=s1,
+                                sample=f'{n1} eval() calls: interp_ec + optdepth loop + '
+                                       'trapezoid2D + band trapezoids, one core')}
+    # parity of the GPU batch with the CPU path on the same walkers (the first batch)
+    res['cpu_baseline']['parity'] = {
+        'bandflux_max_rel_err': float(np.max(np.abs(gpu_flux_last[:n1] / np.array(flux1) - 1))),
+        'walkers_compared': n1}
+    base = '/dev/shm' if os.path.isdir('/dev/shm') else None
+    d = tempfile.mkdtemp(prefix='pb_c5_', dir=base)
+    try:
+        for k, v in (('etable', inp['etable']), ('ttable', inp['ttable']), ('temps', temps),
+                     ('dens', dens), ('radius', radius), ('wn', g['wn'])):
+            np.save(os.path.join(d, k + '.npy'), np.ascontiguousarray(v))
+        bands = [(s, len(r), h) for s, r, h in inp['bands']]
+        shares = [list(range(i, nall, len(procs))) for i in range(len(procs))]
+        t0 = time.perf_counter()
+        for p, ws in zip(procs, shares):
+            p.stdin.write(json.dumps({'dir': d, 'walkers': ws, 'bands': bands,
+                                      'rstar': float(atm['rstar'])}) + '\n')
+            p.stdin.flush()
+        replies = [json.loads(p.stdout.readline()) for p in procs]
+        wall = time.perf_counter() - t0
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+    res['cpu_baseline_allcores'] = dict(
+        value=nall / wall, unit='evals/s', cores=len(procs), kind=replies[0]['kind'],
+        sample=f'{nall} eval() calls over {len(procs)} worker processes (wall {wall:.2f} s)')
+    return res
+
+
+if __name__ == '__main__':
+    import argparse
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--cpu-worker', action='store_true')
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    main(ap.parse_args())
