@@ -339,12 +339,14 @@ int pb_interp_ec_batch(double *ec_d, const double *etable_d, const double *ttabl
 /* optic_depth.py:103-112 + radiative_transfer.py:57-71 (no cloud deck) for a batch:
  * ec_d[nwalkers,nlayers,nwave], raypath_d[nwalkers, n(n-1)/2], radius_d[nwalkers,nlayers] ->
  * spectrum_d[nwalkers,nwave]; depth_d[nwalkers,nlayers,nwave] and ideep_d[nwalkers,nwave] are
- * optional (NULL: not stored). */
+ * optional (NULL: not stored).  work_d: pb_transit_work_doubles(...) doubles of device scratch
+ * (the ray paths re-laid for scalar loads), or NULL (ray paths staged in LDS: slower). */
+int64_t pb_transit_work_doubles(int nlayers, int itop, int ibottom, int nwave, int nwalkers);
 int pb_transit_spectrum_batch(double *spectrum_d, double *depth_d, int32_t *ideep_d,
                               const double *ec_d, const double *raypath_d,
                               const double *radius_d, double rstar, int itop, int ibottom,
                               double maxdepth, int nlayers, int nwave, int nwalkers,
-                              void *stream);
+                              void *work_d, void *stream);
 /* PassBand.integrate for a batch of full-grid spectra: bandflux_d[nwalkers,nbands]
  * (x heights_d[b] when given). */
 int pb_band_integrate_batch(double *bandflux_d, const double *spectrum_d, const double *wn_d,

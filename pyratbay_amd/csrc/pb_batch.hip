@@ -15,6 +15,7 @@
 //                         reference's early exit and the transmission integral in one pass
 //   k_band_integrate_batch bandflux[w][nbands]
 #include <algorithm>
+#include <cstdlib>
 
 #include "pb_common.h"
 
@@ -116,6 +117,34 @@ __global__ __launch_bounds__(kBlock) void k_interp_ec_batch(
     }
 }
 
+// Ray paths re-laid for the fused kernel: for every block of kRows impact parameters the segments
+// [i][row], zero where segment >= row -- contiguous per (block, segment), so that the kernel can
+// take them with wide SCALAR loads (they are wave-uniform) and feed v_fma_f64 from SGPRs.
+__global__ __launch_bounds__(kBlock) void k_path_blocks(double *blocked, const double *raypath,
+                                                        int64_t npath, int64_t nblocked, int rows,
+                                                        int nimpact)
+{
+    const int w = blockIdx.y;
+    const double *path = raypath + (int64_t)w * npath;
+    double *out = blocked + (int64_t)w * nblocked;
+    for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < nblocked;
+         e += (int64_t)gridDim.x * kBlock) {
+        // block b starts at rows * sum_{b'<b} nseg_b', nseg_b = min(rows*b + rows, nimpact) - 1
+        int b = 0;
+        int64_t off = 0;
+        for (;;) {
+            const int64_t n = (int64_t)max(min(rows * b + rows, nimpact) - 1, 0) * rows;
+            if (e < off + n)
+                break;
+            off += n;
+            b++;
+        }
+        const int i = (int)((e - off) / rows), k = (int)((e - off) % rows);
+        const int r = rows * b + k;
+        out[e] = (r < nimpact && i < r) ? path[((int64_t)r * (r - 1)) / 2 + i] : 0.0;
+    }
+}
+
 // ---------------------------------------------------------------------------
 // Transit optical depth + transmission, one pass per column (optic_depth.py:103-112 with the
 // early exit of _trapezoid.c:259-273, radiative_transfer.py:57-71 incl. the cloud deck).
@@ -136,12 +165,15 @@ __device__ inline double deck_integrand(double f_above, double f_below, double r
     return slope * (rsurf - r_below) + f_below;
 }
 
-template <int kRows>
+template <int kRows, bool kScalarPath>
 __global__ __launch_bounds__(kBlock) void k_transit_fused(
     double *depth, int32_t *ideep, double *spectrum, const double *ec, const double *raypath,
     const double *radius, int64_t npath, double rstar, int itop, int ibottom, double maxdepth,
     int nlayers, int nwave, int deck_row, double rsurf)
 {
+    // kScalarPath: raypath is the blocked layout of k_path_blocks (npath = its length per
+    // walker), read through the constant address space = scalar loads; else the packed lower
+    // triangle, staged per block in LDS
     extern __shared__ __align__(16) double s_path[];      // [segment][kRows]
     const int w = blockIdx.y;
     const int col = blockIdx.x * kBlock + threadIdx.x;
@@ -161,26 +193,32 @@ __global__ __launch_bounds__(kBlock) void k_transit_fused(
         for (int r = 0; r < itop; r++)
             depth[(int64_t)r * nwave + col] = 0.0;
     int rdone = 0;                       // rows examined so far (uniform)
+    int64_t boff = 0;                    // start of the current block in the blocked path layout
     for (int rb = 0; rb < nimpact; rb += kRows) {
         // every column of the workgroup has met its exit: nothing left to compute
         if (__syncthreads_count(active && stop < 0) == 0)
             break;
         const int rlast = min(rb + kRows, nimpact) - 1;
         const int nseg = max(rlast, 0);
-        for (int e = threadIdx.x; e < nseg * kRows; e += kBlock) {
-            const int i = e / kRows, k = e % kRows;
-            const int r = rb + k;
-            s_path[e] = (r <= rlast && i < r) ? path[((int64_t)r * (r - 1)) / 2 + i] : 0.0;
+        if (!kScalarPath) {
+            for (int e = threadIdx.x; e < nseg * kRows; e += kBlock) {
+                const int i = e / kRows, k = e % kRows;
+                const int r = rb + k;
+                s_path[e] = (r <= rlast && i < r) ? path[((int64_t)r * (r - 1)) / 2 + i] : 0.0;
+            }
+            __syncthreads();
         }
-        __syncthreads();
         rdone = rlast + 1;
-        if (!active)
+        if (!active) {
+            boff += (int64_t)nseg * kRows;
             continue;
+        }
         if (stop >= 0) {
             // below the first crossing the reference leaves zeros
             if (depth)
                 for (int r = rb; r <= rlast; r++)
                     depth[(int64_t)(itop + r) * nwave + col] = 0.0;
+            boff += (int64_t)nseg * kRows;
             continue;
         }
         double tau[kRows];
@@ -189,43 +227,58 @@ __global__ __launch_bounds__(kBlock) void k_transit_fused(
             tau[k] = 0.0;
         if (nseg > 0) {
             double prev = src[0];
-#pragma unroll 4
-            for (int i = 0; i < nseg; i++) {
-                const double next = src[(int64_t)(i + 1) * nwave];
-                const double s = next + prev;
-                prev = next;
-                const double *pk = s_path + i * kRows;          // LDS broadcast reads
+            if (kScalarPath) {
+                typedef const double __attribute__((address_space(4))) *cpath_t;
+                const cpath_t pb_ = (cpath_t)(unsigned long long)(path + boff);
+#pragma unroll 2
+                for (int i = 0; i < nseg; i++) {
+                    const double next = src[(int64_t)(i + 1) * nwave];
+                    const double s = next + prev;
+                    prev = next;
 #pragma unroll
-                for (int k = 0; k < kRows; k++)
-                    tau[k] += pk[k] * s;
+                    for (int k = 0; k < kRows; k++)
+                        tau[k] += pb_[i * kRows + k] * s;       // wave-uniform: scalar loads
+                }
+            } else {
+#pragma unroll 4
+                for (int i = 0; i < nseg; i++) {
+                    const double next = src[(int64_t)(i + 1) * nwave];
+                    const double s = next + prev;
+                    prev = next;
+                    const double *pk = s_path + i * kRows;      // LDS broadcast reads
+#pragma unroll
+                    for (int k = 0; k < kRows; k++)
+                        tau[k] += pk[k] * s;
+                }
             }
         }
+        boff += (int64_t)nseg * kRows;
 #pragma unroll
         for (int k = 0; k < kRows; k++) {
             const int r = rb + k;
-            if (r > rlast)
-                break;
-            double t = tau[k];
-            if (stop < 0) {
-                if (spectrum) {
-                    const double rr = rad[itop + r];
-                    double f = exp(-t) * rr;
-                    if (r > 0 && r == deck_row) {
-                        f = deck_integrand(fprev, f, rprev, rr, rsurf);
-                        acc += (rsurf - rprev) * (fprev + f);
-                    } else if (r > 0) {
-                        acc += (rr - rprev) * (fprev + f);
+            if (r <= rlast) {
+                double t = tau[k];
+                if (stop < 0) {
+                    if (spectrum) {
+                        const double rr = rad[itop + r];
+                        double f = exp(-t) * rr;
+                        if (r > 0 && r == deck_row) {
+                            f = deck_integrand(fprev, f, rprev, rr, rsurf);
+                            acc += (rsurf - rprev) * (fprev + f);
+                        } else if (r > 0) {
+                            acc += (rr - rprev) * (fprev + f);
+                        }
+                        fprev = f;
+                        rprev = rr;
                     }
-                    fprev = f;
-                    rprev = rr;
+                    if (t > maxdepth)
+                        stop = r;
+                } else {
+                    t = 0.0;
                 }
-                if (t > maxdepth)
-                    stop = r;
-            } else {
-                t = 0.0;
+                if (depth)
+                    depth[(int64_t)(itop + r) * nwave + col] = t;
             }
-            if (depth)
-                depth[(int64_t)(itop + r) * nwave + col] = t;
         }
     }
     if (!active)
@@ -240,6 +293,142 @@ __global__ __launch_bounds__(kBlock) void k_transit_fused(
     if (spectrum) {
         const double rtop = rad[itop];
         spectrum[(int64_t)w * nwave + col] = (rtop * rtop + 2 * (acc * 0.5)) / (rstar * rstar);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// The same pass with the column tile in LDS: workgroup = 64 columns x NB wavefronts, wavefront b
+// owning the impact parameters 16b .. 16b+15.  The tile of s_i = ec[i+1] + ec[i] (64 columns x all
+// segments) is read from HBM ONCE, cooperatively and coalesced, and every wavefront then takes
+// its operands from LDS (the one-thread-per-column form above re-reads the column once per row
+// block: 3x the bytes at 80 layers, all from HBM once the batch outgrows the caches).  The early
+// exit and the transmission integral then run down the rows wavefront after wavefront, the
+// carried state (first crossing, trapezoid sum, previous integrand) passing through LDS.
+// ---------------------------------------------------------------------------
+constexpr int kTileRows = 16;
+
+__global__ __launch_bounds__(1024) void k_transit_tile(
+    double *depth, int32_t *ideep, double *spectrum, const double *ec, const double *raypath,
+    const double *radius, int64_t npath, double rstar, int itop, int ibottom, double maxdepth,
+    int nlayers, int nwave, int deck_row, double rsurf)
+{
+    extern __shared__ __align__(16) double s_mem[];
+    const int w = blockIdx.y;
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int nwaves = blockDim.x >> 6;
+    const int col = blockIdx.x * 64 + lane;
+    const bool active = col < nwave;
+    const int64_t plane = (int64_t)nlayers * nwave;
+    ec += (int64_t)w * plane;
+    if (depth)
+        depth += (int64_t)w * plane;
+    const double *path = raypath ? raypath + (int64_t)w * npath : nullptr;
+    const double *rad = radius ? radius + (int64_t)w * nlayers : nullptr;
+    const int nimpact = min(ibottom, nlayers) - itop;     // rows 0..nimpact-1 are evaluated
+    const int nseg_all = max(nimpact - 1, 0);
+    double *s_tile = s_mem;                               // [segment][64]
+    double *s_carry = s_tile + (size_t)nseg_all * 64;     // [3][64]: acc, fprev, rprev
+    int *s_stop = reinterpret_cast<int *>(s_carry + 3 * 64);   // [64]
+    double *s_path = reinterpret_cast<double *>(s_stop + 64);  // per wavefront [segment][16]
+
+    // the tile: row i of s = ec[itop+i+1] + ec[itop+i]; wavefront v loads rows v, v+nwaves, ...
+    // (each row 512 contiguous bytes); the two operands of a row are two coalesced loads
+    {
+        const double *src = ec + (int64_t)itop * nwave + (active ? col : 0);
+        for (int i = wave; i < nseg_all; i += nwaves) {
+            const double a = src[(int64_t)i * nwave], b = src[(int64_t)(i + 1) * nwave];
+            s_tile[i * 64 + lane] = b + a;
+        }
+    }
+    // my block of rows and its ray paths ([segment][row], zero where segment >= row)
+    const int rb = wave * kTileRows;
+    const int rlast = min(rb + kTileRows, nimpact) - 1;
+    const int nseg = rb <= rlast ? max(rlast, 0) : 0;
+    int poff = 0;                                         // doubles before my block
+    for (int v = 0; v < wave; v++)
+        poff += max(min(v * kTileRows + kTileRows, nimpact) - 1, 0) * kTileRows;
+    double *mypath = s_path + poff;
+    for (int e = lane; e < nseg * kTileRows; e += 64) {
+        const int i = e / kTileRows, k = e % kTileRows;
+        const int r = rb + k;
+        mypath[e] = (r <= rlast && i < r) ? path[((int64_t)r * (r - 1)) / 2 + i] : 0.0;
+    }
+    if (threadIdx.x < 64) {
+        s_stop[lane] = -1;
+        s_carry[lane] = 0.0;
+        s_carry[64 + lane] = 0.0;
+        s_carry[128 + lane] = 0.0;
+    }
+    __syncthreads();
+    double tau[kTileRows];
+#pragma unroll
+    for (int k = 0; k < kTileRows; k++)
+        tau[k] = 0.0;
+    for (int i = 0; i < nseg; i++) {
+        const double s = s_tile[i * 64 + lane];
+        const double *pk = mypath + i * kTileRows;              // LDS broadcast reads
+#pragma unroll
+        for (int k = 0; k < kTileRows; k++)
+            tau[k] += pk[k] * s;
+    }
+    if (depth && active && wave == 0)
+        for (int r = 0; r < itop; r++)
+            depth[(int64_t)r * nwave + col] = 0.0;
+    // the rows in order, one wavefront after the other
+    for (int v = 0; v < nwaves; v++) {
+        if (v == wave && rb <= rlast) {
+            int stop = s_stop[lane];
+            double acc = s_carry[lane], fprev = s_carry[64 + lane], rprev = s_carry[128 + lane];
+#pragma unroll
+            for (int k = 0; k < kTileRows; k++) {
+                const int r = rb + k;
+                if (r > rlast)
+                    break;
+                double t = tau[k];
+                if (stop < 0) {
+                    if (spectrum) {
+                        const double rr = rad[itop + r];
+                        double f = exp(-t) * rr;
+                        if (r > 0 && r == deck_row) {
+                            f = deck_integrand(fprev, f, rprev, rr, rsurf);
+                            acc += (rsurf - rprev) * (fprev + f);
+                        } else if (r > 0) {
+                            acc += (rr - rprev) * (fprev + f);
+                        }
+                        fprev = f;
+                        rprev = rr;
+                    }
+                    if (t > maxdepth)
+                        stop = r;
+                } else {
+                    t = 0.0;
+                }
+                if (depth && active)
+                    depth[(int64_t)(itop + r) * nwave + col] = t;
+            }
+            s_stop[lane] = stop;
+            s_carry[lane] = acc;
+            s_carry[64 + lane] = fprev;
+            s_carry[128 + lane] = rprev;
+        }
+        __syncthreads();
+    }
+    if (!active)
+        return;
+    if (depth)
+        for (int r = max(nimpact, 0) + wave; r < nlayers - itop; r += nwaves)
+            depth[(int64_t)(itop + r) * nwave + col] = 0.0;   // rows at and below ibottom
+    if (wave == 0) {
+        const int stop = s_stop[lane];
+        const int last = nimpact > 0 ? itop + nimpact - 1 : itop;
+        if (ideep)
+            ideep[(int64_t)w * nwave + col] = stop >= 0 ? itop + stop : last;
+        if (spectrum) {
+            const double rtop = rad[itop];
+            spectrum[(int64_t)w * nwave + col] =
+                (rtop * rtop + 2 * (s_carry[lane] * 0.5)) / (rstar * rstar);
+        }
     }
 }
 
@@ -299,32 +488,93 @@ __global__ __launch_bounds__(kBlock) void k_reject_walkers(double *bandflux, con
 
 }  // namespace
 
-// shared with pb_columns.hip: the single-spectrum entries use the fused kernel too
+// rows per block of the fused kernel for a launch of nwave x nwalkers columns
+static int fused_rows(int nwave, int nwalkers, int nrow, bool scalar_path)
+{
+    // measured at C5's shape (64 walkers x 1e5 columns x 80 layers, ray paths in SGPRs): 8 rows
+    // per thread 3.97 ms, 16 rows 3.55 ms, 40 rows 3.70 ms (157 registers); LDS-staged paths 4.68
+    int rows = (int64_t)nwave * nwalkers <= 32768 ? 8 : 16;
+    (void)scalar_path;
+    if (const char *e = getenv("PB_TRANSIT_ROWS"))
+        rows = atoi(e) >= 40 ? 40 : atoi(e) >= 16 ? 16 : 8;
+    while (rows > 8 && (size_t)std::max(nrow, 1) * rows * 8 > 64 * 1024)
+        rows = rows == 40 ? 16 : 8;
+    return rows;
+}
+
+static int64_t blocked_len(int rows, int nimpact)
+{
+    int64_t n = 0;
+    for (int rb = 0; rb < nimpact; rb += rows)
+        n += (int64_t)std::max(std::min(rb + rows, nimpact) - 1, 0) * rows;
+    return n;
+}
+
+// shared with pb_columns.hip: the single-spectrum entries can use the fused kernel too.
+// work_d: nwalkers * blocked_len doubles of scratch for the scalar-path form, or NULL (ray paths
+// staged in LDS).
 int pb_transit_fused_launch(double *depth_d, int32_t *ideep_d, double *spectrum_d,
                             const double *ec_d, const double *raypath_d, const double *radius_d,
                             int64_t npath, double rstar, int itop, int ibottom, double maxdepth,
                             int nlayers, int nwave, int nwalkers, int deck_row, double rsurf,
-                            hipStream_t s)
+                            hipStream_t s, double *work_d)
 {
-    // rows per block: 16 when the grid fills the chip, 8 for narrow launches (shards)
     const int nrow = nlayers - itop;
-    const bool narrow = (int64_t)nwave * nwalkers <= 32768;
-    const int rows = narrow ? 8 : 16;
-    const size_t lds = (size_t)std::max(nrow, 1) * rows * sizeof(double);
-    if (lds > 64 * 1024) {
-        pb::set_error("transit: %d layers need %zu B of LDS", nrow, lds);
-        return PB_ERR_UNSUPPORTED;
+    const int nimpact = std::min(ibottom, nlayers) - itop;
+    // PB_TRANSIT_TILE=1: the LDS-tile form (measured slower: 10.3 ms against 4.5 ms per 64-walker
+    // batch at C5's shape -- five wavefronts of uneven length per 70 KB of LDS); kept for A/B
+    {
+        const int nb = std::max(1, pb::div_up(std::max(nimpact, 1), kTileRows));
+        size_t npd = 0;
+        for (int v = 0; v < nb; v++)
+            npd += (size_t)std::max(std::min(v * kTileRows + kTileRows, nimpact) - 1, 0) * kTileRows;
+        const size_t tl = ((size_t)std::max(nimpact - 1, 0) * 64 + 3 * 64 + npd) * 8 + 64 * 4;
+        static const bool on = getenv("PB_TRANSIT_TILE") && atoi(getenv("PB_TRANSIT_TILE")) != 0;
+        if (on && nb <= 16 && tl <= 150 * 1024) {
+            if (tl > 64 * 1024)
+                PB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_transit_tile),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)tl));
+            dim3 tgrid(pb::div_up(nwave, 64), nwalkers);
+            k_transit_tile<<<tgrid, nb * 64, tl, s>>>(depth_d, ideep_d, spectrum_d, ec_d, raypath_d,
+                                                     radius_d, npath, rstar, itop, ibottom,
+                                                     maxdepth, nlayers, nwave, deck_row, rsurf);
+            PB_LAUNCH_CHECK();
+            return PB_OK;
+        }
     }
+    static const bool no_scalar = getenv("PB_TRANSIT_SCALAR") && atoi(getenv("PB_TRANSIT_SCALAR")) == 0;
+    const bool scalar = work_d != nullptr && nimpact > 1 && !no_scalar;
+    const int rows = fused_rows(nwave, nwalkers, nrow, scalar);
     dim3 grid(pb::div_up(nwave, kBlock), nwalkers);
-    if (narrow)
-        k_transit_fused<8><<<grid, kBlock, lds, s>>>(depth_d, ideep_d, spectrum_d, ec_d, raypath_d,
-                                                   radius_d, npath, rstar, itop, ibottom, maxdepth,
-                                                   nlayers, nwave, deck_row, rsurf);
-    else
-        k_transit_fused<16><<<grid, kBlock, lds, s>>>(depth_d, ideep_d, spectrum_d, ec_d,
-                                                    raypath_d, radius_d, npath, rstar, itop,
-                                                    ibottom, maxdepth, nlayers, nwave, deck_row,
-                                                    rsurf);
+    const double *path_d = raypath_d;
+    int64_t plen = npath;
+    if (scalar) {
+        plen = blocked_len(rows, nimpact);
+        dim3 bgrid((unsigned)std::min<int64_t>(64, pb::div_up(plen, kBlock)), nwalkers);
+        k_path_blocks<<<bgrid, kBlock, 0, s>>>(work_d, raypath_d, npath, plen, rows, nimpact);
+        PB_LAUNCH_CHECK();
+        path_d = work_d;
+    }
+#define PB_FUSED(R, SC)                                                                          \
+    k_transit_fused<R, SC><<<grid, kBlock, SC ? 0 : (size_t)std::max(nrow, 1) * R * 8, s>>>(     \
+        depth_d, ideep_d, spectrum_d, ec_d, path_d, radius_d, plen, rstar, itop, ibottom,        \
+        maxdepth, nlayers, nwave, deck_row, rsurf)
+    if (scalar) {
+        if (rows == 40)
+            PB_FUSED(40, true);
+        else if (rows == 16)
+            PB_FUSED(16, true);
+        else
+            PB_FUSED(8, true);
+    } else {
+        if (rows == 40)
+            PB_FUSED(40, false);
+        else if (rows == 16)
+            PB_FUSED(16, false);
+        else
+            PB_FUSED(8, false);
+    }
+#undef PB_FUSED
     PB_LAUNCH_CHECK();
     return PB_OK;
 }
@@ -383,11 +633,24 @@ int pb_interp_ec_batch(double *ec_d, const double *etable_d, const double *ttabl
     return PB_OK;
 }
 
+int64_t pb_transit_work_doubles(int nlayers, int itop, int ibottom, int nwave, int nwalkers)
+{
+    if (nlayers < 1 || itop < 0 || itop >= nlayers)
+        return 0;
+    const int nimpact = std::min(ibottom, nlayers) - itop;
+    // the largest layout any row-block choice needs
+    int64_t n = 0;
+    for (int rows : {8, 16, 40})
+        n = std::max(n, blocked_len(rows, nimpact));
+    (void)nwave;
+    return n * std::max(nwalkers, 0) + 8;
+}
+
 int pb_transit_spectrum_batch(double *spectrum_d, double *depth_d, int32_t *ideep_d,
                               const double *ec_d, const double *raypath_d,
                               const double *radius_d, double rstar, int itop, int ibottom,
                               double maxdepth, int nlayers, int nwave, int nwalkers,
-                              void *stream)
+                              void *work_d, void *stream)
 {
     PB_REQUIRE(nlayers > 0 && nwave >= 0 && nwalkers >= 0, "pb_transit_spectrum_batch: bad shape");
     PB_REQUIRE(itop >= 0 && itop < nlayers, "pb_transit_spectrum_batch: itop out of range");
@@ -400,7 +663,7 @@ int pb_transit_spectrum_batch(double *spectrum_d, double *depth_d, int32_t *idee
     const int64_t npath = ((int64_t)nrow * (nrow - 1)) / 2;
     return pb_transit_fused_launch(depth_d, ideep_d, spectrum_d, ec_d, raypath_d, radius_d, npath,
                                    rstar, itop, ibottom, maxdepth, nlayers, nwave, nwalkers, -1,
-                                   0.0, pb::as_stream(stream));
+                                   0.0, pb::as_stream(stream), reinterpret_cast<double *>(work_d));
 }
 
 int pb_band_integrate_batch(double *bandflux_d, const double *spectrum_d, const double *wn_d,

@@ -16,7 +16,7 @@ int pb_transit_fused_launch(double *depth_d, int32_t *ideep_d, double *spectrum_
                             const double *ec_d, const double *raypath_d, const double *radius_d,
                             int64_t npath, double rstar, int itop, int ibottom, double maxdepth,
                             int nlayers, int nwave, int nwalkers, int deck_row, double rsurf,
-                            hipStream_t s);
+                            hipStream_t s, double *work_d);
 
 namespace {
 
@@ -679,12 +679,12 @@ static int transit_launch(double *depth_d, int32_t *ideep_d, double *spectrum_d,
     // one-pass kernel of pb_batch.hip (C2: 155 us fused against 97 us), which is what the
     // walker-batched path uses.  PB_TRANSIT=fused|split forces one form (tests compare them).
     const char *mode = getenv("PB_TRANSIT");
-    const bool fused = mode ? !strcmp(mode, "fused") : nwave >= (1 << 21);
+    const bool fused = mode ? !strcmp(mode, "fused") : false;
     if (fused)
         return pb_transit_fused_launch(depth_d, ideep_d, spectrum_d, ec_d, raypath_d, radius_d,
                                        ((int64_t)nrow * (nrow - 1)) / 2, rstar, itop, ibottom,
                                        maxdepth, nlayers, nwave, 1, deck_row0, deck_rsurf,
-                                       pb::as_stream(stream));
+                                       pb::as_stream(stream), nullptr);
     const bool narrow = nwave <= kNarrowColumns;
     const int rows = narrow ? kRowsPerThreadNarrow : kRowsPerThread;
     const int threads = narrow ? 64 : kBlock;

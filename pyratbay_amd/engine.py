@@ -300,9 +300,11 @@ def transit_spectrum_batch(ec, raypath, radius, rstar, itop, ibottom, maxdepth,
     if want_depth:
         depth = torch.empty_like(ec)
         ideep = torch.empty((nw, nwave), dtype=torch.int32, device=ec.device)
+    nwork = _capi.lib().pb_transit_work_doubles(nlayers, int(itop), int(ibottom), nwave, nw)
+    work = torch.empty(nwork, dtype=torch.float64, device=ec.device)
     call('pb_transit_spectrum_batch', _ptr(spectrum), _ptr(depth), _ptr(ideep), _ptr(ec),
          _ptr(raypath), _ptr(radius), float(rstar), int(itop), int(ibottom), float(maxdepth),
-         nlayers, nwave, nw, _stream())
+         nlayers, nwave, nw, _ptr(work), _stream())
     return (spectrum, depth, ideep) if want_depth else spectrum
 
 
