@@ -32,17 +32,18 @@ def _read_str(f):
     return f.read(n).decode('utf-8')
 
 
-def write_tli(path, databases, wn_min=None, wn_max=None):
+def write_tli(path, databases, wn_min=None, wn_max=None, version=VERSION):
     """databases: list of dicts with keys name, molecule, temperatures[ntemp],
     isotopes (names), iso_mass, iso_ratio, partition[niso, ntemp], and the line arrays
-    wn, iso_id (index into the concatenated isotope list), elow, gf sorted by
-    (isotope, wavenumber) within the database."""
+    wn, iso_id, elow, gf sorted by (isotope, wavenumber) within the database.  iso_id counts
+    over the concatenated isotope list of all databases; the FILE holds it relative to the
+    line's own database, as lread.py:181-209,309 writes it."""
     all_wn = np.concatenate([np.asarray(d['wn'], float) for d in databases])
     wn_min = float(all_wn.min()) if wn_min is None else wn_min
     wn_max = float(all_wn.max()) if wn_max is None else wn_max
     with open(path, 'wb') as f:
         f.write(struct.pack('s', sys.byteorder[0].encode()))
-        f.write(struct.pack('3h', *VERSION))
+        f.write(struct.pack('3h', *version))
         f.write(struct.pack('2d', wn_min, wn_max))
         f.write(struct.pack('h', len(databases)))
         n_iso_lines = []
@@ -68,14 +69,28 @@ def write_tli(path, databases, wn_min=None, wn_max=None):
         f.write(struct.pack('i', len(n_iso_lines)))
         f.write(np.asarray(n_iso_lines, np.int32).tobytes())
         f.write(all_wn.tobytes())
-        f.write(np.concatenate([np.asarray(d['iso_id'], np.int16) for d in databases]).tobytes())
+        first, stored = 0, []
+        for d in databases:
+            stored.append(np.asarray(d['iso_id'], np.int64) - first)
+            first += len(d['isotopes'])
+        f.write(np.concatenate(stored).astype(np.int16).tobytes())
         f.write(np.concatenate([np.asarray(d['elow'], float) for d in databases]).tobytes())
         f.write(np.concatenate([np.asarray(d['gf'], float) for d in databases]).tobytes())
 
 
-def read_tli(path, wn_low=-np.inf, wn_high=np.inf):
-    """Returns (databases, wn, gf, elow, iso_id) restricted per isotope to
-    wn_low <= wn <= wn_high, like read_tli_file (line_by_line.py:298-482)."""
+def read_tli(path, wn_low=-np.inf, wn_high=np.inf, strict=False):
+    """Returns (databases, wn, gf, elow, iso_id, meta): the lines restricted per isotope to
+    wn_low <= wn <= wn_high, like read_tli_file (line_by_line.py:298-482; its range search
+    tools.py:219-311 keeps duplicates of a boundary value), + the file header.  The four
+    column blocks are memory-mapped: only the selected ranges are read from disk.
+
+    One quirk of the reference is reproduced unless strict=True: when the window lies entirely
+    ABOVE the lines of an isotope that is not the first in the file, the reference's
+    "not found" index -1 has the isotope's offset added before it is tested
+    (line_by_line.py:418-424), so it returns the last line of the previous isotope followed
+    by ALL lines of that isotope.  (Harmless downstream: the extinction loop skips lines
+    outside the spectral grid, _extcoeff.c:234-236.)  An isotope without lines makes the
+    reference raise (tools.py:264); here it is skipped."""
     with open(path, 'rb') as f:
         endian = f.read(1).decode()
         if endian != sys.byteorder[0]:
@@ -119,12 +134,17 @@ def read_tli(path, wn_low=-np.inf, wn_high=np.inf):
     pieces = []
     lo = 0
     for n in per_iso:
+        n = int(n)
+        if n == 0:
+            continue
         seg = wn_all[lo:lo + n]
         a = lo + int(np.searchsorted(seg, wn_low, 'left'))
         b = lo + int(np.searchsorted(seg, wn_high, 'right'))
+        if not strict and lo > 0 and seg[-1] < wn_low and wn_high >= seg[0]:
+            a, b = lo - 1, lo + n                 # the reference's off-by-offset (see above)
         if b > a:
             pieces.append((a, b))
-        lo += int(n)
+        lo += n
 
     def gather(offset, dtype):
         col = np.memmap(path, dtype, 'r', offset, (n_lines,))
@@ -136,5 +156,11 @@ def read_tli(path, wn_low=-np.inf, wn_high=np.inf):
     iso_id = gather(off_iso, np.int16)
     elow = gather(off_el, np.float64)
     gf = gather(off_gf, np.float64)
-    meta = dict(wn_min=file_wn_min, wn_max=file_wn_max, version=ver, n_lines=n_lines)
+    # index of every returned line's isotope in the concatenated isotope list of the file (the
+    # stored column restarts at 0 in every database: lread.py:181-209)
+    bounds = np.concatenate([[0], np.cumsum(per_iso)])
+    rows = np.concatenate([np.arange(a, b) for a, b in pieces]) if pieces else np.zeros(0, int)
+    iso_global = (np.searchsorted(bounds, rows, 'right') - 1).astype(np.int32)
+    meta = dict(wn_min=file_wn_min, wn_max=file_wn_max, version=ver, n_lines=n_lines,
+                lines_per_isotope=per_iso, iso_global=iso_global)
     return databases, wn, gf, elow, iso_id, meta

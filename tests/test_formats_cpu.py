@@ -43,7 +43,11 @@ def test_tli_round_trip(tmp_path):
     np.testing.assert_array_equal(wn, np.concatenate([d['wn'] for d in dbs]))
     np.testing.assert_array_equal(gf, np.concatenate([d['gf'] for d in dbs]))
     np.testing.assert_array_equal(elow, np.concatenate([d['elow'] for d in dbs]))
-    np.testing.assert_array_equal(iso_id, np.concatenate([d['iso_id'] for d in dbs]))
+    # the stored isotope column restarts at 0 in every database (lread.py:181-209); the
+    # reader also returns the index in the concatenated isotope list
+    np.testing.assert_array_equal(meta['iso_global'], np.concatenate([d['iso_id'] for d in dbs]))
+    np.testing.assert_array_equal(iso_id[:500], dbs[0]['iso_id'])
+    np.testing.assert_array_equal(iso_id[500:], dbs[1]['iso_id'] - 3)
     # file size check of the reader (line_by_line.py:392-404)
     with open(path, 'ab') as f:
         f.write(b'\0\0')
@@ -58,15 +62,22 @@ def test_tli_range_selection(tmp_path):
     path = str(tmp_path / 'mock.tli')
     tli.write_tli(path, dbs)
     lo, hi = 4020.0, 4060.0
-    _, wn, gf, elow, iso_id, _ = tli.read_tli(path, lo, hi)
+    _, wn, gf, elow, iso_id, meta = tli.read_tli(path, lo, hi)
     all_wn = np.concatenate([d['wn'] for d in dbs])
     all_id = np.concatenate([d['iso_id'] for d in dbs])
     keep = (all_wn >= lo) & (all_wn <= hi)
     np.testing.assert_array_equal(wn, all_wn[keep])
-    np.testing.assert_array_equal(iso_id, all_id[keep])
-    assert np.all(np.diff(iso_id) >= 0)
-    _, wn0, *_ = tli.read_tli(path, 9000.0, 9100.0)
+    np.testing.assert_array_equal(meta['iso_global'], all_id[keep])
+    assert np.all(np.diff(meta['iso_global']) >= 0)
+    _, wn0, *_ = tli.read_tli(path, 9000.0, 9100.0, strict=True)
     assert len(wn0) == 0
+    # default mode reproduces the reference's reader, off-by-offset included (G13 pins it): a
+    # window above every line returns each later isotope whole, preceded by the line before it
+    _, wnq, _, _, idq, _ = tli.read_tli(path, 9000.0, 9100.0)
+    counts = np.bincount(all_id)
+    assert len(wnq) == np.sum(counts[1:] + 1)
+    _, wnb, *_ = tli.read_tli(path, 100.0, 200.0)          # below every line: nothing
+    assert len(wnb) == 0
 
 
 def test_opacity_file_format(tmp_path):
@@ -89,3 +100,84 @@ def test_opacity_file_format(tmp_path):
     assert ot.read_opacity(path, 'arrays')[0] == 'H2O'
     with pytest.raises(ValueError):
         ot.write_opacity(path, ['H2O'], temp, press, wn, op)
+
+
+# ---------------------------------------------------------------------------------------------
+# Fixture G13: TLI files written by the REFERENCE's writer and the arrays its reader returns
+# (tests/golden/make_golden_tli.py; pyratbay/opacity/lread.py:277-314,
+# pyrat/line_by_line.py:298-482 with the range search of tools/tools.py:219-311)
+# ---------------------------------------------------------------------------------------------
+import os
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+
+
+@pytest.fixture(scope='module')
+def g13():
+    return np.load(os.path.join(GOLDEN, 'g13_tli_reader.npz'))
+
+
+@pytest.mark.parametrize('name', ['mock_h2o', 'two_db'])
+def test_reads_reference_written_tli(g13, name):
+    path = os.path.join(GOLDEN, f'g13_{name}.tli')
+    dbs, wn, gf, elow, iso_id, meta = tli.read_tli(path)
+    assert len(dbs) == int(g13[f'{name}_ndb'])
+    for i, db in enumerate(dbs):
+        assert db['name'] == str(g13[f'{name}_db{i}_name'])
+        assert db['molecule'] == str(g13[f'{name}_db{i}_molname'])
+        assert len(db['isotopes']) == int(g13[f'{name}_db{i}_niso'])
+        assert np.array_equal(db['temperatures'], g13[f'{name}_db{i}_temp'])
+        assert np.array_equal(db['partition'], g13[f'{name}_db{i}_iso_pf'])
+        assert list(db['isotopes']) == [str(s) for s in g13[f'{name}_db{i}_iso_name']]
+        assert np.array_equal(db['iso_mass'], g13[f'{name}_db{i}_iso_mass'])
+        assert np.array_equal(db['iso_ratio'], g13[f'{name}_db{i}_iso_ratio'])
+    # every range-selection case: the same lines in the same order, bit for bit
+    nonempty = 0
+    for k, (a, b) in enumerate(g13[f'{name}_windows']):
+        _, w, g, e, i_, _ = tli.read_tli(path, a, b)
+        assert np.array_equal(w, g13[f'{name}_w{k}_wn']), (name, k, a, b)
+        assert np.array_equal(g, g13[f'{name}_w{k}_gf'])
+        assert np.array_equal(e, g13[f'{name}_w{k}_elow'])
+        assert np.array_equal(i_, g13[f'{name}_w{k}_iso'])
+        nonempty += len(w) > 0
+    # window 9 (below every line) selects nothing; window 8 (above every line) is the
+    # reference's off-by-offset: every isotope after the first comes back whole
+    assert nonempty >= 7 and len(g13[f'{name}_w9_wn']) == 0 and len(g13[f'{name}_w8_wn']) > 0
+    _, w, *_ = tli.read_tli(path, *g13[f'{name}_windows'][8], strict=True)
+    assert len(w) == 0
+
+
+@pytest.mark.parametrize('name', ['mock_h2o', 'two_db'])
+def test_writer_reproduces_reference_bytes(g13, name, tmp_path):
+    """write_tli(read_tli(file)) is the reference's file, byte for byte."""
+    path = os.path.join(GOLDEN, f'g13_{name}.tli')
+    dbs, wn, gf, elow, iso_id, meta = tli.read_tli(path)
+    lo = 0
+    iso0 = 0
+    glob = meta['iso_global']
+    for db in dbs:
+        niso = len(db['isotopes'])
+        sel = (glob >= iso0) & (glob < iso0 + niso)
+        db.update(wn=wn[sel], iso_id=glob[sel], elow=elow[sel], gf=gf[sel])
+        iso0 += niso
+    out = str(tmp_path / 'copy.tli')
+    tli.write_tli(out, dbs, wn_min=meta['wn_min'], wn_max=meta['wn_max'],
+                  version=meta['version'])
+    assert open(out, 'rb').read() == open(path, 'rb').read()
+
+
+def test_rejects_truncated_and_foreign_files(tmp_path):
+    path = os.path.join(GOLDEN, 'g13_mock_h2o.tli')
+    raw = open(path, 'rb').read()
+    short = tmp_path / 'short.tli'
+    short.write_bytes(raw[:-26])
+    with pytest.raises(ValueError, match='does not correspond'):
+        tli.read_tli(str(short))
+    other = tmp_path / 'other.tli'
+    other.write_bytes((b'b' if raw[:1] == b'l' else b'l') + raw[1:])
+    with pytest.raises(ValueError, match='endianness'):
+        tli.read_tli(str(other))
+    old = tmp_path / 'old.tli'
+    old.write_bytes(raw[:1] + struct.pack('3h', 5, 0, 0) + raw[7:])
+    with pytest.raises(ValueError, match='TLI version'):
+        tli.read_tli(str(old))
