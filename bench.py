@@ -331,9 +331,10 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-north-star', action='store_true',
                     help='skip the 1e6-line leg of the default c2 run')
-    ap.add_argument('--shard', default=None, choices=['layers', 'wavenumber'],
-                    help='multi-GPU decomposition (see pyratbay_amd/dist.py); default: '
-                         'wavenumber for c4 (as BASELINE.json names it), layers otherwise')
+    ap.add_argument('--shard', default='wavenumber', choices=['layers', 'wavenumber'],
+                    help='multi-GPU decomposition `value` is taken from (pyratbay_amd/dist.py): '
+                         "wavenumber = north_star's (shards + RCCL all-gather); the other one is "
+                         'timed in the same run and reported in config.decompositions')
     ap.add_argument('--cpu-layers', type=int, default=None,
                     help='layers of the one-core CPU leg (default: all at c2, 16 otherwise)')
     ap.add_argument('--cpu-worker', action='store_true', help=argparse.SUPPRESS)
@@ -351,8 +352,6 @@ def main():
         raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with '
                          'python -m torch.distributed.run --nproc-per-node N bench.py --gpus N')
     w = WORKLOADS[args.workload]
-    if args.shard is None:
-        args.shard = 'wavenumber' if args.workload == 'c4' else 'layers'
     # CPU workers first: this process has not touched the GPU yet
     pool = None
     want_cpu = world == 1 and not args.no_cpu_baseline
@@ -383,62 +382,87 @@ def main():
     case = make_case(w)
     nwave, nlayers = case['grid']['nwave'], case['atm']['nlayers']
     rt_path = w.get('rt_path', 'transit')
-    layer_mode = world > 1 and args.shard == 'layers' and rt_path == 'transit'
-    t0 = time.perf_counter()
-    if layer_mode:
-        # layer-sharded extinction -> all-to-all -> wavenumber-sharded depth/RT -> all-gather
-        sharded = LayerShardedTransit(case, world, rank)
-        model = sharded.model
-        wcount = nwave                      # the gather kernel covers the full grid ...
-        nlayers_rank = len(sharded.layers)  # ... for this rank's layers
-        step = sharded.step
-    else:
-        gather = SpectrumGather(nwave, world, rank, 'cuda')
-        wbegin, wcount = gather.wbegin, gather.wcount
-        nlayers_rank = nlayers
-        model = engine.LBLSpectrum(case, rt_path=rt_path, wbegin=wbegin, wcount=wcount)
+    dev_reduce = 'cpu' if rehearse else 'cuda'
+    shared = {}                    # Voigt table and line list are built once per rank
 
-        def step():
-            # every rank computes its wavenumber shard, then the shards are re-assembled
-            # on every rank (RCCL all-gather over xGMI when world > 1)
-            return gather(model.run())
-    torch.cuda.synchronize()
-    t_init = time.perf_counter() - t0
+    def run_decomposition(kind):
+        """Build one decomposition, time it, return its numbers.  kind: 'single' (N = 1),
+        'wavenumber' (north_star's: wavenumber shards + all-gather) or 'layers' (layer-sharded
+        extinction + all-to-all + wavenumber-sharded RT + all-gather, consecutive spectra
+        software-pipelined unless PB_PIPELINE=0)."""
+        t0 = time.perf_counter()
+        res = {'kind': kind}
+        if kind == 'layers':
+            sharded = LayerShardedTransit(case, world, rank, voigt=shared.get('voigt'),
+                                          lines=shared.get('lines'))
+            model = sharded.model
+            res.update(wcount=nwave, nlayers_rank=len(sharded.layers))
+            step = sharded.step
+            pipelined = os.environ.get('PB_PIPELINE', '1') != '0'
+        else:
+            gather = SpectrumGather(nwave, world, rank, 'cuda')
+            model = engine.LBLSpectrum(case, rt_path=rt_path, wbegin=gather.wbegin,
+                                       wcount=gather.wcount, voigt=shared.get('voigt'),
+                                       lines=shared.get('lines'))
+            res.update(wcount=gather.wcount, nlayers_rank=nlayers)
+            pipelined = False
 
-    # N > 1, layer-sharded: consecutive spectra are software-pipelined (the all-to-all and the
-    # all-gather of spectrum i run beside the extinction of spectrum i+1; every spectrum of
-    # the timed region is complete before its closing synchronisation).  PB_PIPELINE=0: one
-    # spectrum at a time.
-    pipelined = layer_mode and os.environ.get('PB_PIPELINE', '1') != '0'
+            def step():
+                # every rank computes its wavenumber shard, then the shards are re-assembled
+                # on every rank (RCCL all-gather over xGMI when world > 1)
+                return gather(model.run())
+        shared.setdefault('voigt', model.voigt)
+        shared.setdefault('lines', model.lines)
+        torch.cuda.synchronize()
+        res['init_seconds'] = round(time.perf_counter() - t0, 3)
 
-    def run_steps(k):
-        if pipelined:
-            for _ in range(k):
-                sharded.submit()
-            return sharded.flush()
-        out = None
-        for _ in range(k):
-            out = step()
-        return [out]
-
-    elapsed, gather_ms, launches = timed_steps(
-        run_steps, args.steps, args.warmup, model.lbl, world, dist, torch.cuda.synchronize,
-        'cpu' if rehearse else 'cuda')
-    # N > 1: also the un-pipelined per-spectrum latency (one spectrum complete before the
-    # next starts), so that the pipelined throughput is not mistaken for it
-    latency_ms = None
-    if pipelined:
-        def one_at_a_time(k):
+        def run_steps(k):
+            if pipelined:
+                for _ in range(k):
+                    sharded.submit()
+                return sharded.flush()
             out = None
             for _ in range(k):
                 out = step()
             return [out]
-        el2, _, _ = timed_steps(one_at_a_time, args.steps, 1, model.lbl, world, dist,
-                                torch.cuda.synchronize, 'cpu' if rehearse else 'cuda')
-        latency_ms = 1e3 * el2 / args.steps
+
+        elapsed, gather_ms, launches = timed_steps(
+            run_steps, args.steps, args.warmup, model.lbl, world, dist, torch.cuda.synchronize,
+            dev_reduce)
+        res.update(model=model, elapsed=elapsed, gather_ms=gather_ms, launches=launches,
+                   value=args.steps / elapsed, ms_per_step=1e3 * elapsed / args.steps,
+                   pipelined=pipelined, run_steps=run_steps)
+        # the un-pipelined per-spectrum latency (one spectrum complete before the next starts)
+        # beside the pipelined throughput, so that the one is not mistaken for the other
+        if pipelined:
+            def one_at_a_time(k):
+                out = None
+                for _ in range(k):
+                    out = step()
+                return [out]
+            el2, _, _ = timed_steps(one_at_a_time, args.steps, 1, model.lbl, world, dist,
+                                    torch.cuda.synchronize, dev_reduce)
+            res['unpipelined_ms_per_spectrum'] = 1e3 * el2 / args.steps
+        return res
+
+    if world == 1:
+        order = ['single']
+    elif rt_path != 'transit':
+        order = ['wavenumber']
+    else:
+        other = 'layers' if args.shard == 'wavenumber' else 'wavenumber'
+        order = [args.shard, other]
+    runs = [run_decomposition(k) for k in order]
+    primary = runs[0]
+    model, elapsed = primary['model'], primary['elapsed']
+    gather_ms, launches = primary['gather_ms'], primary['launches']
+    wcount, nlayers_rank = primary['wcount'], primary['nlayers_rank']
+    layer_mode, pipelined = primary['kind'] == 'layers', primary['pipelined']
+    t_init = primary['init_seconds']
+    latency_ms = primary.get('unpipelined_ms_per_spectrum')
     if os.environ.get('PB_DUMP_SPECTRUM'):
         np.save(f"{os.environ['PB_DUMP_SPECTRUM']}.rank{rank}.npy",
-                run_steps(3)[-1].cpu().numpy())
+                primary['run_steps'](3)[-1].cpu().numpy())
 
     if rank == 0:
         ms_per_step = 1e3 * elapsed / args.steps
@@ -492,6 +516,12 @@ def main():
         }
         if latency_ms is not None:
             out['config']['unpipelined_ms_per_spectrum'] = latency_ms
+        if world > 1:
+            # both decompositions of the same run, the one `value` comes from first
+            out['config']['decompositions'] = [
+                {k: r[k] for k in ('kind', 'value', 'ms_per_step', 'pipelined',
+                                   'unpipelined_ms_per_spectrum', 'init_seconds') if k in r}
+                for r in runs]
         if want_cpu:
             budget = args.cpu_layers or (nlayers if args.workload in ('c2', 'small') else 16)
             one, many = cpu_legs(

@@ -172,7 +172,7 @@ class LayerShardedTransit:
     """One transit spectrum per step on `world` GPUs: layer-sharded LBL extinction, one
     all-to-all, wavenumber-sharded optical depth + transmission, one all-gather."""
 
-    def __init__(self, case, world, rank, group=None):
+    def __init__(self, case, world, rank, group=None, voigt=None, lines=None):
         from . import engine
         self.engine = engine
         self.world, self.rank, self.group = world, rank, group
@@ -180,7 +180,8 @@ class LayerShardedTransit:
         self.nwave, self.nlayers = g['nwave'], atm['nlayers']
         self.layers = np.arange(rank, self.nlayers, world)
         self.lp = -(-self.nlayers // world)
-        self.model = engine.LBLSpectrum(case, rt_path='transit')      # full grid, full plan
+        self.model = engine.LBLSpectrum(case, rt_path='transit', voigt=voigt,
+                                        lines=lines)                  # full grid, full plan
         idx = torch.as_tensor(self.layers, device='cuda')
         self.temp = self.model.temp[idx].contiguous()
         self.dens = self.model.dens[idx].contiguous()
