@@ -282,7 +282,8 @@ int pb_alkali_cross_section(double *ec_d, const double *pressure_d, const double
 
 /* Gaussian log-likelihood of band-integrated models (tools/retrieval_tools.py:98-104):
  * loglike_d[w] = -0.5*sum_b ((data_d[b] - bandflux_d[w,b]) / uncert_d[b])^2
- *                -0.5*sum_b log(2*pi*uncert_d[b]^2), or -inf when that is not finite. */
+ *                -0.5*sum_b log(2*pi*uncert_d[b]^2), or -1e98 when that is not finite
+ * (the reference's reject value, retrieval_tools.py:101-103). */
 int pb_loglike(double *loglike_d, const double *bandflux_d, const double *data_d,
                const double *uncert_d, int nwalkers, int nbands, void *stream);
 

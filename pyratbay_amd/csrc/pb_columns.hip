@@ -619,7 +619,7 @@ __global__ __launch_bounds__(64) void k_loglike(double *loglike, const double *m
     }
     if (threadIdx.x == 0) {
         const double ll = -0.5 * chi - 0.5 * norm;
-        loglike[w] = isfinite(ll) ? ll : -INFINITY;
+        loglike[w] = isfinite(ll) ? ll : -1.0e98;     // retrieval_tools.py:101-103
     }
 }
 

@@ -422,7 +422,7 @@ def emission_flux(depth, ideep, wn, temp, mu, weights, rtop, want_intensity=Fals
 
 def loglike(bandflux, data, uncert):
     """tools/retrieval_tools.py:98-104 for a batch of walkers: bandflux[nw, nbands] (or
-    [nbands]) -> loglike[nw]; non-finite values become -inf like the reference's reject."""
+    [nbands]) -> loglike[nw]; a non-finite value becomes -1e98, the reference's reject value."""
     bf = bandflux if bandflux.dim() == 2 else bandflux.view(1, -1)
     out = torch.empty(bf.shape[0], dtype=torch.float64, device=bf.device)
     call('pb_loglike', _ptr(out), _ptr(bf.contiguous()), _ptr(data), _ptr(uncert), bf.shape[0],

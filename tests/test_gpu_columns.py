@@ -199,23 +199,16 @@ def test_interp_ec_golden(eng, golden):
     assert np.array_equal(host(mj), host(m))
 
 
-def test_loglike_matches_reference_formula(eng):
-    """retrieval_tools.py:98-104 on a batch of walkers, including a rejected one."""
-    rng = np.random.default_rng(5)
-    nw, nb = 7, 133
-    model = rng.uniform(1e-3, 2e-3, (nw, nb))
-    data = rng.uniform(1e-3, 2e-3, nb)
-    uncert = rng.uniform(1e-5, 5e-5, nb)
-    model[3, 10] = np.inf                                   # eval()'s reject value
-    want = np.array([-0.5 * np.sum(((data - m) / uncert)**2.0)
-                     - 0.5 * np.sum(np.log(2.0 * np.pi * uncert**2.0)) for m in model])
-    want[~np.isfinite(want)] = -np.inf
-    got = eng.loglike(eng.dev(model), eng.dev(data), eng.dev(uncert)).cpu().numpy()
-    assert got[3] == -np.inf
-    ok = np.isfinite(want)
-    np.testing.assert_allclose(got[ok], want[ok], rtol=1e-13)
-    one = eng.loglike(eng.dev(model[0]), eng.dev(data), eng.dev(uncert)).cpu().numpy()
-    assert one.shape == (1,) and one[0] == got[0]
+def test_loglike_reference_fixture(eng, golden):
+    """pb_loglike against fixture G14 = the reference's own Loglike.__call__
+    (tools/retrieval_tools.py:73-104) on nine band-integrated models: rejected models (inf or
+    nan band flux) give the reference's -1e98, a perfect fit the normalisation term alone."""
+    g = golden('g14_loglike')
+    got = eng.loglike(eng.dev(g['models']), eng.dev(g['data']), eng.dev(g['uncert'])).cpu().numpy()
+    assert got[3] == -1.0e98 and got[6] == -1.0e98
+    np.testing.assert_allclose(got, g['loglike'], rtol=1e-13)
+    one = eng.loglike(eng.dev(g['models'][4]), eng.dev(g['data']), eng.dev(g['uncert']))
+    np.testing.assert_allclose(one.cpu().numpy(), g['loglike'][4:5], rtol=1e-13)
 
 
 @pytest.mark.parametrize('seed', range(8))

@@ -118,3 +118,31 @@ def test_hip_chain_reproduces_reference_run(golden, rt):
     print(f'{rt}: spectrum max rel err vs pb.run() = '
           f'{np.max(np.abs(spectrum.cpu().numpy() / g["spectrum"] - 1)):.2e}; bandflux '
           f'{np.max(np.abs(flux / g["bandflux"] - 1)):.2e}')
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('rt', ['transit', 'emission'])
+def test_hip_band_integrate_on_reference_spectrum(golden, rt):
+    """pb_band_integrate and pb_band_integrate_batch on the REFERENCE's spectrum against the
+    reference's own band_integrate() values (fixture G8; spectrum/spec_tools.py:193-233): the
+    band kernels alone, whole grid, four wavenumber shards summed, and as a batch."""
+    import torch
+    from pyratbay_amd import engine
+    from pyratbay_amd.dist import shard_bounds
+    engine.require_gpu()
+    g = load(golden, rt)[0]
+    wn = g['wn']
+    bands = engine.PassBands(wn, bands_of(g))
+    spec = engine.dev(g['spectrum'])
+    flux = (bands.partial_integrate(spec) * bands.heights).cpu().numpy()
+    np.testing.assert_allclose(flux, g['bandflux'], rtol=1e-13)
+    b = shard_bounds(len(wn), 4)
+    total = torch.zeros(bands.nbands, dtype=torch.float64, device='cuda')
+    for r in range(4):
+        total += bands.partial_integrate(spec, int(b[r]), int(b[r + 1] - b[r]))
+    np.testing.assert_allclose((total * bands.heights).cpu().numpy(), g['bandflux'], rtol=1e-13)
+    batch = torch.stack([spec, 2.0 * spec, spec])
+    got = bands.integrate_batch(batch).cpu().numpy()
+    np.testing.assert_allclose(got[0], g['bandflux'], rtol=1e-13)
+    np.testing.assert_allclose(got[1], 2.0 * g['bandflux'], rtol=1e-13)
+    assert np.array_equal(got[0], got[2])
