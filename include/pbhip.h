@@ -83,6 +83,14 @@ int pb_lines_create(pb_lines **out, const double *lwn_h, const double *elow_h,
                     const double *own_h, int64_t onwn, double own0, double ownstep);
 /* stats[0]=lines in range, [1]=groups, [2]=co-added lines (nadd of _extcoeff.c:256) */
 int pb_lines_stats(const pb_lines *l, int64_t stats[3]);
+/* flag = 1 when the co-add groups were built on the device (lists in TLI order: isotope, then
+ * wavenumber), 0 when the host loop did it (any other order, or PB_LINES_HOST=1). */
+int pb_lines_grouped_on_device(const pb_lines *l, int *flag);
+/* The co-add groups in (isotope, fine index) order: first line, number of lines, nearest
+ * fine-grid index of the leader [ngroups each], and the first group of every isotope
+ * [niso + 1].  Any pointer may be NULL. */
+int pb_lines_groups(const pb_lines *l, int32_t *first_h, int32_t *count_h, int32_t *iown_h,
+                    int64_t *iso_gstart_h);
 void pb_lines_destroy(pb_lines *l);
 
 /* =========================================================================

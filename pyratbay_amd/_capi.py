@@ -36,6 +36,8 @@ _PROTOS = {
     'pb_voigt_destroy': [vp],
     'pb_lines_create': [C.POINTER(vp), vp, vp, vp, vp, i64, i32, vp, i64, f64, f64],
     'pb_lines_stats': [vp, C.POINTER(i64 * 3)],
+    'pb_lines_grouped_on_device': [vp, C.POINTER(i32)],
+    'pb_lines_groups': [vp, vp, vp, vp, vp],
     'pb_lines_destroy': [vp],
     'pb_lbl_create': [C.POINTER(vp), vp, vp, vp, i32, vp, i32, vp, vp, i32, vp, vp, vp, vp,
                       i32, f64, f64, i32, i32],

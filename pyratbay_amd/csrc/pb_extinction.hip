@@ -1844,6 +1844,32 @@ int pb_lines_create(pb_lines **out, const double *lwn_h, const double *elow_h,
     l->ownstep = own_at(1) - own_at(0);
     const double lo = l->own0, hi = l->own_last, step = l->ownstep;
 
+    l->h_lwn.assign(lwn_h, lwn_h + nlines);
+    l->h_elow.assign(elow_h, elow_h + nlines);
+    l->h_gf.assign(gf_h, gf_h + nlines);
+    int rc = PB_OK;
+    if (rc == PB_OK) rc = upload(&l->d_lwn, lwn_h, (size_t)nlines);
+    if (rc == PB_OK) rc = upload(&l->d_elow, elow_h, (size_t)nlines);
+    if (rc == PB_OK) rc = upload(&l->d_gf, gf_h, (size_t)nlines);
+    if (rc == PB_OK) rc = upload(&l->d_lid, lid_h, (size_t)nlines);
+    if (rc != PB_OK) {
+        pb_lines_destroy(l);
+        return rc;
+    }
+    // Grouping on the device (pb_lines.hip) when the list has the TLI order (isotope, then
+    // wavenumber) and valid isotope ids; PB_LINES_HOST=1 or any other order: the host loop below
+    bool grouped = false;
+    if (nlines > 0 && !getenv("PB_LINES_HOST") && lid_h[0] >= 0 && lid_h[nlines - 1] < niso) {
+        const int grc = pb_lines_group_device(l, lwn_h, lid_h, own_h);
+        if (grc == PB_OK) {
+            grouped = true;
+            l->grouped_on_device = 1;
+        } else if (grc != 1) {
+            pb_lines_destroy(l);
+            return grc;
+        }
+    }
+    if (!grouped) {
     struct Group {
         int32_t first, count, iown, iso;
     };
@@ -1854,7 +1880,7 @@ int pb_lines_create(pb_lines **out, const double *lwn_h, const double *elow_h,
         if (i < 0 || i >= niso) {
             pb::set_error("pb_lines_create: line %lld has isotope id %d outside [0,%d)",
                           (long long)ln, i, niso);
-            delete l;
+            pb_lines_destroy(l);
             return PB_ERR_ARG;
         }
         const double v = lwn_h[ln];
@@ -1893,27 +1919,17 @@ int pb_lines_create(pb_lines **out, const double *lwn_h, const double *elow_h,
     gfirst.resize(groups.size());
     gcount.resize(groups.size());
     giown.resize(groups.size());
+    std::vector<int32_t> giso(groups.size());
     for (size_t k = 0; k < groups.size(); k++) {
         gfirst[k] = groups[k].first;
         gcount[k] = groups[k].count;
         giown[k] = groups[k].iown;
+        giso[k] = groups[k].iso;
     }
-    l->h_lwn.assign(lwn_h, lwn_h + nlines);
-    l->h_elow.assign(elow_h, elow_h + nlines);
-    l->h_gf.assign(gf_h, gf_h + nlines);
-    int rc = PB_OK;
-    if (rc == PB_OK) rc = upload(&l->d_lwn, lwn_h, (size_t)nlines);
-    if (rc == PB_OK) rc = upload(&l->d_elow, elow_h, (size_t)nlines);
-    if (rc == PB_OK) rc = upload(&l->d_gf, gf_h, (size_t)nlines);
-    if (rc == PB_OK) rc = upload(&l->d_lid, lid_h, (size_t)nlines);
     if (rc == PB_OK) rc = upload(&l->d_gfirst, gfirst.data(), gfirst.size());
     if (rc == PB_OK) rc = upload(&l->d_gcount, gcount.data(), gcount.size());
     if (rc == PB_OK) rc = upload(&l->d_giown, giown.data(), giown.size());
-    {
-        std::vector<int32_t> giso(groups.size());
-        for (size_t k = 0; k < groups.size(); k++)
-            giso[k] = groups[k].iso;
-        if (rc == PB_OK) rc = upload(&l->d_giso, giso.data(), giso.size());
+    if (rc == PB_OK) rc = upload(&l->d_giso, giso.data(), giso.size());
     }
     if (rc == PB_OK) rc = upload(&l->d_iso_gstart, l->iso_gstart.data(), l->iso_gstart.size());
     if (rc != PB_OK) {
@@ -1921,6 +1937,29 @@ int pb_lines_create(pb_lines **out, const double *lwn_h, const double *elow_h,
         return rc;
     }
     *out = l;
+    return PB_OK;
+}
+
+int pb_lines_grouped_on_device(const pb_lines *l, int *flag)
+{
+    PB_REQUIRE(l && flag, "pb_lines_grouped_on_device: null pointer");
+    *flag = l->grouped_on_device;
+    return PB_OK;
+}
+
+int pb_lines_groups(const pb_lines *l, int32_t *first_h, int32_t *count_h, int32_t *iown_h,
+                    int64_t *iso_gstart_h)
+{
+    PB_REQUIRE(l, "pb_lines_groups: null handle");
+    const size_t n = (size_t)l->ngroups;
+    if (first_h)
+        std::copy(l->h_gfirst.begin(), l->h_gfirst.begin() + n, first_h);
+    if (count_h)
+        std::copy(l->h_gcount.begin(), l->h_gcount.begin() + n, count_h);
+    if (iown_h)
+        std::copy(l->h_giown.begin(), l->h_giown.begin() + n, iown_h);
+    if (iso_gstart_h)
+        std::copy(l->iso_gstart.begin(), l->iso_gstart.end(), iso_gstart_h);
     return PB_OK;
 }
 
@@ -2057,23 +2096,29 @@ int pb_lbl_create(pb_lbl **out, pb_voigt *voigt, pb_lines *lines, const double *
         // phase row of a profile become neighbours (k_ext_staged)
         const int osamp = voigt->osamp;
         const size_t ng = lines->h_giown.size();
+        // counting sort by phase inside every isotope (stable: positions stay ascending); a
+        // comparison sort with a modulo in its comparator took 1.3 s at 1e7 lines
         std::vector<int32_t> order(ng);
-        for (size_t k = 0; k < ng; k++)
-            order[k] = (int32_t)k;
         std::vector<int64_t> start((size_t)niso * (osamp + 1) + 1, 0);
         for (int i = 0; i < niso; i++) {
             const int64_t s0 = lines->iso_gstart[i], s1 = lines->iso_gstart[i + 1];
-            std::stable_sort(order.begin() + s0, order.begin() + s1, [&](int32_t x, int32_t y) {
-                return lines->h_giown[x] % osamp < lines->h_giown[y] % osamp;
-            });
             std::vector<int64_t> cnt((size_t)osamp + 1, 0);
             for (int64_t k = s0; k < s1; k++)
-                cnt[(size_t)(lines->h_giown[order[k]] % osamp) + 1]++;
+                cnt[(size_t)(lines->h_giown[k] % osamp) + 1]++;
             int64_t run = s0;
             for (int ph = 0; ph <= osamp; ph++) {
                 run += cnt[ph];
                 start[(size_t)i * (osamp + 1) + ph] = run;
             }
+            // start[ph] = first slot AFTER phase ph-1 ... re-derive the first slot of each phase
+            std::vector<int64_t> slot((size_t)osamp, 0);
+            int64_t at = s0;
+            for (int ph = 0; ph < osamp; ph++) {
+                slot[ph] = at;
+                at += cnt[(size_t)ph + 1];
+            }
+            for (int64_t k = s0; k < s1; k++)
+                order[(size_t)slot[(size_t)(lines->h_giown[k] % osamp)]++] = (int32_t)k;
         }
         start[(size_t)niso * (osamp + 1)] = (int64_t)ng;
         std::vector<int32_t> f(ng), c(ng), w(ng);

@@ -34,9 +34,14 @@ struct pb_voigt {
 
 int pb_voigt_ensure_flat(pb_voigt *v, hipStream_t stream);
 
+struct pb_lines;
+int pb_lines_group_device(pb_lines *l, const double *lwn_h, const int32_t *lid_h,
+                          const double *own_h);
+
 struct pb_lines {
     int64_t nlines = 0, ngroups = 0, nadd = 0, ninrange = 0;
     int niso = 0;
+    int grouped_on_device = 0;                          // co-add groups built by pb_lines.hip
     int64_t onwn = 0;
     double own0 = 0.0, own_last = 0.0, ownstep = 0.0;   // from the own[] array
     std::vector<int64_t> iso_gstart;                    // [niso+1] group segments

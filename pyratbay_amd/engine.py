@@ -124,6 +124,18 @@ class LineList:
         st = (C.c_int64 * 3)()
         call('pb_lines_stats', self._h, C.byref(st))
         self.ninrange, self.ngroups, self.nadd = st[0], st[1], st[2]
+        flag = C.c_int(0)
+        call('pb_lines_grouped_on_device', self._h, C.byref(flag))
+        self.grouped_on_device = bool(flag.value)
+
+    def groups(self):
+        """(first, count, iown)[ngroups] and iso_gstart[niso + 1] of the co-add groups."""
+        first = np.zeros(self.ngroups, np.int32)
+        count = np.zeros(self.ngroups, np.int32)
+        iown = np.zeros(self.ngroups, np.int32)
+        start = np.zeros(self.niso + 1, np.int64)
+        call('pb_lines_groups', self._h, hptr(first), hptr(count), hptr(iown), hptr(start))
+        return first, count, iown, start
 
     def close(self):
         if self._h:

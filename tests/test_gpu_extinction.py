@@ -327,3 +327,83 @@ def test_random_configurations(eng, orc, seed):
         got = out['staged'][layer]
         assert np.array_equal(got == 0, want == 0), layer
         np.testing.assert_allclose(got, want, rtol=RTOL)
+
+
+def reference_groups(lwn, lid, own):
+    """The sequential pass of _extcoeff.c:230-262 restated for the test: leaders, members."""
+    lo, hi, step = own[0], own[-1], own[1] - own[0]
+    first, count, iown = [], [], []
+    n = len(lwn)
+    ln = 0
+    while ln < n:
+        v = lwn[ln]
+        if v < lo or v > hi:
+            ln += 1
+            continue
+        i = int((v - lo) / step)
+        if i + 1 < len(own) and abs(v - own[i + 1]) < abs(v - own[i]):
+            i += 1
+        f, c = ln, 1
+        while ln + 1 != n and lid[ln + 1] == lid[f] and lwn[ln + 1] <= hi \
+                and abs(lwn[ln + 1] - own[i]) < step:
+            ln += 1
+            c += 1
+        first.append(f)
+        count.append(c)
+        iown.append(i)
+        ln += 1
+    return np.array(first, np.int32), np.array(count, np.int32), np.array(iown, np.int32)
+
+
+@pytest.mark.parametrize('kind', ['dense', 'ragged', 'one_iso_empty', 'nothing', 'golden'])
+def test_device_grouping_equals_reference_pass(eng, monkeypatch, kind):
+    """pb_lines.hip (forward pointers + pointer doubling) against the reference's sequential
+    co-adding pass and against the host loop of pb_lines_create: same leaders, member counts,
+    fine indices, per-isotope segments and counters."""
+    rng = np.random.default_rng(77)
+    own = 5000.0 + np.arange(200001) * 0.0005            # 100 cm-1
+    if kind == 'golden':
+        c = cases.extinction_inputs()
+        lwn, lid, own, niso = c['lwn'], c['lid'], c['own'], 3
+    else:
+        niso = 4
+        parts, ids = [], []
+        for i in range(niso):
+            n = {'dense': 40000, 'ragged': 3000, 'one_iso_empty': 0 if i == 2 else 5000,
+                 'nothing': 50}[kind]
+            if kind == 'nothing':
+                v = rng.uniform(6000, 6100, n)
+            elif kind == 'dense':
+                v = rng.uniform(4999.0, 5101.0, n)         # ~0.2 lines per fine step: chains
+                v[:n // 4] = v[n // 4:2 * (n // 4)] + rng.uniform(-0.9, 0.9, n // 4) * 0.0005
+            else:
+                v = rng.uniform(4990.0, 5110.0, n)         # plenty outside on both sides
+            parts.append(np.sort(v))
+            ids.append(np.full(n, i, np.int32))
+        lwn, lid = np.concatenate(parts), np.concatenate(ids)
+    n = len(lwn)
+    elow, gf = np.ones(n), np.ones(n)
+    dev_ll = eng.LineList(lwn, elow, gf, lid, niso, own)
+    assert dev_ll.grouped_on_device
+    monkeypatch.setenv('PB_LINES_HOST', '1')
+    host_ll = eng.LineList(lwn, elow, gf, lid, niso, own)
+    monkeypatch.delenv('PB_LINES_HOST')
+    assert not host_ll.grouped_on_device
+    want = reference_groups(lwn, lid, own)
+    for ll in (dev_ll, host_ll):
+        first, count, iown, start = ll.groups()
+        assert np.array_equal(first, want[0]) and np.array_equal(count, want[1])
+        assert np.array_equal(iown, want[2])
+        assert ll.ngroups == len(want[0]) and ll.nadd == int(np.sum(want[1] - 1))
+        assert ll.ninrange == int(np.sum(want[1]))
+        assert np.array_equal(start, np.searchsorted(lid[want[0]], np.arange(niso + 1)))
+    if kind == 'dense':
+        assert dev_ll.nadd > 10000 and np.max(want[1]) >= 4
+
+
+def test_unsorted_lines_fall_back_to_host_grouping(eng):
+    rng = np.random.default_rng(3)
+    own = 5000.0 + np.arange(20001) * 0.005
+    lwn = rng.uniform(5000, 5100, 500)                    # not sorted
+    ll = eng.LineList(lwn, np.ones(500), np.ones(500), np.zeros(500, np.int32), 1, own)
+    assert not ll.grouped_on_device and ll.ninrange == 500
