@@ -143,6 +143,18 @@ int pb_lbl_last_state(pb_lbl *p, int32_t *ofactor_h, double *kmax_h, int nlayers
  * profile block each layer can select (block_h[nlayers]).  Synchronises the stream. */
 int pb_lbl_last_layer_kinds(pb_lbl *p, int32_t *resident_h, int32_t *block_h, int nlayers,
                             void *stream);
+/* The same call in two halves, for wavenumber shards on several GPUs.  _begin derives the layer
+ * state and the records of the groups within reach of the shard, with the per-row maxima
+ * (_extcoeff.c:203-226) over THOSE groups only -- 1/N of the exp() work; the caller then
+ * all-reduces (MAX) the buffer pb_lbl_kmax_buffer returns over the ranks -- count 64-bit words
+ * holding the bit patterns of non-negative doubles, which order like integers -- and _end runs
+ * the gather with the global maxima (ethresh * kmax is then the same threshold on every rank). */
+int pb_lbl_extinction_begin(pb_lbl *p, double *ext_d, int64_t wbegin, int64_t wcount,
+                            const double *temp_d, const double *dens_d, const double *isoz_d,
+                            int64_t z_iso_stride, int64_t z_layer_stride, int nlayers, int add,
+                            void *stream);
+int pb_lbl_kmax_buffer(pb_lbl *p, void **kmax_d, int64_t *count);
+int pb_lbl_extinction_end(pb_lbl *p, void *stream);
 /* Work of the last pb_lbl_extinction call, counted on the device from its per-(layer, group)
  * records: work[0] = profile samples multiplied (the FMAs _extcoeff.c:302-307 keeps after
  * resampling), work[1] = lanes the LDS-staged kernels issue for them (256-sample spans),

@@ -46,6 +46,9 @@ _PROTOS = {
     'pb_lbl_set_gather_mode': [vp, i32],
     'pb_lbl_last_gather_mode': [vp, C.POINTER(i32)],
     'pb_lbl_extinction': [vp, vp, i64, i64, vp, vp, vp, i64, i64, i32, i32, vp],
+    'pb_lbl_extinction_begin': [vp, vp, i64, i64, vp, vp, vp, i64, i64, i32, i32, vp],
+    'pb_lbl_kmax_buffer': [vp, C.POINTER(vp), C.POINTER(i64)],
+    'pb_lbl_extinction_end': [vp, vp],
     'pb_lbl_last_state': [vp, vp, vp, i32, i32, vp],
     'pb_lbl_last_layer_kinds': [vp, vp, vp, i32, vp],
     'pb_lbl_last_work': [vp, C.POINTER(i64 * 3), vp],

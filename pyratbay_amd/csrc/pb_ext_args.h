@@ -71,6 +71,10 @@ struct LblArgs {
     const double *g_lead;             // leader lines in position order [3][ngroups]
     int use_records;
     int64_t ngroups;
+    // fine-index window of the groups whose records this call needs (a shard +- the largest
+    // reach), and whether groups outside it are left out of the per-row maxima too
+    int64_t rec_flo, rec_fhi;
+    int kmax_local;
     // resident-profile kernel: which layers it computes, its LDS capacity (doubles, 0 = off)
     // and, per isotope, the first position-sorted group at or after every output sample
     int32_t *ls_resident;

@@ -507,11 +507,19 @@ __global__ __launch_bounds__(kBlock) void k_records(LblArgs a)
         // the group's static data, in the order this pass's gather kernel walks the groups
         int iso = 0, first = 0, count = 0, iown = 0;
         double wavn = 0.0, elow = 0.0, gf = 0.0;
-        if (g < a.ngroups) {
+        // A wavenumber shard needs the records of the groups within reach of it only
+        // [rec_flo, rec_fhi]; the others still count for the per-row maximum unless the caller
+        // all-reduces the maxima of the shards (kmax_local: they are skipped altogether).
+        bool have = g < a.ngroups, inwin = false;
+        if (have) {
+            iown = (kPos ? a.giown : a.rk_iown)[g];
+            inwin = iown >= a.rec_flo && iown <= a.rec_fhi;
+            have = inwin || !a.kmax_local;
+        }
+        if (have) {
             iso = (kPos ? a.giso : a.rk_iso)[g];
             first = (kPos ? a.gfirst : a.rk_first)[g];
             count = (kPos ? a.gcount : a.rk_count)[g];
-            iown = (kPos ? a.giown : a.rk_iown)[g];
             wavn = (kPos ? a.g_lead : a.rk_lwn)[g];                // leader's record
             elow = (kPos ? a.g_lead + a.ngroups : a.rk_elow)[g];
             gf = (kPos ? a.g_lead + 2 * a.ngroups : a.rk_gf)[g];
@@ -525,7 +533,7 @@ __global__ __launch_bounds__(kBlock) void k_records(LblArgs a)
                 continue;
             double k = 0.0, lmax = 0.0;
             int ulo = 0, uhi = 0, q = 0, cell = 0, phi = 0, row = -1;
-            if (g < a.ngroups) {
+            if (have) {
                 row = a.isoiext[iso];
                 if (row >= 0 && a.add)
                     row = 0;
@@ -542,6 +550,12 @@ __global__ __launch_bounds__(kBlock) void k_records(LblArgs a)
                                                         temp, z);
                         k += kp;
                         lmax = fmax(lmax, kp);
+                    }
+                    if (!inwin) {
+                        // outside the shard's reach: the strength for the maximum, no record
+                        atomicMax(&s_max[i * a.nrows + row],
+                                  (unsigned long long)__double_as_longlong(lmax));
+                        continue;
                     }
                     const int ofactor = a.ls_ofactor[layer];
                     const int scale = a.ls_scale[layer];
@@ -1806,6 +1820,14 @@ struct pb_lbl {
     size_t vrec_alloc = 0;            // entries
     UnitHdr *uhdr = nullptr;
     size_t uhdr_alloc = 0;
+    struct Pending {                 // call begun with pb_lbl_extinction_begin
+        double *ext;
+        int64_t wbegin, wcount;
+        const double *temp, *dens, *isoz;
+        int64_t zs0, zs1;
+        int nlayers, add;
+        bool open;
+    } pending = {nullptr, 0, 0, nullptr, nullptr, nullptr, 0, 0, 0, 0, false};
     LblArgs last_args;               // arguments of the last launch (pb_lbl_last_work)
     bool last_packed = false;        // ... whose records are packed, one per (layer, group)
 };
@@ -2259,10 +2281,12 @@ int pb_lbl_set_ethresh(pb_lbl *p, double ethresh)
     return PB_OK;
 }
 
-int pb_lbl_extinction(pb_lbl *p, double *ext_d, int64_t wbegin, int64_t wcount,
-                      const double *temp_d, const double *dens_d, const double *isoz_d,
-                      int64_t z_iso_stride, int64_t z_layer_stride, int nlayers, int add,
-                      void *stream)
+// phase 0: the whole call; 1: up to and including the records, per-row maxima over the shard's
+// own groups only (the caller all-reduces them); 2: the gather of the call begun with phase 1
+static int lbl_extinction(pb_lbl *p, double *ext_d, int64_t wbegin, int64_t wcount,
+                          const double *temp_d, const double *dens_d, const double *isoz_d,
+                          int64_t z_iso_stride, int64_t z_layer_stride, int nlayers, int add,
+                          void *stream, int phase)
 {
     PB_REQUIRE(p && ext_d && temp_d && dens_d && isoz_d, "pb_lbl_extinction: null pointer");
     PB_REQUIRE(nlayers >= 1 && nlayers <= p->max_layers,
@@ -2362,13 +2386,30 @@ int pb_lbl_extinction(pb_lbl *p, double *ext_d, int64_t wbegin, int64_t wcount,
     a.wcount = wcount;
     a.ext = ext_d;
     {
+        // records are needed for the groups within reach of the shard only
+        int64_t hmax_all = 0;
+        for (int32_t h : v->psize)
+            hmax_all = std::max<int64_t>(hmax_all, h);
+        int64_t reach = hmax_all;
+        if (a.cutoff > 0.0)
+            reach = std::min(reach, (int64_t)(a.cutoff / a.ownstep) + 2 * (int64_t)v->osamp + 2);
+        reach += 2 * (int64_t)v->osamp;
+        const bool whole = wbegin == 0 && wcount == p->nwave;
+        a.rec_flo = whole ? INT64_MIN : wbegin * (int64_t)v->osamp - reach;
+        a.rec_fhi = whole ? INT64_MAX : (wbegin + wcount - 1) * (int64_t)v->osamp + reach;
+        a.kmax_local = phase != 0 ? 1 : 0;
+    }
+    {
         const char *e = getenv("PB_EXPERIMENT");
         a.experiment = e ? atoi(e) : 0;
     }
 
     // Kernel choice (constant-step grids): the LDS-staged kernel when several groups share
-    // a (tile, phase) row, else the global gather.  The choice depends only on global
-    // properties (never on the shard), so shards and the full grid run the same arithmetic.
+    // a (tile, phase) row, else the global gather.  Every kernel adds the terms of a sample in
+    // one fixed order, so a call is bitwise reproducible and shards of ONE configuration
+    // concatenate exactly; the choice of kernel and the phase split below do depend on the size
+    // of the call (shard width, layers), and a different choice changes the association of the
+    // per-sample sums: results of different configurations agree to ~1e-13, not bit for bit.
     constexpr int kStagedWaves = 8;
     constexpr int kStagedThreads = kStagedWaves * 64;
     // rows longer than kStageRowMax samples are staged in chunks: (phase, chunk) pairs act as
@@ -2495,9 +2536,13 @@ int pb_lbl_extinction(pb_lbl *p, double *ext_d, int64_t wbegin, int64_t wcount,
     }
     a.use_records = use_records ? 1 : 0;
 
+    if (phase != 2) {
     k_layer_state<<<nlayers, 64, ((size_t)a.nlor + a.ndop) * 8 + (size_t)a.ndivs * 4, s>>>(a);
     PB_LAUNCH_CHECK();
-    if (use_records) {
+    }
+    if (phase == 2) {
+        // records and maxima are in place
+    } else if (use_records) {
         // (one layer per thread for launches of few layers measured slower: 10 layers of C2
         // 49 us against 27 us with four; PB_REC_LAYERS=1 selects it)
         const int per = getenv("PB_REC_LAYERS") && atoi(getenv("PB_REC_LAYERS")) == 1 ? 1 : kRecLayers;
@@ -2521,6 +2566,8 @@ int pb_lbl_extinction(pb_lbl *p, double *ext_d, int64_t wbegin, int64_t wcount,
         k_kmax<<<grid, kBlock, (size_t)a.nrows * 8, s>>>(a, lines_per_block);
         PB_LAUNCH_CHECK();
     }
+    if (phase == 1)
+        return PB_OK;
     const int layer_groups = (nlayers + 7) / 8;
     const bool timed = p->ev_used + 2 <= (int)p->ev.size();
     if (timed)
@@ -2739,6 +2786,44 @@ int pb_lbl_extinction(pb_lbl *p, double *ext_d, int64_t wbegin, int64_t wcount,
         PB_HIP(hipEventRecord(p->ev[p->ev_used + 1], s));
         p->ev_used += 2;
     }
+    return PB_OK;
+}
+
+int pb_lbl_extinction(pb_lbl *p, double *ext_d, int64_t wbegin, int64_t wcount,
+                      const double *temp_d, const double *dens_d, const double *isoz_d,
+                      int64_t z_iso_stride, int64_t z_layer_stride, int nlayers, int add,
+                      void *stream)
+{
+    return lbl_extinction(p, ext_d, wbegin, wcount, temp_d, dens_d, isoz_d, z_iso_stride,
+                          z_layer_stride, nlayers, add, stream, 0);
+}
+
+int pb_lbl_extinction_begin(pb_lbl *p, double *ext_d, int64_t wbegin, int64_t wcount,
+                            const double *temp_d, const double *dens_d, const double *isoz_d,
+                            int64_t z_iso_stride, int64_t z_layer_stride, int nlayers, int add,
+                            void *stream)
+{
+    PB_REQUIRE(p, "pb_lbl_extinction_begin: null handle");
+    p->pending = {ext_d, wbegin, wcount, temp_d, dens_d, isoz_d, z_iso_stride, z_layer_stride,
+                  nlayers, add, true};
+    return lbl_extinction(p, ext_d, wbegin, wcount, temp_d, dens_d, isoz_d, z_iso_stride,
+                          z_layer_stride, nlayers, add, stream, 1);
+}
+
+int pb_lbl_extinction_end(pb_lbl *p, void *stream)
+{
+    PB_REQUIRE(p && p->pending.open, "pb_lbl_extinction_end: no call was begun");
+    const auto c = p->pending;
+    p->pending.open = false;
+    return lbl_extinction(p, c.ext, c.wbegin, c.wcount, c.temp, c.dens, c.isoz, c.zs0, c.zs1,
+                          c.nlayers, c.add, stream, 2);
+}
+
+int pb_lbl_kmax_buffer(pb_lbl *p, void **kmax_d, int64_t *count)
+{
+    PB_REQUIRE(p && kmax_d && count, "pb_lbl_kmax_buffer: null pointer");
+    *kmax_d = p->kmax_bits;
+    *count = (int64_t)p->max_layers * p->kmax_rows;
     return PB_OK;
 }
 

@@ -16,8 +16,10 @@ Two decompositions are provided:
   balances), one all-to-all turns [my layers, all columns] into [all layers, my columns],
   the column stages (optical depth, spectrum) run on the wavenumber shard, and the
   all-gather re-assembles the spectrum.  Per-rank work is 1/N of the single-GPU work with
-  the same tile geometry and no halo; the result is bit-identical to the single-GPU
-  spectrum because every ec row and every column is computed by the same arithmetic.
+  the same tile geometry and no halo.  Every rank gets the same spectrum bit for bit; against
+  the single-GPU spectrum it agrees to ~1e-13 (a rank-size launch splits the phases of a tile
+  between more workgroups, which changes the association of the per-sample sums -- bit for bit
+  only when both runs pick the same kernel and split, e.g. PB_STAGE_SPLIT=1).
 
 Band fluxes: all-reduce(SUM) of per-shard partial trapezoids (`allreduce_bandflux`).
 RCCL over xGMI on GPUs, gloo in the CPU tests.
@@ -123,6 +125,21 @@ class SpectrumGather:
         if base:
             self.full[rem * (base + 1):].view(self.world - rem, base).copy_(blocks[rem:, :base])
         return self.full
+
+
+def kmax_allreduce(group=None):
+    """The exchange step of the two-phase shard extinction (engine.LBL.extinction_begin/_end):
+    returns a function that all-reduces (MAX) the int64 view of the per-row maxima in place --
+    nlayers x rows words, the only mid-path collective of the wavenumber decomposition
+    (SURVEY 8e option 1; _extcoeff.c:225,265)."""
+    def exchange(kmax):
+        if _via_host(group):
+            host = kmax.cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.MAX, group=group)
+            kmax.copy_(host)
+        else:
+            dist.all_reduce(kmax, op=dist.ReduceOp.MAX, group=group)
+    return exchange
 
 
 def allreduce_bandflux(partial, heights=None, group=None):

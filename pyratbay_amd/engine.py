@@ -210,6 +210,40 @@ class LBL:
              _stream())
         return out
 
+    def extinction_begin(self, temp, dens, isoz, add=True, out=None, wbegin=0, wcount=None):
+        """First half of extinction() for a wavenumber shard of a multi-GPU run: layer state +
+        the records of the groups within reach of the shard, per-row maxima over those groups
+        only.  All-reduce (MAX) kmax_tensor() over the ranks, then call extinction_end()."""
+        nlayers = temp.shape[0]
+        if wcount is None:
+            wcount = self.nwave - wbegin
+        rows = 1 if add else self.nrows_sep
+        if out is None:
+            alloc = torch.zeros if self.resolution else torch.empty
+            out = alloc((nlayers, rows, wcount), dtype=torch.float64, device=temp.device)
+        assert out.shape == (nlayers, rows, wcount) and out.is_contiguous()
+        assert dens.shape == (nlayers, self.nmol) and isoz.shape == (self.niso, nlayers)
+        call('pb_lbl_extinction_begin', self._h, _ptr(out), int(wbegin), int(wcount), _ptr(temp),
+             _ptr(dens), _ptr(isoz), isoz.stride(0), isoz.stride(1), nlayers, int(bool(add)),
+             _stream())
+        return out
+
+    def kmax_tensor(self):
+        """The per-(layer, row) maxima of the plan as an int64 device tensor that ALIASES the
+        library's buffer (bit patterns of non-negative doubles: integer MAX = double max)."""
+        if getattr(self, '_kmax', None) is None:
+            ptr, n = C.c_void_p(), C.c_int64(0)
+            call('pb_lbl_kmax_buffer', self._h, C.byref(ptr), C.byref(n))
+
+            class _Alias:
+                __cuda_array_interface__ = {'shape': (n.value,), 'typestr': '<i8',
+                                            'data': (ptr.value, False), 'version': 2}
+            self._kmax = torch.as_tensor(_Alias(), device='cuda')
+        return self._kmax
+
+    def extinction_end(self):
+        call('pb_lbl_extinction_end', self._h, _stream())
+
     def timing_begin(self, max_launches):
         call('pb_lbl_timing_begin', self._h, int(max_launches))
 
@@ -593,6 +627,9 @@ class LBLSpectrum:
         self.ec = torch.empty((self.nlayers, 1, self.wcount), dtype=torch.float64,
                               device='cuda')
         self.depth = self.ideep = self.spectrum = None
+        # set to a function(tensor) that all-reduces (MAX) over the ranks to switch the
+        # extinction of a wavenumber shard to its two-phase form (dist.kmax_allreduce)
+        self.kmax_exchange = None
 
     def set_atmosphere(self, temp, dens, isoz, radius=None, continuum_density=None):
         """New temperature / number-density / partition-function (and radius) profiles for the
@@ -617,8 +654,17 @@ class LBLSpectrum:
                 self.intervals.copy_(dev(-np.diff(radius)))
 
     def extinction(self):
-        self.lbl.extinction(self.temp, self.dens, self.isoz, add=True, out=self.ec,
-                            wbegin=self.wbegin, wcount=self.wcount)
+        if self.kmax_exchange is not None:
+            # wavenumber shard of a multi-GPU run: every rank derives the records (and the
+            # strengths, the exp() work) of its own groups only; the per-row maxima that set
+            # the ethresh threshold are made global by ONE small all-reduce(MAX)
+            self.lbl.extinction_begin(self.temp, self.dens, self.isoz, add=True, out=self.ec,
+                                      wbegin=self.wbegin, wcount=self.wcount)
+            self.kmax_exchange(self.lbl.kmax_tensor())
+            self.lbl.extinction_end()
+        else:
+            self.lbl.extinction(self.temp, self.dens, self.isoz, add=True, out=self.ec,
+                                wbegin=self.wbegin, wcount=self.wcount)
         if self.continuum is not None:
             self.continuum.add(self.ec.view(self.nlayers, self.wcount), self.temp_host,
                                self.continuum_density)

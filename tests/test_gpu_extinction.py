@@ -407,3 +407,56 @@ def test_unsorted_lines_fall_back_to_host_grouping(eng):
     lwn = rng.uniform(5000, 5100, 500)                    # not sorted
     ll = eng.LineList(lwn, np.ones(500), np.ones(500), np.zeros(500, np.int32), 1, own)
     assert not ll.grouped_on_device and ll.ninrange == 500
+
+
+@pytest.mark.parametrize('gather', ['staged', 'global', 'rounds'])
+@pytest.mark.parametrize('ethresh', [1e-30, 1e-3])
+def test_two_phase_shards_with_kmax_exchange(eng, monkeypatch, gather, ethresh):
+    """The multi-GPU form of a wavenumber shard (pb_lbl_extinction_begin / kmax all-reduce /
+    _end): every "rank" derives records and strengths only for the groups within reach of its
+    shard, the per-row maxima are combined with an element-wise integer MAX (what the RCCL
+    all-reduce does), and the shards concatenate to the full-grid result bit for bit -- also
+    with a threshold high enough to drop most lines, i.e. the exchanged maxima really are the
+    global ones."""
+    import torch
+    from pyratbay_amd import synth
+    monkeypatch.setenv('PB_STAGE_SPLIT', '1')
+    case = synth.lbl_case(9001, 5, 40000, wnosamp=24, nlor=18, ndop=9, extent=80.0,
+                          cutoff=3.0, niso=3, seed=8)
+    g, atm, ln, iso, vg = (case[k] for k in ('grid', 'atm', 'lines', 'iso', 'voigt'))
+    iso['isoiext'] = np.array([0, 1, 0], np.int32)
+    vt = eng.VoigtTable.build(vg['lorentz'], vg['doppler'], vg['size'], g['ownstep'], 24)
+    ll = eng.LineList(ln['lwn'], ln['elow'], ln['gf'], ln['lid'], 3, g['own'])
+
+    def plan():
+        lbl = eng.LBL(vt, ll, g['wn'], g['divisors'], atm['mol_radius'], atm['mol_mass'],
+                      iso['isoimol'], iso['isomass'], iso['isoratio'], iso['isoiext'],
+                      vg['cutoff'], ethresh, max_layers=5)
+        lbl.set_gather_mode(gather)
+        return lbl
+    t, d, z = eng.dev(atm['temp']), eng.dev(atm['dens']), eng.dev(iso['isoz'])
+    for add in (True, False):
+        full_plan = plan()
+        full = host(full_plan.extinction(t, d, z, add=add))
+        _, kmax_full = full_plan.last_state(5, 1 if add else 2)
+        bounds = [0, 1300, 4096, 4097, 7000, 9001]
+        ranks = [plan() for _ in bounds[:-1]]
+        outs = [r.extinction_begin(t, d, z, add=add, wbegin=a, wcount=b - a)
+                for r, a, b in zip(ranks, bounds[:-1], bounds[1:])]
+        local = torch.stack([r.kmax_tensor().clone() for r in ranks])
+        glob = local.max(dim=0).values                          # the all-reduce (MAX)
+        nrow = 1 if add else 2
+        assert np.array_equal(glob[:5 * nrow].view(torch.float64).cpu().numpy().reshape(5, nrow),
+                              kmax_full)
+        # most ranks do not see the strongest lines themselves: the exchange matters
+        assert sum(not torch.equal(l_[:5 * nrow], glob[:5 * nrow]) for l_ in local) >= 3
+        for r in ranks:
+            r.kmax_tensor().copy_(glob)
+            r.extinction_end()
+        got = np.concatenate([host(o) for o in outs], axis=2)
+        assert np.array_equal(got, full), (gather, add)
+        if ethresh > 1e-10:
+            # the threshold does drop lines here: the result differs from the unthresholded one
+            loose = plan()
+            loose.set_ethresh(1e-30)
+            assert not np.array_equal(host(loose.extinction(t, d, z, add=add)), full)
