@@ -216,3 +216,32 @@ def test_exchange_pipeline_two_ranks(tmp_path, nlayers, nwave, nsteps):
     for rank in range(world):
         ok, n = np.load(tmp_path / f'p{rank}.npy')
         assert ok == 1 and n == nsteps + 2
+
+
+def _worker_kmax(rank, world, port, tmp):
+    sys.path.insert(0, ROOT)
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from pyratbay_amd import dist as pbd
+    # per-(layer, row) maxima as the bit patterns of non-negative doubles, one shard's view each
+    rng = np.random.default_rng(100 + rank)
+    local = 10.0**rng.uniform(-30, -15, 24)
+    local[rank::world] = 0.0                      # rows this shard saw no line of
+    bits = torch.from_numpy(local.view(np.int64).copy())
+    pbd.kmax_allreduce()(bits)
+    np.save(os.path.join(tmp, f'k{rank}.npy'), bits.numpy().view(np.float64))
+    np.save(os.path.join(tmp, f'l{rank}.npy'), local)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_kmax_exchange_two_ranks(tmp_path):
+    """dist.kmax_allreduce: integer MAX over the ranks of the double bit patterns = the maximum
+    of the doubles (the exchange step of the two-phase shard extinction)."""
+    world = 2
+    mp.spawn(_worker_kmax, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    local = [np.load(tmp_path / f'l{r}.npy') for r in range(world)]
+    want = np.maximum(local[0], local[1])
+    for rank in range(world):
+        assert np.array_equal(np.load(tmp_path / f'k{rank}.npy'), want)
