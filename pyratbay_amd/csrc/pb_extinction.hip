@@ -2457,6 +2457,17 @@ static int lbl_extinction(pb_lbl *p, double *ext_d, int64_t wbegin, int64_t wcou
         while (nsplit > 1 && (nsplit - 1) * plane > ((int64_t)1 << 30))
             nsplit--;
     }
+    {
+        // tile quantisation of a narrow shard: 12 500 samples are 3.05 tiles of 4096 (31 % of
+        // the workgroups' rows staged for nothing) but 6.1 of 2048 (15 %); one span per
+        // workgroup when that saves more than 12 % (N = 8 shards of C2: 0.305 -> 0.297 ms, of the
+        // 1e6-line list 1.47 -> 1.28 ms; N = 4: the two-span tile stays faster).  The sums do not
+        // depend on S (tests/test_gpu_extinction.py::test_staged_variants_agree).
+        const double w2 = (double)pb::div_up(wcount, 2 * sub) * 2 * sub / (double)wcount;
+        const double w1 = (double)pb::div_up(wcount, sub) * sub / (double)wcount;
+        if (w2 - w1 > 0.12)
+            S = 1;
+    }
     if (const char *e = getenv("PB_STAGE_S"))
         S = atoi(e) >= 4 ? 4 : atoi(e) >= 2 ? 2 : 1;
     if (const char *e = getenv("PB_STAGE_SPLIT"))
