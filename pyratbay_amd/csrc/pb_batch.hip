@@ -165,7 +165,10 @@ __device__ inline double deck_integrand(double f_above, double f_below, double r
     return slope * (rsurf - r_below) + f_below;
 }
 
-template <int kRows, bool kScalarPath>
+// kFma: tau += path*s as ONE fused multiply-add instead of the reference's product-then-sum
+// (two roundings): half the FP64 instructions, results equal to ~1e-16 relative.  Used only
+// where no optical depth is returned (the retrieval batch: spectrum only).
+template <int kRows, bool kScalarPath, bool kFma>
 __global__ __launch_bounds__(kBlock) void k_transit_fused(
     double *depth, int32_t *ideep, double *spectrum, const double *ec, const double *raypath,
     const double *radius, int64_t npath, double rstar, int itop, int ibottom, double maxdepth,
@@ -235,9 +238,13 @@ __global__ __launch_bounds__(kBlock) void k_transit_fused(
                     const double next = src[(int64_t)(i + 1) * nwave];
                     const double s = next + prev;
                     prev = next;
+                    double pv[kRows];                           // wave-uniform: scalar loads
 #pragma unroll
                     for (int k = 0; k < kRows; k++)
-                        tau[k] += pb_[i * kRows + k] * s;       // wave-uniform: scalar loads
+                        pv[k] = pb_[i * kRows + k];
+#pragma unroll
+                    for (int k = 0; k < kRows; k++)
+                        tau[k] = kFma ? fma(pv[k], s, tau[k]) : tau[k] + pv[k] * s;
                 }
             } else {
 #pragma unroll 4
@@ -556,10 +563,16 @@ int pb_transit_fused_launch(double *depth_d, int32_t *ideep_d, double *spectrum_
         path_d = work_d;
     }
 #define PB_FUSED(R, SC)                                                                          \
-    k_transit_fused<R, SC><<<grid, kBlock, SC ? 0 : (size_t)std::max(nrow, 1) * R * 8, s>>>(     \
+    k_transit_fused<R, SC, false><<<grid, kBlock, SC ? 0 : (size_t)std::max(nrow, 1) * R * 8, s>>>( \
         depth_d, ideep_d, spectrum_d, ec_d, path_d, radius_d, plen, rstar, itop, ibottom,        \
         maxdepth, nlayers, nwave, deck_row, rsurf)
-    if (scalar) {
+    static const bool no_fma = getenv("PB_TRANSIT_FMA") && atoi(getenv("PB_TRANSIT_FMA")) == 0;
+    if (scalar && rows == 16 && !depth_d && !ideep_d && nwalkers > 1 && !no_fma) {
+        // the retrieval batch: spectrum only
+        k_transit_fused<16, true, true><<<grid, kBlock, 0, s>>>(
+            depth_d, ideep_d, spectrum_d, ec_d, path_d, radius_d, plen, rstar, itop, ibottom,
+            maxdepth, nlayers, nwave, deck_row, rsurf);
+    } else if (scalar) {
         if (rows == 40)
             PB_FUSED(40, true);
         else if (rows == 16)
