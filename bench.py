@@ -455,7 +455,28 @@ def main():
     else:
         other = 'layers' if args.shard == 'wavenumber' else 'wavenumber'
         order = [args.shard, other]
-    runs = [run_decomposition(k) for k in order]
+    runs, failed = [], []
+    for k in order:
+        # a decomposition that fails (a collective the backend rejects, ...) must not take the
+        # other one's number with it: it is reported in config.decompositions with its error
+        try:
+            runs.append(run_decomposition(k))
+        except Exception as e:                                   # noqa: BLE001
+            if world == 1:
+                raise
+            failed.append({'kind': k, 'error': f'{type(e).__name__}: {e}'[:300]})
+            ok = torch.tensor([0.0], device=dev_reduce)
+        else:
+            ok = torch.tensor([1.0], device=dev_reduce)
+        if world > 1:
+            # every rank must agree on whether the decomposition ran (a rank-local failure would
+            # otherwise leave the others waiting in a collective of the next one)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if float(ok.item()) == 0.0 and runs and runs[-1]['kind'] == k:
+                failed.append({'kind': k, 'error': 'failed on another rank'})
+                runs.pop()
+    if not runs:
+        raise SystemExit(f'every decomposition failed: {failed}')
     # `value` = the faster decomposition of this run (both end in the wavenumber-sharded RT and
     # the RCCL all-gather north_star names; they differ in how the extinction is cut); the other
     # one is listed beside it in config.decompositions.  PB_BENCH_PRIMARY=first: the --shard one.
@@ -530,7 +551,7 @@ def main():
             out['config']['decompositions'] = [
                 {k: r[k] for k in ('kind', 'value', 'ms_per_step', 'pipelined',
                                    'unpipelined_ms_per_spectrum', 'init_seconds') if k in r}
-                for r in runs]
+                for r in runs] + failed
         if want_cpu:
             budget = args.cpu_layers or (nlayers if args.workload in ('c2', 'small') else 16)
             one, many = cpu_legs(
