@@ -114,6 +114,7 @@ struct LblArgs {
     int32_t *ls_ofactor, *ls_scale;
     int64_t *ls_dnwn;
     double *ls_dwnstep;
+    double *ls_cutsteps, *ls_inv_ofactor, *ls_inv_scale;   // per-layer quotients for k_records
     double *li_alphad, *li_dens, *li_z;
     int32_t *li_ilor, *li_hmax;
     int32_t *li_rowmax;               // longest phase row the (layer, isotope) can select

@@ -144,6 +144,9 @@ __global__ __launch_bounds__(64) void k_layer_state(LblArgs a)
         const int ofactor = s_div[d - 1];
         a.ls_ofactor[layer] = ofactor;
         a.ls_dwnstep[layer] = a.ownstep * ofactor;
+        a.ls_cutsteps[layer] = a.cutoff / (a.ownstep * ofactor);
+        a.ls_inv_ofactor[layer] = 1.0 / (double)ofactor;
+        a.ls_inv_scale[layer] = 1.0 / (double)(int)round(a.wnstep / a.ownstep / ofactor);
         a.ls_dnwn[layer] = 1 + (a.onwn - 1) / ofactor;
         a.ls_scale[layer] = (int)round(a.wnstep / a.ownstep / ofactor);
         a.ls_resident[layer] = a.res_cap > 0 && s_block <= a.res_cap;
@@ -210,10 +213,19 @@ struct Window {
     int half, cell;
 };
 
+// a / d truncated toward zero like C's integer division, for |a| < 2^31, 0 < d < 2^20, inv = 1.0/d
+__device__ inline int trunc_div_inv(int a, double inv)
+{
+    return a >= 0 ? floor_div_inv(a, inv) : -floor_div_inv(-a, inv);
+}
+
+// cutsteps = cutoff / dwnstep and inv_ofactor = 1.0 / ofactor are per-layer values prepared by
+// k_layer_state (the same quotients the reference forms per line, _extcoeff.c:281-299)
 __device__ inline Window group_window(const LblArgs &a, double wavn, int iown, int ilor,
                                       double alphad, int ofactor, double dwnstep,
                                       int64_t dnwn, int idop_lo, int idop_hi,
-                                      const double *doppler = nullptr)
+                                      const double *doppler, double cutsteps,
+                                      double inv_ofactor)
 {
     // [idop_lo, idop_hi] brackets the answer (nearest index is monotonic in wavn), which
     // turns the bisection over the whole Doppler grid into 0-2 steps; `doppler` may point
@@ -227,14 +239,13 @@ __device__ inline Window group_window(const LblArgs &a, double wavn, int iown, i
     w.cell = ilor * a.ndop + idop;
     w.half = a.psize[w.cell];
     const int subw = iown - idwn * ofactor;
-    w.minj = idwn - (w.half - subw) / ofactor;
-    w.maxj = idwn + (w.half + subw) / ofactor;
+    w.minj = idwn - trunc_div_inv(w.half - subw, inv_ofactor);
+    w.maxj = idwn + trunc_div_inv(w.half + subw, inv_ofactor);
     if (w.minj < 0)
         w.minj = 0;
     if (w.maxj > dnwn)
         w.maxj = dnwn;
     if (a.cutoff > 0.0) {
-        const double cutsteps = a.cutoff / dwnstep;      // wave-uniform
         const int mincut = (int)(idwn - cutsteps);
         const int maxcut = (int)(idwn + cutsteps);
         if (mincut > w.minj)
@@ -558,12 +569,12 @@ __global__ __launch_bounds__(kBlock) void k_records(LblArgs a)
                         continue;
                     }
                     const int ofactor = a.ls_ofactor[layer];
-                    const int scale = a.ls_scale[layer];
                     const Window w = group_window(a, wavn, iown, a.li_ilor[li], a.li_alphad[li],
                                                   ofactor, a.ls_dwnstep[layer], a.ls_dnwn[layer],
-                                                  0, a.ndop - 1, s_dop);
+                                                  0, a.ndop - 1, s_dop, a.ls_cutsteps[layer],
+                                                  a.ls_inv_ofactor[layer]);
                     // kept samples: minj <= scale*jo < maxj, inside the profile and the grid
-                    const double inv_scale = 1.0 / (double)scale;
+                    const double inv_scale = a.ls_inv_scale[layer];
                     ulo = -floor_div_inv(-(int)w.minj, inv_scale);
                     uhi = -floor_div_inv(-(int)w.maxj, inv_scale);
                     ulo = max(ulo, -floor_div_inv(w.half - iown, a.inv_osamp));
@@ -1656,7 +1667,9 @@ __global__ __launch_bounds__(kBlock) void k_ext_linterp(LblArgs a)
                         if (a.add)
                             k *= dens;
                         const Window w = group_window(a, a.lwn[first], iown, ilor, alphad,
-                                                      ofactor, dwnstep, dnwn, 0, a.ndop - 1);
+                                                      ofactor, dwnstep, dnwn, 0, a.ndop - 1,
+                                                      nullptr, a.ls_cutsteps[layer],
+                                                      a.ls_inv_ofactor[layer]);
                         // dynamic sample j reads flat[pindex + half + ofactor*j - iown]
                         mn = (int)w.minj;
                         mx = (int)w.maxj;
@@ -1782,6 +1795,7 @@ struct pb_lbl {
     int32_t *li_rowmax = nullptr, *li_hlo = nullptr, *li_hhi = nullptr;
     int64_t *ls_dnwn = nullptr;
     double *ls_dwnstep = nullptr, *li_alphad = nullptr, *li_dens = nullptr, *li_z = nullptr;
+    double *ls_quot = nullptr;        // [3][max_layers]: cutsteps, 1/ofactor, 1/scale
     unsigned long long *kmax_bits = nullptr;
     int kmax_rows = 0;
     // phase-sorted copy of the groups for the LDS-staged kernel
@@ -2102,6 +2116,7 @@ int pb_lbl_create(pb_lbl **out, pb_voigt *voigt, pb_lines *lines, const double *
     alloc((void **)&p->ls_scale, L * 4);
     alloc((void **)&p->ls_dnwn, L * 8);
     alloc((void **)&p->ls_dwnstep, L * 8);
+    alloc((void **)&p->ls_quot, 3 * L * 8);
     alloc((void **)&p->li_alphad, LI * 8);
     alloc((void **)&p->li_dens, LI * 8);
     alloc((void **)&p->li_z, LI * 8);
@@ -2360,6 +2375,9 @@ static int lbl_extinction(pb_lbl *p, double *ext_d, int64_t wbegin, int64_t wcou
     a.ls_scale = p->ls_scale;
     a.ls_dnwn = p->ls_dnwn;
     a.ls_dwnstep = p->ls_dwnstep;
+    a.ls_cutsteps = p->ls_quot;
+    a.ls_inv_ofactor = p->ls_quot + p->max_layers;
+    a.ls_inv_scale = p->ls_quot + 2 * (size_t)p->max_layers;
     a.li_alphad = p->li_alphad;
     a.li_dens = p->li_dens;
     a.li_z = p->li_z;
@@ -2949,6 +2967,7 @@ void pb_lbl_destroy(pb_lbl *p)
     (void)hipFree(p->gs_start);
     (void)hipFree(p->ls_dnwn);
     (void)hipFree(p->ls_dwnstep);
+    (void)hipFree(p->ls_quot);
     (void)hipFree(p->li_alphad);
     (void)hipFree(p->li_dens);
     (void)hipFree(p->li_z);
