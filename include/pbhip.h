@@ -368,6 +368,14 @@ int pb_transit_spectrum_batch(double *spectrum_d, double *depth_d, int32_t *idee
                               const double *radius_d, double rstar, int itop, int ibottom,
                               double maxdepth, int nlayers, int nwave, int nwalkers,
                               void *work_d, void *stream);
+/* Emission geometry for a batch: plane_parallel_optical_depth (src_c/_trapezoid.c:175-213) +
+ * blackbody + intensity + quadrature sum (pyrat/spectrum.py:366-377) in one pass, no cloud deck:
+ * ec_d[nwalkers,nlayers,nwave], intervals_d[nwalkers,nlayers-1], temp_d[nwalkers,nlayers] ->
+ * flux_d[nwalkers,nwave]. */
+int pb_emission_flux_batch(double *flux_d, const double *ec_d, const double *intervals_d,
+                           const double *wn_d, const double *temp_d, const double *mu_d,
+                           const double *weights_d, int nmu, double maxdepth, int itop,
+                           int ibottom, int nlayers, int nwave, int nwalkers, void *stream);
 /* PassBand.integrate for a batch of full-grid spectra: bandflux_d[nwalkers,nbands]
  * (x heights_d[b] when given). */
 int pb_band_integrate_batch(double *bandflux_d, const double *spectrum_d, const double *wn_d,

@@ -416,6 +416,77 @@ __global__ void k_emission_flux(double *flux, double *intensity, const double *t
 }
 
 // ---------------------------------------------------------------------------
+// Plane-parallel optical depth + emission flux in ONE pass, for a batch of walkers (the
+// retrieval inner loop in emission geometry): the running optical depth of k_plane_depth
+// (_trapezoid.c:175-213) feeds the intensity sums of k_emission_flux (_trapezoid.c:304-341 +
+// pyrat/spectrum.py:366-377) layer by layer, so depth is neither written nor read.  Same
+// operations in the same order as the two kernels run one after the other.
+// grid (columns, walkers); ec[nw][L][W], intervals[nw][L-1], temp[nw][L] -> flux[nw][W].
+// ---------------------------------------------------------------------------
+__global__ void k_emission_fused(double *flux, const double *ec, const double *intervals,
+                                 const double *wn, const double *temp, const double *mu,
+                                 const double *weights, int nmu, double maxdepth, int itop,
+                                 int ibottom, int nlayers, int nwave)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= nwave)
+        return;
+    const int wk = blockIdx.y;
+    ec += (int64_t)wk * nlayers * nwave;
+    const double *h = intervals + (int64_t)wk * (nlayers - 1);
+    const double *tp = temp + (int64_t)wk * nlayers;
+    const double w = wn[j];
+    const double factor = planck_factor(w);
+    const int rtop = itop;
+    double acc[kMaxMu], eprev[kMaxMu];
+#pragma unroll
+    for (int k = 0; k < kMaxMu; k++) {
+        acc[k] = 0.0;
+        eprev[k] = k < nmu ? exp(-0.0 / mu[k]) : 0.0;        // depth[rtop] = 0
+    }
+    double bprev = planck(factor, w, tp[rtop]);
+    double depth = 0.0, tlast = 0.0;
+    double prev = ec[(int64_t)itop * nwave + j];
+    int last = rtop;                                          // deepest layer seen so far
+    for (int k = itop + 1; k < nlayers; k++) {
+        const double cur = ec[(int64_t)k * nwave + j];
+        depth += 0.5 * h[k - 1] * (cur + prev);
+        prev = cur;
+        // intensity terms of the interval (k-1, k)
+        const double bnext = planck(factor, w, tp[k]);
+        const double bsum = bnext + bprev;
+#pragma unroll
+        for (int m = 0; m < kMaxMu; m++) {
+            if (m < nmu) {
+                const double enext = exp(-depth / mu[m]);
+                acc[m] += (enext - eprev[m]) * bsum;
+                eprev[m] = enext;
+            }
+        }
+        bprev = bnext;
+        tlast = depth;
+        last = k;
+        if (depth >= maxdepth || k == ibottom || k == nlayers - 1)
+            break;
+    }
+    // (itop == nlayers-1: no interval; the reference's loop then leaves ideep = nlayers, clipped)
+    const double blast = (last > rtop) ? bprev : planck(factor, w, tp[last]);
+    double total = 0.0;
+#pragma unroll
+    for (int m = 0; m < kMaxMu; m++) {
+        if (m < nmu) {
+            double val;
+            if (last - rtop == 1)
+                val = blast;
+            else
+                val = blast * exp(-tlast / mu[m]) - 0.5 * acc[m];
+            total += val * weights[m];
+        }
+    }
+    flux[(int64_t)wk * nwave + j] = total;
+}
+
+// ---------------------------------------------------------------------------
 // _simpson.simps2D (src_c/_simpson.c:167-203, include/simpson.h:29-47)
 // ---------------------------------------------------------------------------
 __global__ void k_simps2d(double *out, const double *y, int ny, int nwave,
@@ -908,6 +979,27 @@ int pb_loglike(double *loglike_d, const double *bandflux_d, const double *data_d
     PB_REQUIRE(loglike_d && bandflux_d && data_d && uncert_d, "pb_loglike: null pointer");
     k_loglike<<<nwalkers, 64, 0, pb::as_stream(stream)>>>(loglike_d, bandflux_d, data_d, uncert_d,
                                                          nbands);
+    PB_LAUNCH_CHECK();
+    return PB_OK;
+}
+
+int pb_emission_flux_batch(double *flux_d, const double *ec_d, const double *intervals_d,
+                           const double *wn_d, const double *temp_d, const double *mu_d,
+                           const double *weights_d, int nmu, double maxdepth, int itop,
+                           int ibottom, int nlayers, int nwave, int nwalkers, void *stream)
+{
+    PB_REQUIRE(nlayers >= 1 && nwave >= 0 && nwalkers >= 0, "pb_emission_flux_batch: bad shape");
+    PB_REQUIRE(nmu >= 1 && nmu <= kMaxMu, "pb_emission_flux_batch: nmu must be 1..%d", kMaxMu);
+    PB_REQUIRE(itop >= 0 && itop < nlayers, "pb_emission_flux_batch: itop out of range");
+    if (nwave == 0 || nwalkers == 0)
+        return PB_OK;
+    PB_REQUIRE(flux_d && ec_d && wn_d && temp_d && mu_d && weights_d &&
+                   (nlayers == 1 || intervals_d),
+               "pb_emission_flux_batch: null pointer");
+    dim3 grid(pb::div_up(nwave, kBlock), nwalkers);
+    k_emission_fused<<<grid, kBlock, 0, pb::as_stream(stream)>>>(
+        flux_d, ec_d, intervals_d, wn_d, temp_d, mu_d, weights_d, nmu, maxdepth, itop, ibottom,
+        nlayers, nwave);
     PB_LAUNCH_CHECK();
     return PB_OK;
 }

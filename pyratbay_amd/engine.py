@@ -354,6 +354,17 @@ def transit_spectrum_batch(ec, raypath, radius, rstar, itop, ibottom, maxdepth,
     return (spectrum, depth, ideep) if want_depth else spectrum
 
 
+def emission_flux_batch(ec, intervals, wn, temps, mu, weights, itop, ibottom, maxdepth):
+    """plane-parallel optical depth + emission flux for a batch: ec[nw, L, W],
+    intervals[nw, L-1], temps[nw, L] -> flux[nw, W] (no cloud deck)."""
+    nw, nlayers, nwave = ec.shape
+    flux = torch.empty((nw, nwave), dtype=torch.float64, device=ec.device)
+    call('pb_emission_flux_batch', _ptr(flux), _ptr(ec), _ptr(intervals.contiguous()), _ptr(wn),
+         _ptr(temps.contiguous()), _ptr(mu), _ptr(weights), len(mu), float(maxdepth), int(itop),
+         int(ibottom), nlayers, nwave, nw, _stream())
+    return flux
+
+
 # --------------------------------------------------------------------------
 # Column stages (device tensors in, device tensors out)
 # --------------------------------------------------------------------------
@@ -800,18 +811,28 @@ class TableSpectrum:
         band integration -- with no per-walker Python and no host synchronisation.  Walkers
         whose temperatures leave the table's range get +inf, like eval()'s reject path
         (pyrat_obj.py:302-320, 378-380)."""
-        assert self.rt_path == 'transit' and self.continuum is None, \
-            'eval_bands: transit geometry on sampled cross sections'
+        assert self.rt_path in ('transit', 'emission') and self.continuum is None, \
+            'eval_bands: transit or emission geometry on sampled cross sections'
         nw = temps.shape[0]
         out = torch.empty((nw, bands.nbands), dtype=torch.float64, device='cuda')
         if radius is None:
             radius = self.radius.view(1, -1)
         shared_radius = radius.shape[0] == 1
-        path1 = transit_path_device(radius[0], self.itop).view(1, -1) if shared_radius else None
+        transit = self.rt_path == 'transit'
+        path1 = (transit_path_device(radius[0], self.itop).view(1, -1)
+                 if shared_radius and transit else None)
         for w0 in range(0, nw, chunk):
             w1 = min(w0 + chunk, nw)
             n = w1 - w0
             ec = interp_ec_batch(self.etable, self.ttable, temps[w0:w1], dens[w0:w1])
+            if not transit:
+                rad = radius.expand(n, -1) if shared_radius else radius[w0:w1]
+                intervals = (rad[:, :-1] - rad[:, 1:]).contiguous()        # -diff(radius)
+                spectra = emission_flux_batch(ec, intervals, self.wn, temps[w0:w1], self.mu,
+                                              self.weights, self.itop, self.nlayers,
+                                              self.maxdepth)
+                bands.integrate_batch(spectra, out[w0:w1])
+                continue
             if shared_radius:
                 rad = radius.expand(n, -1).contiguous()
                 path = path1.expand(n, -1).contiguous()

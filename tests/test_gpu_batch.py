@@ -181,3 +181,53 @@ def test_eval_bands_64_walkers_vs_oracle(eng, orc):
     got2 = host(model.eval_bands(eng.dev(temps[:8]), eng.dev(dens[:8]), pb))
     spec = model.eval(temps[1], eng.dev(dens[1]))
     np.testing.assert_allclose(got2[1], host(pb.partial_integrate(spec) * pb.heights), rtol=1e-13)
+
+
+def test_eval_bands_emission_batch(eng, orc):
+    """The walker batch in emission geometry (plane-parallel optical depth + Planck + intensity +
+    quadrature sum fused in one pass, pb_emission_flux_batch): equal to the one-walker eval()
+    bit for bit and to the oracle chain at 1e-11; rejects as in the transit case."""
+    from pyratbay_amd import synth
+    rng = np.random.default_rng(5)
+    nspec, ntemp, L, W, nw = 3, 8, 18, 2001, 21
+    g = synth.spectral_grid(4000.0, 4000.0 + (W - 1) * 0.05 + 0.01, 0.05, 12)
+    wn = g['wn']
+    ttable = np.linspace(300.0, 3000.0, ntemp)
+    press = np.logspace(-6, 2, L)
+    etable = 10.0**rng.uniform(-27, -21, (nspec, ntemp, L, 1)) * \
+        10.0**rng.uniform(-1, 1, (nspec, 1, 1, W))
+    base_radius = np.linspace(8.0e9, 7.0e9, L)
+    raygrid = np.radians([0.0, 20.0, 40.0, 60.0, 80.0])
+    mu = np.cos(raygrid)
+    bounds = np.linspace(0, 0.5 * np.pi, len(raygrid) + 1)
+    bounds[1:-1] = 0.5 * (raygrid[:-1] + raygrid[1:])
+    weights = np.pi * (np.sin(bounds[1:])**2 - np.sin(bounds[:-1])**2)
+    model = eng.TableSpectrum(etable, ttable, wn, base_radius, 8.8e10, rt_path='emission',
+                              quadrature_mu=mu, quadrature_weights=weights)
+    bands = []
+    for lo, hi in ((20, 900), (800, 1990)):
+        resp = np.exp(-np.linspace(-1.5, 1.5, hi - lo)**2)
+        bands.append((lo, resp, 1.0 / np.trapezoid(resp, wn[lo:hi])))
+    pb = eng.PassBands(wn, bands)
+    temps = 1500.0 * (1 + 0.1 * rng.uniform(-1, 1, (nw, 1))) * np.linspace(0.8, 1.2, L)
+    dens = (press / temps)[:, :, None] * 7.2e21 * 10.0**rng.uniform(-6, -2, (nw, 1, nspec))
+    radius = np.array([hydro_radius(rng, L, 0.01) for _ in range(nw)])
+    temps[4, 2] = 3001.0
+    got = host(model.eval_bands(eng.dev(temps), eng.dev(dens), pb, radius=eng.dev(radius),
+                                chunk=8))
+    assert np.all(np.isinf(got[4]))
+    for w in (0, 7, 20):
+        model.set_radius(radius[w])
+        spec = model.eval(temps[w], eng.dev(dens[w]))
+        one = host(pb.partial_integrate(spec) * pb.heights)
+        np.testing.assert_allclose(got[w], one, rtol=1e-14)
+        ec = np.zeros((L, W))
+        orc.interp_ec(ec, etable, ttable, temps[w], dens[w], 0, L)
+        depth = np.zeros((L, W))
+        ideep = np.zeros(W, np.int32)
+        orc.plane_parallel_optical_depth(depth, ideep, ec, -np.diff(radius[w]), 10.0, 0, L)
+        B = orc.blackbody_wn_2D(wn, temps[w])
+        inten = orc.intensity(depth, ideep, B, mu, 0)
+        flux = np.sum(inten * weights[:, None], axis=0)
+        want = [np.trapezoid(flux[s:s + len(r)] * r, wn[s:s + len(r)]) * h for s, r, h in bands]
+        np.testing.assert_allclose(got[w], want, rtol=1e-11)
