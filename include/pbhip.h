@@ -353,7 +353,7 @@ int pb_transit_path(double *raypath_d, const double *radius_d, int itop, int nla
                     int nwalkers, void *stream);
 /* interp_ec (src_c/_extcoeff.c:367-418), assigning form, for a batch: temps_d[nwalkers,nlayers],
  * density_d[nwalkers,nlayers,nmol] -> ec_d[nwalkers,nlayers,nwave].  The table is read once per
- * chunk of walkers.  work_d: nwalkers*nlayers*20 bytes of device scratch.  nmol <= 8. */
+ * chunk of walkers.  work_d: nwalkers*nlayers*136 bytes of device scratch.  nmol <= 8. */
 int pb_interp_ec_batch(double *ec_d, const double *etable_d, const double *ttable_d,
                        const double *temps_d, const double *density_d, void *work_d, int nmol,
                        int ntemp, int nlayers, int nwave, int nwalkers, void *stream);

@@ -54,8 +54,8 @@ __global__ __launch_bounds__(kBlock) void k_transit_path(double *raypath, const 
 // k_interp_weights (wave-uniform loads).  kS = species held in registers (<= 8).
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(kBlock) void k_interp_weights(
-    int32_t *tlo_out, double *wlo_out, double *whi_out, const double *ttable,
-    const double *temps, int ntemp, int64_t n)
+    int32_t *tlo_out, double *coef_out, const double *ttable, const double *temps,
+    const double *density, int nmol, int ncoef, int ntemp, int64_t n)
 {
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (i >= n)
@@ -67,23 +67,34 @@ __global__ __launch_bounds__(kBlock) void k_interp_weights(
         tlo--;
     tlo = max(tlo, 0);
     const double span = ttable[tlo + 1] - ttable[tlo];
+    const double a = (ttable[tlo + 1] - t) / span, c = (t - ttable[tlo]) / span;
     tlo_out[i] = tlo;
-    wlo_out[i] = (ttable[tlo + 1] - t) / span;
-    whi_out[i] = (t - ttable[tlo]) / span;
+    // the products interp_ec forms per sample, once per (walker, layer): w_lo*d_j, w_hi*d_j
+    double *co = coef_out + i * 2 * ncoef;
+    for (int j = 0; j < ncoef; j++) {
+        const double d = j < nmol ? density[i * nmol + j] : 0.0;
+        co[j] = a * d;
+        co[ncoef + j] = c * d;
+    }
 }
 
 template <int kS>
 __global__ __launch_bounds__(kBlock) void k_interp_ec_batch(
-    double *ec, const double *etable, const int32_t *tlo, const double *wlo, const double *whi,
-    const double *density, int nmol, int ntemp, int nlayers, int nwave, int nwalkers, int chunk)
+    double *ec, const double *etable, const int32_t *tlo, const double *coef, int nmol,
+    int ntemp, int nlayers, int nwave, int nwalkers, int chunk)
 {
+    // per-(walker, layer) brackets and coefficients are wave-uniform: through the constant
+    // address space they are SCALAR loads (one s_load_dwordx16 per walker at four species)
+    typedef const double __attribute__((address_space(4))) *ccoef_t;
+    typedef const int32_t __attribute__((address_space(4))) *ctlo_t;
+    const ctlo_t ctlo = (ctlo_t)(unsigned long long)tlo;
     const int k = blockIdx.y;
     const int i = blockIdx.x * kBlock + threadIdx.x;
     const int w0 = blockIdx.z * chunk, w1 = min(w0 + chunk, nwalkers);
-    // brackets used by the chunk at this layer (wave-uniform)
+    // brackets used by the chunk at this layer
     int bmin = ntemp, bmax = -1;
     for (int w = w0; w < w1; w++) {
-        const int b = tlo[(int64_t)w * nlayers + k];
+        const int b = ctlo[(int64_t)w * nlayers + k];
         bmin = min(bmin, b);
         bmax = max(bmax, b);
     }
@@ -103,15 +114,14 @@ __global__ __launch_bounds__(kBlock) void k_interp_ec_batch(
         }
         for (int w = w0; w < w1; w++) {
             const int64_t wk = (int64_t)w * nlayers + k;
-            if (tlo[wk] != b)
+            if (ctlo[wk] != b)
                 continue;                                   // wave-uniform
-            const double a = wlo[wk], c = whi[wk];
-            const double *d = density + wk * nmol;
+            const ccoef_t co = (ccoef_t)(unsigned long long)(coef + wk * 2 * kS);
             double acc = 0.0;
 #pragma unroll
             for (int j = 0; j < kS; j++)
                 if (j < nmol)
-                    acc += lo[j] * (a * d[j]) + hi[j] * (c * d[j]);
+                    acc += lo[j] * co[j] + hi[j] * co[kS + j];
             ec[wk * nwave + i] = acc;
         }
     }
@@ -186,7 +196,9 @@ __global__ __launch_bounds__(kBlock) void k_transit_fused(
     if (depth)
         depth += (int64_t)w * plane;
     const double *path = raypath ? raypath + (int64_t)w * npath : nullptr;
-    const double *rad = radius ? radius + (int64_t)w * nlayers : nullptr;
+    // the walker's radii are wave-uniform: scalar loads through the constant address space
+    typedef const double __attribute__((address_space(4))) *crad_t;
+    const crad_t rad = (crad_t)(unsigned long long)(radius ? radius + (int64_t)w * nlayers : nullptr);
     const int nimpact = min(ibottom, nlayers) - itop;     // rows 0..nimpact-1 are evaluated
     const double *src = ec + (int64_t)itop * nwave + (active ? col : 0);
 
@@ -624,12 +636,12 @@ int pb_interp_ec_batch(double *ec_d, const double *etable_d, const double *ttabl
                "pb_interp_ec_batch: null pointer");
     hipStream_t s = pb::as_stream(stream);
     const int64_t n = (int64_t)nwalkers * nlayers;
-    // workspace: wlo[n] | whi[n] doubles, then tlo[n] ints
-    double *wlo = reinterpret_cast<double *>(work_d);
-    double *whi = wlo + n;
-    int32_t *tlo = reinterpret_cast<int32_t *>(whi + n);
-    k_interp_weights<<<pb::div_up(n, kBlock), kBlock, 0, s>>>(tlo, wlo, whi, ttable_d, temps_d,
-                                                            ntemp, n);
+    const int ncoef = nmol <= 4 ? 4 : 8;
+    // workspace: coef[n][2*ncoef] doubles, then tlo[n] ints
+    double *coef = reinterpret_cast<double *>(work_d);
+    int32_t *tlo = reinterpret_cast<int32_t *>(coef + n * 2 * ncoef);
+    k_interp_weights<<<pb::div_up(n, kBlock), kBlock, 0, s>>>(tlo, coef, ttable_d, temps_d,
+                                                            density_d, nmol, ncoef, ntemp, n);
     PB_LAUNCH_CHECK();
     // walkers per chunk: enough to amortise the table reads, few enough to fill the chip
     int chunk = 16;
@@ -637,11 +649,11 @@ int pb_interp_ec_batch(double *ec_d, const double *etable_d, const double *ttabl
         chunk /= 2;
     dim3 grid(pb::div_up(nwave, kBlock), nlayers, pb::div_up(nwalkers, chunk));
     if (nmol <= 4)
-        k_interp_ec_batch<4><<<grid, kBlock, 0, s>>>(ec_d, etable_d, tlo, wlo, whi, density_d, nmol,
-                                                   ntemp, nlayers, nwave, nwalkers, chunk);
+        k_interp_ec_batch<4><<<grid, kBlock, 0, s>>>(ec_d, etable_d, tlo, coef, nmol, ntemp,
+                                                   nlayers, nwave, nwalkers, chunk);
     else
-        k_interp_ec_batch<8><<<grid, kBlock, 0, s>>>(ec_d, etable_d, tlo, wlo, whi, density_d, nmol,
-                                                   ntemp, nlayers, nwave, nwalkers, chunk);
+        k_interp_ec_batch<8><<<grid, kBlock, 0, s>>>(ec_d, etable_d, tlo, coef, nmol, ntemp,
+                                                   nlayers, nwave, nwalkers, chunk);
     PB_LAUNCH_CHECK();
     return PB_OK;
 }

@@ -512,6 +512,26 @@ __global__ __launch_bounds__(kBlock) void k_records(LblArgs a)
         s_max[r] = 0ull;
     for (int d = threadIdx.x; d < a.ndop; d += kBlock)
         s_dop[d] = a.doppler[d];
+    // the state of this block's (layer, isotope) pairs, once into LDS: the per-record reads of
+    // it were ~12 same-address global loads per layer in a dependent chain
+    double *s_alphad = s_dop + a.ndop;                            // [kRecLayers][niso]
+    double *s_z = s_alphad + kRecLayers * a.niso;
+    double *s_ratio = s_z + kRecLayers * a.niso;                  // [niso]
+    int *s_ilor = reinterpret_cast<int *>(s_ratio + a.niso);      // [kRecLayers][niso]
+    int *s_iext = s_ilor + kRecLayers * a.niso;                   // [niso]
+    for (int e = threadIdx.x; e < kRecLayers * a.niso; e += kBlock) {
+        const int layer = layer0 + e / a.niso;
+        if (layer < a.nlayers) {
+            const int64_t li = (int64_t)layer * a.niso + e % a.niso;
+            s_alphad[e] = a.li_alphad[li];
+            s_z[e] = a.li_z[li];
+            s_ilor[e] = a.li_ilor[li];
+        }
+    }
+    for (int e = threadIdx.x; e < a.niso; e += kBlock) {
+        s_ratio[e] = a.isoratio[e];
+        s_iext[e] = a.isoiext[e];
+    }
     __syncthreads();
     auto pass = [&](auto posc) {
         constexpr bool kPos = decltype(posc)::value;
@@ -545,14 +565,14 @@ __global__ __launch_bounds__(kBlock) void k_records(LblArgs a)
             double k = 0.0, lmax = 0.0;
             int ulo = 0, uhi = 0, q = 0, cell = 0, phi = 0, row = -1;
             if (have) {
-                row = a.isoiext[iso];
+                row = s_iext[iso];
                 if (row >= 0 && a.add)
                     row = 0;
                 if (row >= 0) {
-                    const int64_t li = (int64_t)layer * a.niso + iso;
+                    const int e = i * a.niso + iso;
                     const double temp = a.temp[layer];
-                    const double ratio = a.isoratio[iso];
-                    const double z = a.li_z[li];
+                    const double ratio = s_ratio[iso];
+                    const double z = s_z[e];
                     k = line_strength(ratio, gf, elow, wavn, temp, z);
                     lmax = k;
                     for (int m = 1; m < count; m++) {
@@ -569,7 +589,7 @@ __global__ __launch_bounds__(kBlock) void k_records(LblArgs a)
                         continue;
                     }
                     const int ofactor = a.ls_ofactor[layer];
-                    const Window w = group_window(a, wavn, iown, a.li_ilor[li], a.li_alphad[li],
+                    const Window w = group_window(a, wavn, iown, s_ilor[e], s_alphad[e],
                                                   ofactor, a.ls_dwnstep[layer], a.ls_dnwn[layer],
                                                   0, a.ndop - 1, s_dop, a.ls_cutsteps[layer],
                                                   a.ls_inv_ofactor[layer]);
@@ -2576,7 +2596,8 @@ static int lbl_extinction(pb_lbl *p, double *ext_d, int64_t wbegin, int64_t wcou
         // 49 us against 27 us with four; PB_REC_LAYERS=1 selects it)
         const int per = getenv("PB_REC_LAYERS") && atoi(getenv("PB_REC_LAYERS")) == 1 ? 1 : kRecLayers;
         dim3 grid(pb::div_up(l->ngroups, kBlock), pb::div_up(nlayers, per));
-        const size_t rlds = (size_t)per * a.nrows * 8 + (size_t)a.ndop * 8;
+        const size_t rlds = (size_t)per * a.nrows * 8 + (size_t)a.ndop * 8 +
+                            (size_t)per * a.niso * (8 + 8 + 4) + (size_t)a.niso * (8 + 4) + 16;
         const int fmt = a.rec32 ? 3 : (a.rec16 && a.nch_max > 1) ? 2 : a.rec16 ? 1 : 0;
         void (*krec)(LblArgs) =
             per == 1 ? (fmt == 3   ? k_records<3, 1>

@@ -330,7 +330,7 @@ def interp_ec_batch(etable, ttable, temps, dens, out=None):
     assert temps.shape == (nw, nlayers) and dens.shape == (nw, nlayers, nmol)
     if out is None:
         out = torch.empty((nw, nlayers, nwave), dtype=torch.float64, device=etable.device)
-    work = torch.empty(nw * nlayers * 20 // 8 + 8, dtype=torch.float64, device=etable.device)
+    work = torch.empty(nw * nlayers * 17 + 8, dtype=torch.float64, device=etable.device)
     call('pb_interp_ec_batch', _ptr(out), _ptr(etable), _ptr(ttable), _ptr(temps.contiguous()),
          _ptr(dens.contiguous()), _ptr(work), nmol, ntemp, nlayers, nwave, nw, _stream())
     return out
