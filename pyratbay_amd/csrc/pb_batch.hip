@@ -604,6 +604,31 @@ int pb_transit_fused_launch(double *depth_d, int32_t *ideep_d, double *spectrum_
     return PB_OK;
 }
 
+// the blocked ray-path layout for one spectrum in stream-ordered scratch (freed by the caller
+// with hipFreeAsync on the same stream)
+int pb_path_blocks_launch(double **blocked_d, int64_t *len, const double *raypath_d, int64_t npath,
+                          int rows, int nimpact, hipStream_t s)
+{
+    const int64_t plen = blocked_len(rows, nimpact);
+    *blocked_d = nullptr;
+    *len = plen;
+    if (plen <= 0)
+        return PB_ERR_ARG;
+    double *buf = nullptr;
+    if (hipMallocAsync(reinterpret_cast<void **>(&buf), (size_t)plen * 8, s) != hipSuccess) {
+        (void)hipGetLastError();
+        return PB_ERR_NOMEM;
+    }
+    dim3 bgrid((unsigned)std::min<int64_t>(64, pb::div_up(plen, kBlock)), 1);
+    k_path_blocks<<<bgrid, kBlock, 0, s>>>(buf, raypath_d, npath, plen, rows, nimpact);
+    if (hipGetLastError() != hipSuccess) {
+        (void)hipFreeAsync(buf, s);
+        return PB_ERR_HIP;
+    }
+    *blocked_d = buf;
+    return PB_OK;
+}
+
 extern "C" {
 
 int pb_transit_path(double *raypath_d, const double *radius_d, int itop, int nlayers,

@@ -8,6 +8,7 @@
 // src_c/_blackbody.c:35-130, src_c/_simpson.c:167-203, src_c/cutils.c:27-42 and the
 // Python loops pyratbay/opacity/optic_depth.py:103-112,
 // pyratbay/spectrum/radiative_transfer.py:57-71, pyratbay/pyrat/spectrum.py:366-377.
+#include <algorithm>
 #include <cstdlib>
 
 #include "pb_common.h"
@@ -17,6 +18,8 @@ int pb_transit_fused_launch(double *depth_d, int32_t *ideep_d, double *spectrum_
                             int64_t npath, double rstar, int itop, int ibottom, double maxdepth,
                             int nlayers, int nwave, int nwalkers, int deck_row, double rsurf,
                             hipStream_t s, double *work_d);
+int pb_path_blocks_launch(double **blocked_d, int64_t *len, const double *raypath_d, int64_t npath,
+                          int rows, int nimpact, hipStream_t s);
 
 namespace {
 
@@ -78,7 +81,10 @@ constexpr int kRowsPerThread = 16;     // 32 and 40 measured slower at W = 1e5
 constexpr int kRowsPerThreadNarrow = 4;
 constexpr int kNarrowColumns = 32768;
 
-template <int kRows>
+// kScalar: `raypath` is the blocked layout of pb_path_blocks_launch ([block][segment][row], zero
+// where segment >= row) and is read through the constant address space = scalar loads, the
+// products taking the path from SGPRs; else the packed triangle, staged per block in LDS.
+template <int kRows, bool kScalar>
 __global__ __launch_bounds__(kBlock) void k_transit_tau(double *depth, const double *ec,
                                                         const double *raypath, int itop,
                                                         int ibottom, int nlayers, int nwave)
@@ -91,13 +97,15 @@ __global__ __launch_bounds__(kBlock) void k_transit_tau(double *depth, const dou
     const int nimpact = min(ibottom, nlayers) - itop;     // rows 0..nimpact-1 are evaluated
     const int rb = blockIdx.y * kRows;
     const int rlast = min(rb + kRows, nimpact) - 1;       // last evaluated row here
-    const int nseg = max(rlast, 0);                                 // segments i < rlast
-    for (int e = threadIdx.x; e < nseg * kRows; e += blockDim.x) {
-        const int i = e / kRows, k = e % kRows;
-        const int r = rb + k;
-        s_path[e] = (r <= rlast && i < r) ? raypath[(r * (r - 1)) / 2 + i] : 0.0;
+    const int nseg = rb < nimpact ? max(rlast, 0) : 0;    // segments i < rlast; none below ibottom
+    if (!kScalar) {
+        for (int e = threadIdx.x; e < nseg * kRows; e += blockDim.x) {
+            const int i = e / kRows, k = e % kRows;
+            const int r = rb + k;
+            s_path[e] = (r <= rlast && i < r) ? raypath[(r * (r - 1)) / 2 + i] : 0.0;
+        }
+        __syncthreads();
     }
-    __syncthreads();
     if (col >= nwave)
         return;
     double tau[kRows];
@@ -107,15 +115,36 @@ __global__ __launch_bounds__(kBlock) void k_transit_tau(double *depth, const dou
     if (nseg > 0) {
         const double *src = ec + (int64_t)itop * nwave + col;
         double prev = src[0];
-#pragma unroll 4
-        for (int i = 0; i < nseg; i++) {
-            const double next = src[(int64_t)(i + 1) * nwave];
-            const double s = next + prev;
-            prev = next;
-            const double *pk = s_path + i * kRows;          // LDS broadcast reads
+        if (kScalar) {
+            // blocks before this one are full: nseg_b = kRows*b + kRows - 1
+            const int64_t b = blockIdx.y;
+            const int64_t boff = (int64_t)kRows * (kRows * b * (b - 1) / 2 + b * (kRows - 1));
+            typedef const double __attribute__((address_space(4))) *cpath_t;
+            const cpath_t pb_ = (cpath_t)(unsigned long long)(raypath + boff);
+#pragma unroll 2
+            for (int i = 0; i < nseg; i++) {
+                const double next = src[(int64_t)(i + 1) * nwave];
+                const double s = next + prev;
+                prev = next;
+                double pv[kRows];
 #pragma unroll
-            for (int k = 0; k < kRows; k++)
-                tau[k] += pk[k] * s;
+                for (int k = 0; k < kRows; k++)
+                    pv[k] = pb_[i * kRows + k];
+#pragma unroll
+                for (int k = 0; k < kRows; k++)
+                    tau[k] += pv[k] * s;
+            }
+        } else {
+#pragma unroll 4
+            for (int i = 0; i < nseg; i++) {
+                const double next = src[(int64_t)(i + 1) * nwave];
+                const double s = next + prev;
+                prev = next;
+                const double *pk = s_path + i * kRows;          // LDS broadcast reads
+#pragma unroll
+                for (int k = 0; k < kRows; k++)
+                    tau[k] += pk[k] * s;
+            }
         }
     }
 #pragma unroll
@@ -140,12 +169,16 @@ __device__ inline double deck_integrand(double f_above, double f_below, double r
 }
 
 __global__ __launch_bounds__(kBlock) void k_transit_finish(
-    double *depth, int32_t *ideep, double *spectrum, const double *radius, double rstar,
+    double *depth, int32_t *ideep, double *spectrum, const double *radius_g, double rstar,
     int itop, int ibottom, double maxdepth, int nlayers, int nwave, int deck_row, double rsurf)
 {
     const int col = blockIdx.x * blockDim.x + threadIdx.x;
     if (col >= nwave)
         return;
+    // the radii are wave-uniform: scalar loads through the constant address space (as
+    // same-address vector loads they sit in the dependent chain of every row)
+    typedef const double __attribute__((address_space(4))) *crad_t;
+    const crad_t radius = (crad_t)(unsigned long long)radius_g;
     const int nimpact = min(ibottom, nlayers) - itop;
     int stop = -1;
     double acc = 0.0, fprev = 0.0, rprev = 0.0;
@@ -765,11 +798,30 @@ static int transit_launch(double *depth_d, int32_t *ideep_d, double *spectrum_d,
         pb::set_error("%s: %d layers need %zu B of LDS", who, nrow, lds);
         return PB_ERR_UNSUPPORTED;
     }
-    if (narrow)
-        k_transit_tau<kRowsPerThreadNarrow><<<grid, threads, lds, pb::as_stream(stream)>>>(
+    // the ray paths re-laid per block of rows in stream-ordered scratch, so that the kernel can
+    // take them with scalar loads (PB_TRANSIT_SCALAR=0: packed triangle staged in LDS)
+    static const bool no_scalar = getenv("PB_TRANSIT_SCALAR") && atoi(getenv("PB_TRANSIT_SCALAR")) == 0;
+    const int nimpact = std::min(ibottom, nlayers) - itop;
+    double *blocked = nullptr;
+    if (!no_scalar && nimpact > 1) {
+        int64_t plen = 0;
+        if (pb_path_blocks_launch(&blocked, &plen, raypath_d, ((int64_t)nrow * (nrow - 1)) / 2,
+                                  rows, nimpact, pb::as_stream(stream)) != PB_OK)
+            blocked = nullptr;                     // fall back to the LDS form
+    }
+    if (blocked) {
+        if (narrow)
+            k_transit_tau<kRowsPerThreadNarrow, true><<<grid, threads, 0, pb::as_stream(stream)>>>(
+                depth_d, ec_d, blocked, itop, ibottom, nlayers, nwave);
+        else
+            k_transit_tau<kRowsPerThread, true><<<grid, threads, 0, pb::as_stream(stream)>>>(
+                depth_d, ec_d, blocked, itop, ibottom, nlayers, nwave);
+        (void)hipFreeAsync(blocked, pb::as_stream(stream));
+    } else if (narrow)
+        k_transit_tau<kRowsPerThreadNarrow, false><<<grid, threads, lds, pb::as_stream(stream)>>>(
             depth_d, ec_d, raypath_d, itop, ibottom, nlayers, nwave);
     else
-        k_transit_tau<kRowsPerThread><<<grid, threads, lds, pb::as_stream(stream)>>>(
+        k_transit_tau<kRowsPerThread, false><<<grid, threads, lds, pb::as_stream(stream)>>>(
             depth_d, ec_d, raypath_d, itop, ibottom, nlayers, nwave);
     PB_LAUNCH_CHECK();
     // radiative_transfer.py:63: the deck matters only when it lies below the top layer
