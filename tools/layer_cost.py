@@ -1,44 +1,54 @@
-"""Where the extinction time goes: per block of layers, gather time in both kernels.
-usage: python tools/layer_cost.py [workload] [layers per block]"""
-import sys
+"""Where the gather's time goes, layer by layer: for layer l of the workload every layer of the
+atmosphere is set to l's state, so that one launch does 80x the work of that layer at full
+occupancy; prints per-layer gather ms (/nlayers), live records, useful and issued FMA lanes and
+the CU-cycles per 256-sample visit.  usage: python tools/layer_cost.py [workload] [stride]"""
 import os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import numpy as np
-import torch
-import bench
-from pyratbay_amd import engine, synth
+import sys
 
-name = sys.argv[1] if len(sys.argv) > 1 else 'c2'
-step = int(sys.argv[2]) if len(sys.argv) > 2 else 8
-w = bench.WORKLOADS[name]
-case = synth.lbl_case(w['nwave'], w['nlayers'], w['nlines'], wnstep=w['wnstep'],
-                      niso=w['niso'], seed=42)
-model = engine.LBLSpectrum(case, rt_path='transit')
-model.run()
-L = w['nlayers']
-ofac, _ = model.lbl.last_state(L, 1)
-resident, block = model.lbl.last_layer_kinds(L)
-print('resident layers:', resident.tolist())
-print('block sizes (doubles):', block.tolist())
-temp, dens, isoz = model.temp, model.dens, model.isoz
-vt = model.voigt
-print('voigt sizes (idop 0, every 10th ilor):', np.asarray(vt.size)[0, ::10] if hasattr(vt, 'size') else '')
-for l0 in range(0, L, step):
-    l1 = min(L, l0 + step)
-    res = []
-    for mode in ('staged', 'auto'):
-        model.lbl.set_gather_mode(mode)
-        rep = L // (l1 - l0)       # a full-size launch made of copies of this block
-        t, d, z = (temp[l0:l1].repeat(rep).contiguous(), dens[l0:l1].repeat(rep, 1).contiguous(),
-                   isoz[:, l0:l1].repeat(1, rep).contiguous())
-        for _ in range(2):
-            model.lbl.extinction(t, d, z)
-        torch.cuda.synchronize()
-        model.lbl.timing_begin(16)
-        for _ in range(5):
-            model.lbl.extinction(t, d, z)
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench                                           # noqa: E402
+
+
+def main():
+    import torch
+    from pyratbay_amd import engine, _capi
+    if os.environ.get('PB_PROBE_LIB'):          # an instrumented build (tools only)
+        _capi.LIBPATH = os.path.abspath(os.environ['PB_PROBE_LIB'])
+    name = sys.argv[1] if len(sys.argv) > 1 else 'c2'
+    stride = int(sys.argv[2]) if len(sys.argv) > 2 else 8
+    case = bench.make_case(bench.WORKLOADS[name])
+    atm, iso = case['atm'], case['iso']
+    L = len(atm['temp'])
+    model = engine.LBLSpectrum(case, rt_path='transit')
+    model.run()
+    torch.cuda.synchronize()
+    reps = 5
+    rows = []
+    for l in list(range(0, L, stride)) + [L - 1]:
+        temp = np.full(L, atm['temp'][l])
+        dens = np.repeat(np.asarray(atm['dens'])[l:l + 1], L, 0)
+        isoz = np.repeat(np.asarray(iso['isoz'])[:, l:l + 1], L, 1)
+        model.set_atmosphere(temp, dens, isoz)
+        model.extinction()
+        model.lbl.timing_begin(reps)
+        for _ in range(reps):
+            model.extinction()
         torch.cuda.synchronize()
         ms, n = model.lbl.timing_end()
-        res.append((ms / n, model.lbl.last_gather_kernel))
-    print(f'layers {l0:2d}-{l1-1:2d} ofactor {ofac[l0]:3d}..{ofac[l1-1]:3d}  '
-          f'staged {res[0][0]:.3f} ms  auto {res[1][0]:.3f} ms ({res[1][1]})')
+        w = model.lbl.last_work() or {}
+        ofac, _ = model.lbl.last_state(L, 1)
+        ms = ms / max(n, 1)
+        visits = w.get('fma_lanes_issued', 0) / 256.0
+        cyc = ms * 1e-3 * 2.4e9 * 256 / visits if visits else float('nan')
+        rows.append((l, ms / L * 1e3, w.get('live_records', 0) / L,
+                     w.get('fma_lanes_useful', 0) / L, w.get('fma_lanes_issued', 0) / L, cyc,
+                     int(ofac[0]), model.lbl.last_gather_kernel))
+    print('layer  us/layer  live_rec  useful_lanes  issued_lanes  CUcyc/visit  ofactor  kernel')
+    for r in rows:
+        print(f'{r[0]:5d} {r[1]:9.2f} {r[2]:9.0f} {r[3]:13.3e} {r[4]:13.3e} {r[5]:10.1f} {r[6]:7d}  {r[7]}')
+
+
+if __name__ == '__main__':
+    main()

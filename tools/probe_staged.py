@@ -1,0 +1,116 @@
+"""Instrumentation of k_ext_staged for A/B builds -- NOT part of the product build.
+
+Patches pyratbay_amd/csrc/pb_extinction.hip + pb_ext_args.h IN PLACE (restore them with
+`git checkout pyratbay_amd/csrc` afterwards) so that `hipcc -DPB_PROBE=<bits>` builds
+    bit 0  the kernel without its row DMA         (timing only, results are wrong)
+    bit 1  the kernel without the walk            (timing only, results are wrong)
+    bit 2  counters printed to stderr after every launch: segment steps, visits, the sum over
+           the steps of the busiest wavefront's visits (what a barrier waits for), batches,
+           records, and the shader clock the kernel ran at (clock64 against wall_clock64)
+Build the object with the flags of csrc/Makefile, link it with the other objects into
+build_ab/libpbhip_p<bits>.so and run `PB_PROBE_LIB=build_ab/libpbhip_p<bits>.so python
+tools/layer_cost.py c2 16`.  Findings of round 2: profiles/r02_gather_ab.md."""
+import os
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+p = os.path.join(ROOT, 'pyratbay_amd/csrc/pb_extinction.hip')
+s=open(p).read()
+h = os.path.join(ROOT, 'pyratbay_amd/csrc/pb_ext_args.h')
+t=open(h).read()
+t=t.replace("    int experiment;","    unsigned long long *probe;\n    int experiment;",1)
+open(h,'w').write(t)
+s=s.replace('template <int NW, int S, bool kDma>\n__global__ __launch_bounds__(NW * 64, 8) void k_ext_staged','#ifndef PB_PROBE\n#define PB_PROBE 0\n#endif\ntemplate <int NW, int S, bool kDma>\n__global__ __launch_bounds__(NW * 64, 8) void k_ext_staged',1)
+old='''    auto dma_row = [&](int sg, int buf) {
+        const unsigned long long d = s_desc[sg];'''
+new='''    auto dma_row = [&](int sg, int buf) {
+#if PB_PROBE & 1
+        return;
+#endif
+        const unsigned long long d = s_desc[sg];'''
+assert old in s
+s=s.replace(old,new)
+old='''            auto walk = [&](int sg, int buf) {
+'''
+new='''            auto walk = [&](int sg, int buf) {
+#if PB_PROBE & 4
+                if ((sg & 63) == 0) find_hits(sg);
+                {
+                    int cnt = 0;
+                    for (int u = 0; u < S; u++)
+                        cnt += (int)((unsigned)__builtin_amdgcn_readlane((int)hits[u], sg & 63) >> 16);
+                    if (lane == 0) {
+                        atomicAdd(&a.probe[1], (unsigned long long)cnt);
+                        atomicMax(&s_part[0], cnt);
+                        if (wave == 0) atomicAdd(&a.probe[0], 1ull);
+                    }
+                }
+#endif
+#if PB_PROBE & 2
+                return;
+#endif
+'''
+assert s.count(old)==1
+s=s.replace(old,new)
+old='''                    walk(sg, sg & 1);
+                    __builtin_amdgcn_s_waitcnt(0x0f70);       // the row of sg+1 has landed
+                    __syncthreads();'''
+new='''                    walk(sg, sg & 1);
+                    __builtin_amdgcn_s_waitcnt(0x0f70);       // the row of sg+1 has landed
+                    __syncthreads();
+#if PB_PROBE & 4
+                    if (tid == 0) { atomicAdd(&a.probe[2], (unsigned long long)s_part[0]); s_part[0] = 0; }
+                    __syncthreads();
+#endif'''
+assert old in s
+s=s.replace(old,new)
+old='''            if (nseg == 0)
+                continue;'''
+new='''#if PB_PROBE & 4
+            if (tid == 0) { atomicAdd(&a.probe[3], 1ull); atomicAdd(&a.probe[4], (unsigned long long)nrec); s_part[0] = 0; }
+            __syncthreads();
+#endif
+            if (nseg == 0)
+                continue;'''
+assert s.count(old)==1
+s=s.replace(old,new)
+old='''        kern<<<grid, kStagedThreads, lds, s>>>(a);'''
+new='''#if PB_PROBE & 4
+        static unsigned long long *probe_d = nullptr;
+        if (!probe_d) hipMalloc(&probe_d, 64);
+        hipMemsetAsync(probe_d, 0, 64, s);
+        a.probe = probe_d;
+#endif
+        kern<<<grid, kStagedThreads, lds, s>>>(a);
+#if PB_PROBE & 4
+        { unsigned long long hh[8]; hipMemcpyAsync(hh, probe_d, 64, hipMemcpyDeviceToHost, s); hipStreamSynchronize(s);
+          fprintf(stderr, "probe: segsteps %llu visits %llu sum_max_visits %llu batches %llu recs %llu  grid %u nsplit %d S %d\\n", hh[0], hh[1], hh[2], hh[3], hh[4], grid.x, a.nsplit, S); }
+#endif'''
+assert s.count(old)==1
+s=s.replace(old,new)
+i = s.index('void k_ext_staged')
+old2 = """    const int row = blockIdx.y;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+"""
+j = s.index(old2, i)
+s = s[:j] + old2 + """#if PB_PROBE & 4
+    const long long probe_c0 = clock64(), probe_w0 = wall_clock64();
+#endif
+""" + s[j + len(old2):]
+old3 = """    double *out = zsplit == 0
+                      ? a.ext
+                      : a.part + (int64_t)(zsplit - 1) * a.nlayers * a.nrows * a.wcount;"""
+j = s.index(old3, i)
+s = s[:j] + """#if PB_PROBE & 4
+    if (tid == 0) {
+        atomicAdd(&a.probe[5], (unsigned long long)(clock64() - probe_c0));
+        atomicAdd(&a.probe[6], (unsigned long long)(wall_clock64() - probe_w0));
+    }
+#endif
+""" + s[j:]
+s = s.replace('fprintf(stderr, "probe: segsteps %llu', 'fprintf(stderr, "probe: MHz %.0f segsteps %llu', 1)
+s = s.replace('hh[0], hh[1], hh[2], hh[3], hh[4], grid.x',
+              'hh[6] ? 100.0 * (double)hh[5] / (double)hh[6] : 0.0, hh[0], hh[1], hh[2], hh[3], '
+              'hh[4], grid.x', 1)
+open(p,'w').write(s)
