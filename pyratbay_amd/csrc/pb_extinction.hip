@@ -501,6 +501,16 @@ constexpr int kRecLayers = 4;        // layers per thread of k_records (group da
 // kernel are in position order and always use the SoA arrays.  The two orders are two passes
 // with their own pointer sets (one body instantiated twice): with both sets and every record
 // format live at once the kernel held a third of its scalar state in spilled registers.
+// A wave-uniform element of a device array written by an EARLIER kernel: read through the constant
+// address space, i.e. by a scalar load (a plain load of a uniform address is a vector load that
+// every lane waits for).
+template <class T>
+__device__ __forceinline__ T uniform_load(const T *p, int64_t i)
+{
+    typedef const T __attribute__((address_space(4))) *cptr;
+    return ((cptr)(unsigned long long)p)[i];
+}
+
 template <int kFmt, int kRecLayers>
 __global__ __launch_bounds__(kBlock) void k_records(LblArgs a)
 {
@@ -559,7 +569,7 @@ __global__ __launch_bounds__(kBlock) void k_records(LblArgs a)
             const int layer = layer0 + i;
             if (layer >= a.nlayers)
                 break;
-            const bool pos = kFmt == 3 || (a.res_cap > 0 && a.ls_resident[layer]);
+            const bool pos = kFmt == 3 || (a.res_cap > 0 && uniform_load(a.ls_resident, layer));
             if (pos != kPos)                                          // wave-uniform
                 continue;
             double k = 0.0, lmax = 0.0;
@@ -570,7 +580,7 @@ __global__ __launch_bounds__(kBlock) void k_records(LblArgs a)
                     row = 0;
                 if (row >= 0) {
                     const int e = i * a.niso + iso;
-                    const double temp = a.temp[layer];
+                    const double temp = uniform_load(a.temp, layer);
                     const double ratio = s_ratio[iso];
                     const double z = s_z[e];
                     k = line_strength(ratio, gf, elow, wavn, temp, z);
@@ -588,13 +598,13 @@ __global__ __launch_bounds__(kBlock) void k_records(LblArgs a)
                                   (unsigned long long)__double_as_longlong(lmax));
                         continue;
                     }
-                    const int ofactor = a.ls_ofactor[layer];
+                    const int ofactor = uniform_load(a.ls_ofactor, layer);
                     const Window w = group_window(a, wavn, iown, s_ilor[e], s_alphad[e],
-                                                  ofactor, a.ls_dwnstep[layer], a.ls_dnwn[layer],
-                                                  0, a.ndop - 1, s_dop, a.ls_cutsteps[layer],
-                                                  a.ls_inv_ofactor[layer]);
+                                                  ofactor, uniform_load(a.ls_dwnstep, layer), uniform_load(a.ls_dnwn, layer),
+                                                  0, a.ndop - 1, s_dop, uniform_load(a.ls_cutsteps, layer),
+                                                  uniform_load(a.ls_inv_ofactor, layer));
                     // kept samples: minj <= scale*jo < maxj, inside the profile and the grid
-                    const double inv_scale = a.ls_inv_scale[layer];
+                    const double inv_scale = uniform_load(a.ls_inv_scale, layer);
                     ulo = -floor_div_inv(-(int)w.minj, inv_scale);
                     uhi = -floor_div_inv(-(int)w.maxj, inv_scale);
                     ulo = max(ulo, -floor_div_inv(w.half - iown, a.inv_osamp));
