@@ -163,7 +163,7 @@ __global__ __launch_bounds__(kBlock) void k_path_blocks(double *blocked, const d
 // later blocks come from L2 / the Infinity Cache), the kRows running sums stay in registers and
 // the ray-path segments of the block sit in LDS ([segment][row], zero where segment >= row, so one
 // predicate-free loop serves all rows with the reference's products and additions).  After each
-// block its rows are examined in order: exp(-tau)*r joins the trapezoid, the first tau above
+// block its rows are examined in order: pb::exp_s(-tau)*r joins the trapezoid, the first tau above
 // maxdepth ends the column -- later blocks are not computed at all, which is where the time
 // of the two-kernel form went (every row of every column, then a second pass to find the exit).
 // depth and ideep are optional outputs (a retrieval needs neither).
@@ -280,7 +280,7 @@ __global__ __launch_bounds__(kBlock) void k_transit_fused(
                 if (stop < 0) {
                     if (spectrum) {
                         const double rr = rad[itop + r];
-                        double f = exp(-t) * rr;
+                        double f = pb::exp_s(-t) * rr;
                         if (r > 0 && r == deck_row) {
                             f = deck_integrand(fprev, f, rprev, rr, rsurf);
                             acc += (rsurf - rprev) * (fprev + f);
@@ -408,7 +408,7 @@ __global__ __launch_bounds__(1024) void k_transit_tile(
                 if (stop < 0) {
                     if (spectrum) {
                         const double rr = rad[itop + r];
-                        double f = exp(-t) * rr;
+                        double f = pb::exp_s(-t) * rr;
                         if (r > 0 && r == deck_row) {
                             f = deck_integrand(fprev, f, rprev, rr, rsurf);
                             acc += (rsurf - rprev) * (fprev + f);

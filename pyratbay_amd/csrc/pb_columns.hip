@@ -197,7 +197,7 @@ __global__ __launch_bounds__(kBlock) void k_transit_finish(
             if (stop < 0) {
                 if (spectrum) {
                     const double rad = radius[itop + r];
-                    double f = exp(-t[k]) * rad;
+                    double f = pb::exp_s(-t[k]) * rad;
                     if (r > 0 && r == deck_row) {
                         f = deck_integrand(fprev, f, rprev, rad, rsurf);
                         acc += (rsurf - rprev) * (fprev + f);
@@ -293,10 +293,10 @@ __global__ void k_transmission(double *spectrum, const double *depth,
     double acc = 0.0;
     if (n > 0) {
         double rprev = radius[itop];
-        double prev = exp(-depth[(int64_t)itop * nwave + j]) * rprev;
+        double prev = pb::exp_s(-depth[(int64_t)itop * nwave + j]) * rprev;
         for (int i = 0; i < n; i++) {
             double rnext = radius[itop + i + 1];
-            double next = exp(-depth[(int64_t)(itop + i + 1) * nwave + j]) * rnext;
+            double next = pb::exp_s(-depth[(int64_t)(itop + i + 1) * nwave + j]) * rnext;
             if (i + 1 == deck_row) {
                 next = deck_integrand(prev, next, rprev, rnext, rsurf);
                 acc += (rsurf - rprev) * (prev + next);
@@ -321,7 +321,7 @@ __device__ inline double planck_factor(double wn)
 }
 __device__ inline double planck(double factor, double wn, double temp)
 {
-    return factor / (exp(pb::kH * pb::kLS * wn / (pb::kKB * temp)) - 1.0);
+    return factor / (pb::exp_s(pb::kH * pb::kLS * wn / (pb::kKB * temp)) - 1.0);
 }
 
 __global__ void k_blackbody2d(double *B, const double *wn, int nwave, const double *temp,
@@ -370,17 +370,17 @@ __global__ void k_intensity(double *out, const double *tau, const int32_t *ideep
     } else {
         double acc = 0.0;
         if (last > rtop) {
-            double eprev = exp(-tau[(int64_t)rtop * nwave + j] / m);
+            double eprev = pb::exp_s(-tau[(int64_t)rtop * nwave + j] / m);
             double bprev = bbody[(int64_t)rtop * nwave + j];
             for (int i = rtop; i < last; i++) {
-                double enext = exp(-tau[(int64_t)(i + 1) * nwave + j] / m);
+                double enext = pb::exp_s(-tau[(int64_t)(i + 1) * nwave + j] / m);
                 double bnext = bbody[(int64_t)(i + 1) * nwave + j];
                 acc += (enext - eprev) * (bnext + bprev);
                 eprev = enext;
                 bprev = bnext;
             }
         }
-        result = blast * exp(-tau[(int64_t)last * nwave + j] / m) - 0.5 * acc;
+        result = blast * pb::exp_s(-tau[(int64_t)last * nwave + j] / m) - 0.5 * acc;
     }
     out[(int64_t)k * nwave + j] = result;
 }
@@ -409,7 +409,7 @@ __global__ void k_emission_flux(double *flux, double *intensity, const double *t
 #pragma unroll
     for (int k = 0; k < kMaxMu; k++) {
         acc[k] = 0.0;
-        eprev[k] = k < nmu ? exp(-t0 / mu[k]) : 0.0;
+        eprev[k] = k < nmu ? pb::exp_s(-t0 / mu[k]) : 0.0;
     }
     double bprev = planck(factor, w, temp[rtop]);
     double tlast = t0;
@@ -420,7 +420,7 @@ __global__ void k_emission_flux(double *flux, double *intensity, const double *t
 #pragma unroll
         for (int k = 0; k < kMaxMu; k++) {
             if (k < nmu) {
-                double enext = exp(-t / mu[k]);
+                double enext = pb::exp_s(-t / mu[k]);
                 acc[k] += (enext - eprev[k]) * bsum;
                 eprev[k] = enext;
             }
@@ -439,7 +439,7 @@ __global__ void k_emission_flux(double *flux, double *intensity, const double *t
             if (last - rtop == 1)
                 val = blast;
             else
-                val = blast * exp(-tlast / mu[k]) - 0.5 * acc[k];
+                val = blast * pb::exp_s(-tlast / mu[k]) - 0.5 * acc[k];
             if (intensity)
                 intensity[(int64_t)k * nwave + j] = val;
             total += val * weights[k];
@@ -475,7 +475,7 @@ __global__ void k_emission_fused(double *flux, const double *ec, const double *i
 #pragma unroll
     for (int k = 0; k < kMaxMu; k++) {
         acc[k] = 0.0;
-        eprev[k] = k < nmu ? exp(-0.0 / mu[k]) : 0.0;        // depth[rtop] = 0
+        eprev[k] = k < nmu ? pb::exp_s(-0.0 / mu[k]) : 0.0;        // depth[rtop] = 0
     }
     double bprev = planck(factor, w, tp[rtop]);
     double depth = 0.0, tlast = 0.0;
@@ -491,7 +491,7 @@ __global__ void k_emission_fused(double *flux, const double *ec, const double *i
 #pragma unroll
         for (int m = 0; m < kMaxMu; m++) {
             if (m < nmu) {
-                const double enext = exp(-depth / mu[m]);
+                const double enext = pb::exp_s(-depth / mu[m]);
                 acc[m] += (enext - eprev[m]) * bsum;
                 eprev[m] = enext;
             }
@@ -512,7 +512,7 @@ __global__ void k_emission_fused(double *flux, const double *ec, const double *i
             if (last - rtop == 1)
                 val = blast;
             else
-                val = blast * exp(-tlast / mu[m]) - 0.5 * acc[m];
+                val = blast * pb::exp_s(-tlast / mu[m]) - 0.5 * acc[m];
             total += val * weights[m];
         }
     }
@@ -615,7 +615,7 @@ __device__ inline double exp1_real(double x)
     double t0 = 0.0;
     for (int k = m; k > 0; k--)
         t0 = k / (1.0 + k / (x + t0));
-    return exp(-x) * (1.0 / (x + t0));
+    return pb::exp_s(-x) * (1.0 / (x + t0));
 }
 
 // One column per thread.  The downward sweep parks trans[i] in flux_up[i] so that the
@@ -641,10 +641,10 @@ __global__ __launch_bounds__(kBlock) void k_two_stream(
         const double dnext = depth[(int64_t)(i + 1) * nwave + j];
         const double bnext = planck(factor, w, temp[i + 1]);
         const double dtau0 = dnext - dprev;
-        const double trans = (1 - dtau0) * exp(-dtau0) + dtau0 * dtau0 * exp1_real(dtau0);
+        const double trans = (1 - dtau0) * pb::exp_s(-dtau0) + dtau0 * dtau0 * exp1_real(dtau0);
         const double bp = (bnext - bprev) / dtau0;
         down = trans * down + pi * bprev * (1 - trans) +
-               pi * bp * (-2.0 / 3 * (1 - exp(-dtau0)) + dtau0 * (1 - trans / 3));
+               pi * bp * (-2.0 / 3 * (1 - pb::exp_s(-dtau0)) + dtau0 * (1 - trans / 3));
         flux_down[(int64_t)(i + 1) * nwave + j] = down;
         flux_up[(int64_t)i * nwave + j] = trans;
         dprev = dnext;
@@ -660,7 +660,7 @@ __global__ __launch_bounds__(kBlock) void k_two_stream(
         const double trans = flux_up[(int64_t)i * nwave + j];
         const double bp = (bprev - blo) / dtau0;
         up = trans * up + pi * bprev * (1 - trans) +
-             pi * bp * (2.0 / 3 * (1 - exp(-dtau0)) - dtau0 * (1 - trans / 3));
+             pi * bp * (2.0 / 3 * (1 - pb::exp_s(-dtau0)) - dtau0 * (1 - trans / 3));
         flux_up[(int64_t)i * nwave + j] = up;
         dprev = dlo;
         bprev = blo;

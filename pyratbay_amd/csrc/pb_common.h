@@ -87,4 +87,46 @@ __host__ __device__ inline int64_t ceil_div(int64_t a, int64_t b)
     return -floor_div(-a, b);
 }
 
+// exp() with its constants in SGPRs.  The arithmetic is the device library's (range reduction by
+// ln2 in two parts, degree-11 polynomial, ldexp, the same overflow/underflow selects), so the
+// result is the same bit pattern; what changes is that the polynomial coefficients sit in scalar
+// registers (an empty asm with an "s" constraint hides each value from constant folding and pins
+// it to an SGPR pair, loop-invariant) instead of being re-materialised with two v_mov each per
+// call: ~25 vector instructions per exp instead of ~50.  The column kernels evaluate one exp
+// per (layer, sample) and are bound by exactly that instruction count.
+__device__ __forceinline__ double sgpr_const(double v)
+{
+    asm("" : "+s"(v));
+    return v;
+}
+
+__device__ __forceinline__ double exp_s(double x)
+{
+    const double log2e = sgpr_const(0x1.71547652b82fep+0);
+    const double nln2h = sgpr_const(-0x1.62e42fefa39efp-1);
+    const double nln2l = sgpr_const(-0x1.abc9e3b39803fp-56);
+    const double c11 = sgpr_const(0x1.ade156a5dcb37p-26), c10 = sgpr_const(0x1.28af3fca7ab0cp-22),
+                 c9 = sgpr_const(0x1.71dee623fde64p-19), c8 = sgpr_const(0x1.a01997c89e6b0p-16),
+                 c7 = sgpr_const(0x1.a01a014761f6ep-13), c6 = sgpr_const(0x1.6c16c1852b7b0p-10),
+                 c5 = sgpr_const(0x1.1111111122322p-7), c4 = sgpr_const(0x1.55555555502a1p-5),
+                 c3 = sgpr_const(0x1.5555555555511p-3), c2 = sgpr_const(0x1.000000000000bp-1);
+    const double n = rint(x * log2e);
+    double r = fma(n, nln2h, x);
+    r = fma(nln2l, n, r);
+    double p = fma(c11, r, c10);
+    p = fma(r, p, c9);
+    p = fma(r, p, c8);
+    p = fma(r, p, c7);
+    p = fma(r, p, c6);
+    p = fma(r, p, c5);
+    p = fma(r, p, c4);
+    p = fma(r, p, c3);
+    p = fma(r, p, c2);
+    p = fma(r, p, 1.0);
+    p = fma(r, p, 1.0);
+    double v = ldexp(p, (int)n);
+    v = x > 1024.0 ? __builtin_huge_val() : v;
+    return x < -1075.0 ? 0.0 : v;
+}
+
 }  // namespace pb
