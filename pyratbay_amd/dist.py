@@ -114,8 +114,7 @@ class SpectrumGather:
         """local[wcount] -> full[nwave] on every rank."""
         assert local.shape[0] == self.wcount
         if self.world == 1:
-            self.full.copy_(local)
-            return self.full
+            return local                          # nothing to assemble
         self.send[:self.wcount].copy_(local)
         all_gather_flat(self.recv, self.send, self.group)
         blocks = self.recv.view(self.world, self.pad)
