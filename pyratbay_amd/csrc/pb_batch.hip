@@ -78,7 +78,9 @@ __global__ __launch_bounds__(kBlock) void k_interp_weights(
     }
 }
 
-template <int kS>
+// kFull: nmol == kS, no per-species predicate (the coefficient loads of a walker then merge into
+// one scalar load and one wait)
+template <int kS, bool kFull>
 __global__ __launch_bounds__(kBlock) void k_interp_ec_batch(
     double *ec, const double *etable, const int32_t *tlo, const double *coef, int nmol,
     int ntemp, int nlayers, int nwave, int nwalkers, int chunk)
@@ -105,13 +107,15 @@ __global__ __launch_bounds__(kBlock) void k_interp_ec_batch(
     double lo[kS], hi[kS];
 #pragma unroll
     for (int j = 0; j < kS; j++)
-        hi[j] = j < nmol ? tab[((int64_t)j * ntemp + bmin) * slice] : 0.0;
+        hi[j] = kFull || j < nmol ? tab[((int64_t)j * ntemp + bmin) * slice] : 0.0;
     for (int b = bmin; b <= bmax; b++) {
 #pragma unroll
         for (int j = 0; j < kS; j++) {
             lo[j] = hi[j];
-            hi[j] = j < nmol ? tab[((int64_t)j * ntemp + b + 1) * slice] : 0.0;
+            hi[j] = kFull || j < nmol ? tab[((int64_t)j * ntemp + b + 1) * slice] : 0.0;
         }
+        // (the walkers of bracket b as the set bits of a ballot over per-lane brackets -- no
+        // scalar load and wait per walker and bracket -- measured slower: 1.21 against 1.11 ms)
         for (int w = w0; w < w1; w++) {
             const int64_t wk = (int64_t)w * nlayers + k;
             if (ctlo[wk] != b)
@@ -120,7 +124,7 @@ __global__ __launch_bounds__(kBlock) void k_interp_ec_batch(
             double acc = 0.0;
 #pragma unroll
             for (int j = 0; j < kS; j++)
-                if (j < nmol)
+                if (kFull || j < nmol)
                     acc += lo[j] * co[j] + hi[j] * co[kS + j];
             ec[wk * nwave + i] = acc;
         }
@@ -668,17 +672,28 @@ int pb_interp_ec_batch(double *ec_d, const double *etable_d, const double *ttabl
     k_interp_weights<<<pb::div_up(n, kBlock), kBlock, 0, s>>>(tlo, coef, ttable_d, temps_d,
                                                             density_d, nmol, ncoef, ntemp, n);
     PB_LAUNCH_CHECK();
-    // walkers per chunk: enough to amortise the table reads, few enough to fill the chip
-    int chunk = 16;
+    // walkers per chunk: every chunk reads the table slices its walkers bracket again, so as many
+    // as the launch can afford while it still fills the chip (C5, 64 walkers: 1.40 ms in chunks
+    // of 16, 1.23 in one chunk, 1.11 with the species count a template constant)
+    int chunk = 64;
+    if (const char *e = getenv("PB_INTERP_CHUNK"))
+        chunk = std::max(1, atoi(e));
     while (chunk > 1 && (int64_t)pb::div_up(nwave, kBlock) * nlayers * pb::div_up(nwalkers, chunk) < 2048)
         chunk /= 2;
     dim3 grid(pb::div_up(nwave, kBlock), nlayers, pb::div_up(nwalkers, chunk));
-    if (nmol <= 4)
-        k_interp_ec_batch<4><<<grid, kBlock, 0, s>>>(ec_d, etable_d, tlo, coef, nmol, ntemp,
-                                                   nlayers, nwave, nwalkers, chunk);
+#define PB_INTERP(S, FULL)                                                                     \
+    k_interp_ec_batch<S, FULL><<<grid, kBlock, 0, s>>>(ec_d, etable_d, tlo, coef, nmol, ntemp,  \
+                                                       nlayers, nwave, nwalkers, chunk)
+    static const bool no_full = getenv("PB_INTERP_FULL") && atoi(getenv("PB_INTERP_FULL")) == 0;
+    if (nmol == 4 && !no_full)
+        PB_INTERP(4, true);
+    else if (nmol <= 4)
+        PB_INTERP(4, false);
+    else if (nmol == 8)
+        PB_INTERP(8, true);
     else
-        k_interp_ec_batch<8><<<grid, kBlock, 0, s>>>(ec_d, etable_d, tlo, coef, nmol, ntemp,
-                                                   nlayers, nwave, nwalkers, chunk);
+        PB_INTERP(8, false);
+#undef PB_INTERP
     PB_LAUNCH_CHECK();
     return PB_OK;
 }
