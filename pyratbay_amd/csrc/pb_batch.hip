@@ -320,6 +320,114 @@ __global__ __launch_bounds__(kBlock) void k_transit_fused(
 }
 
 // ---------------------------------------------------------------------------
+// The retrieval batch (spectrum only, no cloud deck): the same pass with TWO columns per thread,
+// so that every ray-path value fetched by a scalar load feeds two fused multiply-adds -- the
+// scalar cache cannot hold the ray paths of the few walkers a CU works on at once (30 KB each),
+// and with one column per thread the waits for those loads are half of the kernel's time.
+// ---------------------------------------------------------------------------
+template <int kRows>
+__global__ __launch_bounds__(kBlock) void k_transit_pair(
+    double *spectrum, const double *ec, const double *blocked, const double *radius, int64_t plen,
+    double rstar, int itop, int ibottom, double maxdepth, int nlayers, int nwave)
+{
+    const int w = blockIdx.y;
+    const int col[2] = {(int)(blockIdx.x * 2 * kBlock + threadIdx.x),
+                        (int)(blockIdx.x * 2 * kBlock + kBlock + threadIdx.x)};
+    const bool active[2] = {col[0] < nwave, col[1] < nwave};
+    const int64_t plane = (int64_t)nlayers * nwave;
+    ec += (int64_t)w * plane;
+    typedef const double __attribute__((address_space(4))) *cdbl_t;
+    const cdbl_t rad = (cdbl_t)(unsigned long long)(radius + (int64_t)w * nlayers);
+    const cdbl_t path = (cdbl_t)(unsigned long long)(blocked + (int64_t)w * plen);
+    const int nimpact = min(ibottom, nlayers) - itop;
+    const double *src[2] = {ec + (int64_t)itop * nwave + (active[0] ? col[0] : 0),
+                            ec + (int64_t)itop * nwave + (active[1] ? col[1] : 0)};
+    int stop[2] = {-1, -1};
+    double acc[2] = {0.0, 0.0}, fprev[2] = {0.0, 0.0};
+    int64_t boff = 0;
+    for (int rb = 0; rb < nimpact; rb += kRows) {
+        if (__syncthreads_count((active[0] && stop[0] < 0) || (active[1] && stop[1] < 0)) == 0)
+            break;
+        const int rlast = min(rb + kRows, nimpact) - 1;
+        const int nseg = max(rlast, 0);
+        double tau[2][kRows];
+#pragma unroll
+        for (int k = 0; k < kRows; k++)
+            tau[0][k] = tau[1][k] = 0.0;
+        if (nseg > 0) {
+            double prev0 = src[0][0], prev1 = src[1][0];
+            const cdbl_t pb_ = path + boff;
+            // rows of ec are fetched kAhead at a time, one group ahead of the sums that use them
+            // (a wavefront then keeps 2 x kAhead row loads in flight: the stream comes from HBM)
+            constexpr int kAhead = 4;
+            double nx0[kAhead], nx1[kAhead];
+#pragma unroll
+            for (int j = 0; j < kAhead; j++) {
+                const int64_t row = (int64_t)min(j + 1, nseg) * nwave;
+                nx0[j] = src[0][row];
+                nx1[j] = src[1][row];
+            }
+            for (int i0 = 0; i0 < nseg; i0 += kAhead) {
+                double c0[kAhead], c1[kAhead];
+#pragma unroll
+                for (int j = 0; j < kAhead; j++) {
+                    c0[j] = nx0[j];
+                    c1[j] = nx1[j];
+                }
+#pragma unroll
+                for (int j = 0; j < kAhead; j++) {
+                    const int64_t row = (int64_t)min(i0 + kAhead + j + 1, nseg) * nwave;
+                    nx0[j] = src[0][row];
+                    nx1[j] = src[1][row];
+                }
+#pragma unroll
+                for (int j = 0; j < kAhead; j++) {
+                    const int i = i0 + j;
+                    if (i < nseg) {                             // uniform
+                        const double s0 = c0[j] + prev0, s1 = c1[j] + prev1;
+                        prev0 = c0[j];
+                        prev1 = c1[j];
+                        double pv[kRows];                       // wave-uniform: scalar loads
+#pragma unroll
+                        for (int k = 0; k < kRows; k++)
+                            pv[k] = pb_[i * kRows + k];
+#pragma unroll
+                        for (int k = 0; k < kRows; k++) {
+                            tau[0][k] = fma(pv[k], s0, tau[0][k]);
+                            tau[1][k] = fma(pv[k], s1, tau[1][k]);
+                        }
+                    }
+                }
+            }
+        }
+        boff += (int64_t)nseg * kRows;
+#pragma unroll
+        for (int c = 0; c < 2; c++) {
+#pragma unroll
+            for (int k = 0; k < kRows; k++) {
+                const int r = rb + k;
+                if (r <= rlast && active[c] && stop[c] < 0) {
+                    const double t = tau[c][k];
+                    const double rr = rad[itop + r];
+                    const double f = pb::exp_s(-t) * rr;
+                    if (r > 0)
+                        acc[c] += (rr - rad[itop + r - 1]) * (fprev[c] + f);
+                    fprev[c] = f;
+                    if (t > maxdepth)
+                        stop[c] = r;
+                }
+            }
+        }
+    }
+    const double rtop = rad[itop];
+#pragma unroll
+    for (int c = 0; c < 2; c++)
+        if (active[c])
+            spectrum[(int64_t)w * nwave + col[c]] =
+                (rtop * rtop + 2 * (acc[c] * 0.5)) / (rstar * rstar);
+}
+
+// ---------------------------------------------------------------------------
 // The same pass with the column tile in LDS: workgroup = 64 columns x NB wavefronts, wavefront b
 // owning the impact parameters 16b .. 16b+15.  The tile of s_i = ec[i+1] + ec[i] (64 columns x all
 // segments) is read from HBM ONCE, cooperatively and coalesced, and every wavefront then takes
@@ -583,7 +691,14 @@ int pb_transit_fused_launch(double *depth_d, int32_t *ideep_d, double *spectrum_
         depth_d, ideep_d, spectrum_d, ec_d, path_d, radius_d, plen, rstar, itop, ibottom,        \
         maxdepth, nlayers, nwave, deck_row, rsurf)
     static const bool no_fma = getenv("PB_TRANSIT_FMA") && atoi(getenv("PB_TRANSIT_FMA")) == 0;
-    if (scalar && rows == 16 && !depth_d && !ideep_d && nwalkers > 1 && !no_fma) {
+    static const bool no_pair = getenv("PB_TRANSIT_PAIR") && atoi(getenv("PB_TRANSIT_PAIR")) == 0;
+    if (scalar && rows == 16 && !depth_d && !ideep_d && nwalkers > 1 && !no_fma && !no_pair &&
+        deck_row < 0 && spectrum_d) {
+        // the retrieval batch, two columns per thread
+        dim3 pgrid(pb::div_up(nwave, 2 * kBlock), nwalkers);
+        k_transit_pair<16><<<pgrid, kBlock, 0, s>>>(spectrum_d, ec_d, path_d, radius_d, plen, rstar,
+                                                   itop, ibottom, maxdepth, nlayers, nwave);
+    } else if (scalar && rows == 16 && !depth_d && !ideep_d && nwalkers > 1 && !no_fma) {
         // the retrieval batch: spectrum only
         k_transit_fused<16, true, true><<<grid, kBlock, 0, s>>>(
             depth_d, ideep_d, spectrum_d, ec_d, path_d, radius_d, plen, rstar, itop, ibottom,

@@ -121,18 +121,35 @@ __global__ __launch_bounds__(kBlock) void k_transit_tau(double *depth, const dou
             const int64_t boff = (int64_t)kRows * (kRows * b * (b - 1) / 2 + b * (kRows - 1));
             typedef const double __attribute__((address_space(4))) *cpath_t;
             const cpath_t pb_ = (cpath_t)(unsigned long long)(raypath + boff);
-#pragma unroll 2
-            for (int i = 0; i < nseg; i++) {
-                const double next = src[(int64_t)(i + 1) * nwave];
-                const double s = next + prev;
-                prev = next;
-                double pv[kRows];
+            // rows of ec are fetched kAhead at a time, one group ahead of the sums that use them
+            constexpr int kAhead = 4;
+            double nx[kAhead];
 #pragma unroll
-                for (int k = 0; k < kRows; k++)
-                    pv[k] = pb_[i * kRows + k];
+            for (int j = 0; j < kAhead; j++)
+                nx[j] = src[(int64_t)min(j + 1, nseg) * nwave];
+            for (int i0 = 0; i0 < nseg; i0 += kAhead) {
+                double cur[kAhead];
 #pragma unroll
-                for (int k = 0; k < kRows; k++)
-                    tau[k] += pv[k] * s;
+                for (int j = 0; j < kAhead; j++)
+                    cur[j] = nx[j];
+#pragma unroll
+                for (int j = 0; j < kAhead; j++)
+                    nx[j] = src[(int64_t)min(i0 + kAhead + j + 1, nseg) * nwave];
+#pragma unroll
+                for (int j = 0; j < kAhead; j++) {
+                    const int i = i0 + j;
+                    if (i < nseg) {                             // uniform
+                        const double s = cur[j] + prev;
+                        prev = cur[j];
+                        double pv[kRows];
+#pragma unroll
+                        for (int k = 0; k < kRows; k++)
+                            pv[k] = pb_[i * kRows + k];
+#pragma unroll
+                        for (int k = 0; k < kRows; k++)
+                            tau[k] += pv[k] * s;
+                    }
+                }
             }
         } else {
 #pragma unroll 4
@@ -184,11 +201,21 @@ __global__ __launch_bounds__(kBlock) void k_transit_finish(
     double acc = 0.0, fprev = 0.0, rprev = 0.0;
     // rows are fetched eight at a time (independent loads in flight), then examined in order
     constexpr int kFetch = 8;
+    double nx[kFetch];
+#pragma unroll
+    for (int k = 0; k < kFetch; k++)
+        nx[k] = k < nimpact ? depth[(int64_t)(itop + k) * nwave + col] : 0.0;
     for (int r0 = 0; r0 < nimpact; r0 += kFetch) {
         double t[kFetch];
 #pragma unroll
         for (int k = 0; k < kFetch; k++)
-            t[k] = (r0 + k < nimpact) ? depth[(int64_t)(itop + r0 + k) * nwave + col] : 0.0;
+            t[k] = nx[k];
+        // the next group is requested before this one is examined
+#pragma unroll
+        for (int k = 0; k < kFetch; k++)
+            nx[k] = (r0 + kFetch + k < nimpact)
+                        ? depth[(int64_t)(itop + r0 + kFetch + k) * nwave + col]
+                        : 0.0;
 #pragma unroll
         for (int k = 0; k < kFetch; k++) {
             const int r = r0 + k;
