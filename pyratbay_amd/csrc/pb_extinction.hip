@@ -1239,16 +1239,22 @@ __global__ __launch_bounds__(NW * 64, 8) void k_ext_staged(LblArgs a)
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(kBlock) void k_work_stats(LblArgs a, unsigned long long *out)
 {
-    const int64_t n = (int64_t)a.nlayers * a.ngroups;
+    // long rows: one record per (group, chunk of the row), empty ones have length 0; the groups'
+    // entries are not in group order there, so only the one-row (add) form is counted
+    const int64_t per_layer = (int64_t)a.ngroups * a.nch_max;
+    const int64_t n = (int64_t)a.nlayers * per_layer;
     unsigned long long useful = 0, issued = 0, live = 0;
     for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n;
          i += (int64_t)gridDim.x * kBlock) {
-        const int layer = (int)(i / a.ngroups);
-        const int64_t g = i - (int64_t)layer * a.ngroups;
-        const int iext = a.isoiext[a.ph_iso[g]];
-        if (iext < 0)
-            continue;
-        const int row = a.add ? 0 : iext;
+        const int layer = (int)(i / per_layer);
+        int row = 0;
+        if (a.nch_max == 1) {
+            const int64_t g = i - (int64_t)layer * a.ngroups;
+            const int iext = a.isoiext[a.ph_iso[g]];
+            if (iext < 0)
+                continue;
+            row = a.add ? 0 : iext;
+        }
         const double kthresh =
             a.ethresh * __longlong_as_double((long long)a.kmax_bits[(int64_t)layer * a.nrows + row]);
         const Rec16 r = a.rec16[i];
@@ -2841,7 +2847,12 @@ static int lbl_extinction(pb_lbl *p, double *ext_d, int64_t wbegin, int64_t wcou
     }
     PB_LAUNCH_CHECK();
     p->last_args = a;
-    p->last_packed = a.rec16 != nullptr && a.nch_max == 1;
+    // (chunked records are counted only in the one-row form with every isotope kept: the entries
+    // of a skipped isotope are never written)
+    p->last_packed = a.rec16 != nullptr &&
+                     (a.nch_max == 1 ||
+                      (a.nrows == 1 && std::all_of(p->isoiext.begin(), p->isoiext.end(),
+                                                   [](int32_t v) { return v >= 0; })));
     if (timed) {
         PB_HIP(hipEventRecord(p->ev[p->ev_used + 1], s));
         p->ev_used += 2;
