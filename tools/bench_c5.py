@@ -218,7 +218,7 @@ def main(args):
         interp_bytes = 8.0 * NSPEC * nwave * nodes + 8.0 * nlayers * nwave * nloc
         transit_bytes = (8.0 * nlayers * nwave + 8.0 * nwave) * nloc
         kernels = [
-            {'kernel': 'k_transit_fused<16,true,true>', 'kernel_ms': transit_ms,
+            {'kernel': 'k_transit_pair<16>', 'kernel_ms': transit_ms,
              'kernel_bytes': transit_bytes, 'bound_by': 'FP64 vector ALU (3160 fma + 80 exp per '
              'column), not HBM'},
             {'kernel': 'k_interp_ec_batch<4,true>', 'kernel_ms': interp_ms,
