@@ -513,6 +513,16 @@ def main():
         # what the gather kernel IS bound by: every profile sample it multiplies is one 8-byte
         # LDS read (zero lanes around a row included) -- counted on the device from the record
         # windows of the last launch
+        # the operand SURVEY 8(d)'s byte count leaves out: the Voigt-table samples the launch's
+        # live records select, each counted once (what any evaluation must read of `profile`)
+        tsamp = model.lbl.last_table_samples()
+        if tsamp is not None:
+            roof['table_bytes_unique'] = 8.0 * tsamp
+            roof['with_table'] = {
+                'bytes': kernel_bytes + 8.0 * tsamp,
+                'achieved': (kernel_bytes + 8.0 * tsamp) / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0,
+                'note': 'kernel_bytes + distinct table samples x 8 B: compare with `traffic`'}
+            roof['with_table']['frac'] = roof['with_table']['achieved'] / HBM_PEAK_GBS
         work = model.lbl.last_work()
         if work is not None and kernel_ms > 0:
             lds_tbps = work['fma_lanes_issued'] * 8.0 / (kernel_ms * 1e-3) / 1e12

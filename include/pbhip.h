@@ -160,6 +160,11 @@ int pb_lbl_extinction_end(pb_lbl *p, void *stream);
  * resampling), work[1] = lanes the LDS-staged kernels issue for them (256-sample spans),
  * work[2] = live records.  All -1 when the last launch kept no packed records. */
 int pb_lbl_last_work(pb_lbl *p, int64_t work[3], void *stream);
+/* Diagnostics: distinct Voigt-table samples the live records of the last extinction call select
+ * (per (layer, isotope, Doppler column, phase) row the longest window taken from it) -- what any
+ * evaluation of _extcoeff.c:302-307 must read of `profile` at least once.  -1 when the last
+ * launch kept no packed one-piece records. */
+int pb_lbl_last_table_samples(pb_lbl *p, int64_t *samples, void *stream);
 /* Per-launch timing of the gather kernel with HIP events on the call's stream:
  * begin() arms up to max_launches start/stop pairs, every following
  * pb_lbl_extinction records one pair around its gather launch, end() returns the summed

@@ -52,6 +52,7 @@ _PROTOS = {
     'pb_lbl_last_state': [vp, vp, vp, i32, i32, vp],
     'pb_lbl_last_layer_kinds': [vp, vp, vp, i32, vp],
     'pb_lbl_last_work': [vp, C.POINTER(i64 * 3), vp],
+    'pb_lbl_last_table_samples': [vp, C.POINTER(i64), vp],
     'pb_lbl_timing_begin': [vp, i32],
     'pb_lbl_timing_end': [vp, C.POINTER(f64), C.POINTER(i32)],
     'pb_lbl_destroy': [vp],

@@ -1279,6 +1279,52 @@ __global__ __launch_bounds__(kBlock) void k_work_stats(LblArgs a, unsigned long 
     }
 }
 
+// Distinct Voigt-table samples the live records of the last launch select: per (layer, isotope,
+// Doppler column, phase) row the longest window any record takes from it (maxlen, zeroed by the
+// caller); the sum of those lengths is what ANY gather must read of the table at least once --
+// the operand SURVEY 8(d)'s byte count leaves out.
+__global__ __launch_bounds__(kBlock) void k_table_rows(LblArgs a, int32_t *maxlen)
+{
+    const int64_t n = (int64_t)a.nlayers * a.ngroups;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n;
+         i += (int64_t)gridDim.x * kBlock) {
+        const int layer = (int)(i / a.ngroups);
+        const int64_t g = i - (int64_t)layer * a.ngroups;
+        const int iso = a.ph_iso[g];
+        const int iext = a.isoiext[iso];
+        if (iext < 0)
+            continue;
+        const int row = a.add ? 0 : iext;
+        const double kthresh =
+            a.ethresh * __longlong_as_double((long long)a.kmax_bits[(int64_t)layer * a.nrows + row]);
+        const Rec16 r = a.rec16[i];
+        const int len = (int)(r.lc & 0xfffu);
+        const int64_t lo = max((int64_t)r.ulo, a.wbegin);
+        const int64_t hi = min((int64_t)r.ulo + len, a.wbegin + a.wcount);
+        if (r.k < kthresh || hi <= lo)
+            continue;
+        const int cell = (int)(r.lc >> 12);
+        const int idop = cell - a.li_ilor[(int64_t)layer * a.niso + iso] * a.ndop;
+        const int d = a.psize[cell] - a.ph_iown[g];
+        const int q = floor_div_inv(d, a.inv_osamp);
+        const int phi = d - q * a.osamp;
+        atomicMax(&maxlen[(((int64_t)layer * a.niso + iso) * a.ndop + idop) * a.osamp + phi], len);
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void k_sum_i32(const int32_t *v, int64_t n,
+                                                    unsigned long long *out)
+{
+    unsigned long long acc = 0;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n;
+         i += (int64_t)gridDim.x * kBlock)
+        acc += (unsigned long long)v[i];
+    for (int d = 32; d >= 1; d >>= 1)
+        acc += __shfl_down(acc, d);
+    if ((threadIdx.x & 63) == 0)
+        atomicAdd(out, acc);
+}
+
 // ---------------------------------------------------------------------------
 // 3a''. Resident-profile gather (constant-step grid), for layers whose profiles are narrow:
 // the WHOLE phase-major block of a table cell (osamp rows of a few tens of samples,
@@ -2984,6 +3030,40 @@ int pb_lbl_last_work(pb_lbl *p, int64_t work[3], void *stream)
     PB_HIP(e);
     for (int i = 0; i < 3; i++)
         work[i] = (int64_t)h[i];
+    return PB_OK;
+}
+
+int pb_lbl_last_table_samples(pb_lbl *p, int64_t *samples, void *stream)
+{
+    PB_REQUIRE(p && samples, "pb_lbl_last_table_samples: null pointer");
+    *samples = -1;
+    const LblArgs &a = p->last_args;
+    if (!p->last_packed || a.nch_max != 1)
+        return PB_OK;                 // not counted for this kernel / record format
+    hipStream_t s = pb::as_stream(stream);
+    const int64_t n = (int64_t)a.nlayers * a.niso * a.ndop * a.osamp;
+    int32_t *maxlen = nullptr;
+    unsigned long long *d = nullptr;
+    PB_HIP(hipMalloc(&maxlen, (size_t)n * sizeof(int32_t)));
+    hipError_t e = hipMalloc(&d, sizeof(unsigned long long));
+    if (e == hipSuccess)
+        e = hipMemsetAsync(maxlen, 0, (size_t)n * sizeof(int32_t), s);
+    if (e == hipSuccess)
+        e = hipMemsetAsync(d, 0, sizeof(unsigned long long), s);
+    unsigned long long h = 0;
+    if (e == hipSuccess) {
+        k_table_rows<<<1024, kBlock, 0, s>>>(a, maxlen);
+        k_sum_i32<<<256, kBlock, 0, s>>>(maxlen, n, d);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess)
+        e = hipMemcpyAsync(&h, d, sizeof(h), hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess)
+        e = hipStreamSynchronize(s);
+    (void)hipFree(maxlen);
+    (void)hipFree(d);
+    PB_HIP(e);
+    *samples = (int64_t)h;
     return PB_OK;
 }
 

@@ -263,6 +263,13 @@ class LBL:
         return dict(fma_lanes_useful=int(w[0]), fma_lanes_issued=int(w[1]),
                     live_records=int(w[2]))
 
+    def last_table_samples(self):
+        """Distinct Voigt-table samples the live records of the last call select (None when not
+        counted): pb_lbl_last_table_samples."""
+        n = C.c_int64(-1)
+        call('pb_lbl_last_table_samples', self._h, C.byref(n), _stream())
+        return None if n.value < 0 else int(n.value)
+
     def last_state(self, nlayers, rows):
         ofactor = np.zeros(nlayers, np.int32)
         kmax = np.zeros((nlayers, rows))

@@ -278,6 +278,52 @@ def test_staged_variants_agree(eng, monkeypatch):
             np.testing.assert_allclose(got, base, rtol=1e-13)
 
 
+def test_work_counters_of_last_launch(eng):
+    """The device-side counters behind bench.py's roofline block (pb_lbl_last_work,
+    pb_lbl_last_table_samples): multiplied profile samples partition exactly over wavenumber
+    shards, the staged kernels issue whole 256-sample spans, and the distinct table samples of a
+    call lie between the larger shard's and the sum of both."""
+    from pyratbay_amd import synth
+    case = synth.lbl_case(9001, 6, 60000, wnosamp=24, nlor=18, ndop=9, extent=80.0,
+                          cutoff=3.0, niso=2, seed=78)
+    g, atm, ln, iso, vg = (case[k] for k in ('grid', 'atm', 'lines', 'iso', 'voigt'))
+    vt = eng.VoigtTable.build(vg['lorentz'], vg['doppler'], vg['size'], g['ownstep'], 24)
+    ll = eng.LineList(ln['lwn'], ln['elow'], ln['gf'], ln['lid'], 2, g['own'])
+    lbl = eng.LBL(vt, ll, g['wn'], g['divisors'], atm['mol_radius'], atm['mol_mass'],
+                  iso['isoimol'], iso['isomass'], iso['isoratio'], iso['isoiext'],
+                  vg['cutoff'], 1e-30, max_layers=6)
+    lbl.set_gather_mode('staged')
+    t, d, z = eng.dev(atm['temp']), eng.dev(atm['dens']), eng.dev(iso['isoz'])
+    nwave = len(g['wn'])
+
+    def counters(a, b):
+        ext = host(lbl.extinction(t, d, z, add=True, wbegin=a, wcount=b - a))
+        w = lbl.last_work()
+        return w, lbl.last_table_samples(), ext
+
+    whole, tab, ext = counters(0, nwave)
+    assert 0 < whole['fma_lanes_useful'] <= whole['fma_lanes_issued']
+    assert whole['fma_lanes_issued'] % 256 == 0
+    assert 0 < whole["live_records"] <= 6 * ll.ngroups
+    # every distinct table sample is multiplied at least once; none beyond the table per layer
+    assert 0 < tab <= whole['fma_lanes_useful']
+    assert tab <= 6 * vt.device_bytes // 8
+    cut = 4097
+    left, tab_l, _ = counters(0, cut)
+    right, tab_r, _ = counters(cut, nwave)
+    assert left['fma_lanes_useful'] + right['fma_lanes_useful'] == whole['fma_lanes_useful']
+    assert max(tab_l, tab_r) <= tab <= tab_l + tab_r
+    # a threshold that drops lines lowers every count
+    lbl2 = eng.LBL(vt, ll, g['wn'], g['divisors'], atm['mol_radius'], atm['mol_mass'],
+                   iso['isoimol'], iso['isomass'], iso['isoratio'], iso['isoiext'],
+                   vg['cutoff'], 1e-3, max_layers=6)
+    lbl2.set_gather_mode('staged')
+    lbl2.extinction(t, d, z, add=True)
+    w2, tab2 = lbl2.last_work(), lbl2.last_table_samples()
+    assert w2['live_records'] < whole['live_records']
+    assert w2['fma_lanes_useful'] < whole['fma_lanes_useful'] and tab2 <= tab
+
+
 @pytest.mark.parametrize("seed", range(10))
 def test_random_configurations(eng, orc, seed):
     """Randomly drawn grids, oversampling factors, profile extents, cutoffs, line densities
