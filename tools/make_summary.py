@@ -3,6 +3,7 @@ and after copying its outputs into profiles/).  usage: python tools/make_summary
 import csv
 import json
 import os
+import re
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -23,8 +24,9 @@ def main():
     stats = {}
     with open(os.path.join(P, f'{tag}_kernel_stats.csv')) as f:
         for r in csv.DictReader(f):
-            name = r['Name'].split('(')[0].split('::')[-1].split('<')[0].strip()
-            stats[name] = float(r['AverageNs']) / 1e6
+            m = re.search(r'\b(k_[a-z_0-9]+)', r['Name'])
+            if m and m.group(1) not in stats:
+                stats[m.group(1)] = float(r['AverageNs']) / 1e6
     c2 = d['c2']
     r2, n = c2['roofline'], c2['north_star_target']
     b, wt = r2['binding'], r2.get('with_table', {})
