@@ -8,6 +8,9 @@
   agree to 1e-12) plus oracle parity on sampled layers (the oracle's C restatement of
   _extcoeff.extinction on one host core; a few seconds per layer).
 
+* C1 (the reference's CPU-runnable tutorial shape: 4 501 wavenumbers x 51 layers, one species):
+  the whole path, every layer of ec and the transit / emission spectrum against the oracle.
+
 Tolerance as in test_gpu_extinction.py: rtol 1e-10 against the oracle on every non-zero
 sample and an identical zero pattern."""
 import time
@@ -215,3 +218,37 @@ def test_full_size_config(eng, orc, name, monkeypatch):
         assert relr <= 1e-12, relr
         want0 = oracle_rows(orc, case, vt, profile, 10, False)
         check(host(rows[0]), want0, 'c4 add=0 layer 10')
+
+
+# ---------------------------------------------------------------------------
+# C1: the reference's CPU-runnable tutorial shape (W ~ 3.2-5 k, L ~ 40-51, one species) through
+# the whole path, every layer against the oracle
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize('rt_path', ['transit', 'emission'])
+def test_c1_tutorial_shape(eng, orc, rt_path):
+    from pyratbay_amd import synth
+    case = synth.lbl_case(4501, 51, 6000, wnstep=0.2, nlor=40, ndop=20, seed=5)
+    g, atm, ln, iso, vg = (case[k] for k in ('grid', 'atm', 'lines', 'iso', 'voigt'))
+    nl, nw = atm['nlayers'], g['nwave']
+    assert (nl, nw) == (51, 4501)
+    model = eng.LBLSpectrum(case, rt_path=rt_path)
+    spectrum = host(model.run())
+    profile = model.voigt.flat()
+    ec = np.zeros((nl, nw))
+    for layer in range(nl):
+        ec[layer] = oracle_rows(orc, case, model.voigt, profile, layer, True, case['ethresh'])[0]
+    check(host(model.ec)[:, 0], ec, f'c1 {rt_path} ec')
+    if rt_path == 'transit':
+        depth, ideep = orc.optical_depth_transit(ec, atm['radius'], 0, nl, case['maxdepth'])
+        want = orc.transmission(depth, atm['radius'], atm['rstar'], ideep, 0)
+    else:
+        depth = np.zeros((nl, nw))
+        ideep = np.full(nw, nl - 1, np.int32)
+        orc.plane_parallel_optical_depth(depth, ideep, ec, -orc.ediff(atm['radius']),
+                                         case['maxdepth'], 0, nl)
+        inten = orc.intensity(depth, ideep, orc.blackbody_wn_2D(g['wn'], atm['temp']),
+                              host(model.mu), 0)
+        want = np.sum(inten * host(model.weights)[:, None], axis=0)
+    assert np.array_equal(host(model.ideep), ideep)
+    np.testing.assert_allclose(spectrum, want, rtol=RTOL)
+    assert want.max() / want.min() > 1.0005
