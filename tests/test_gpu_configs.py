@@ -8,6 +8,9 @@
   agree to 1e-12) plus oracle parity on sampled layers (the oracle's C restatement of
   _extcoeff.extinction on one host core; a few seconds per layer).
 
+* C5 at FULL size: one 64-walker batch of the retrieval inner loop -- run-to-run bitwise equal,
+  independent of how the walkers are chunked, out-of-range temperatures rejected, the one-walker
+  eval() chain and the oracle chain on sampled walkers.
 * C1 (the reference's CPU-runnable tutorial shape: 4 501 wavenumbers x 51 layers, one species):
   the whole path, every layer of ec and the transit / emission spectrum against the oracle.
 
@@ -252,3 +255,47 @@ def test_c1_tutorial_shape(eng, orc, rt_path):
     assert np.array_equal(host(model.ideep), ideep)
     np.testing.assert_allclose(spectrum, want, rtol=RTOL)
     assert want.max() / want.min() > 1.0005
+
+
+# ---------------------------------------------------------------------------
+# C5 at FULL size: one batch of 64 walkers of the retrieval inner loop (1e5 wavenumbers x 80
+# layers, 4 species x 10 table temperatures = 2.56 GB of cross sections, per-walker radius)
+# ---------------------------------------------------------------------------
+def test_full_size_c5_batch(eng, orc):
+    import torch
+    from tools import bench_c5
+    inp = bench_c5.inputs()
+    g, atm = inp['grid'], inp['atm']
+    nl, nw = atm['nlayers'], g['nwave']
+    assert (nl, nw, inp['etable'].shape[:2]) == (80, 100001, (4, 10))
+    model = eng.TableSpectrum(inp['etable'], inp['ttable'], g['wn'], atm['radius'], atm['rstar'])
+    bands = eng.PassBands(g['wn'], inp['bands'])
+    temps, dens, radius = bench_c5.walkers(inp, 64, 700)
+    temps[17, 40] = 3000.5                               # above the table: rejected
+    td, dd, rd = eng.dev(temps), eng.dev(dens), eng.dev(radius)
+    flux = model.eval_bands(td, dd, bands, radius=rd, chunk=64)
+    again = model.eval_bands(td, dd, bands, radius=rd, chunk=64)
+    assert torch.equal(flux, again), 'two runs differ'
+    got = host(flux)
+    assert got.shape == (64, 24)
+    assert np.all(np.isinf(got[17])) and np.all(got[17] > 0)
+    ok = [w for w in range(64) if w != 17]
+    assert np.all(np.isfinite(got[ok]))
+    # a walker's result does not depend on the batch it travels in (same kernels: chunks of 32)
+    halves = torch.cat([model.eval_bands(td[a:b], dd[a:b], bands, radius=rd[a:b], chunk=32)
+                        for a, b in ((0, 32), (32, 64))])
+    assert torch.equal(halves[ok], flux[ok])
+    # the one-walker eval() chain (reference products and sums) agrees to rounding
+    for w in (0, 45):
+        model.set_radius(radius[w])
+        one = host(bands.integrate_batch(model.eval(temps[w], dens[w]).view(1, -1)))[0]
+        np.testing.assert_allclose(got[w], one, rtol=1e-12)
+    # oracle: interp_ec -> transit_path -> optical depth -> transmission -> trapezoid
+    for w in (3, 60):
+        ec = np.zeros((nl, nw))
+        orc.interp_ec(ec, inp['etable'], inp['ttable'], temps[w], dens[w], 0, nl)
+        depth, ideep = orc.optical_depth_transit(ec, radius[w], 0, nl, 10.0)
+        spec = orc.transmission(depth, radius[w], atm['rstar'], ideep, 0)
+        want = [np.trapezoid(spec[s:s + len(r)] * r, g['wn'][s:s + len(r)]) * h
+                for s, r, h in inp['bands']]
+        np.testing.assert_allclose(got[w], want, rtol=RTOL)
