@@ -73,9 +73,15 @@ def test_interp_ec_batch_vs_single_and_oracle(eng, orc):
         np.testing.assert_allclose(got6[w], want, rtol=RTOL)
 
 
+@pytest.mark.parametrize('rows', [None, 16])
 @pytest.mark.parametrize('itop,ibottom,maxdepth', [(0, None, 10.0), (2, None, 10.0),
                                                    (0, 19, 10.0), (1, None, np.inf)])
-def test_transit_spectrum_batch_vs_oracle(eng, orc, itop, ibottom, maxdepth):
+def test_transit_spectrum_batch_vs_oracle(eng, orc, itop, ibottom, maxdepth, rows, monkeypatch):
+    """rows=16 forces the block size of large launches at this small size: the spectrum-only
+    call then runs k_transit_pair (two columns per thread, fused multiply-adds), the call that
+    returns depth the one-column kernel with the reference's products and sums."""
+    if rows:
+        monkeypatch.setenv('PB_TRANSIT_ROWS', str(rows))
     rng = np.random.default_rng(7)
     c = cases.column_case(seed=9, nlayers=24, nwave=700)
     L, W, nw = c['nlayers'], c['nwave'], 6
@@ -89,13 +95,17 @@ def test_transit_spectrum_batch_vs_oracle(eng, orc, itop, ibottom, maxdepth):
                                                     ibottom, maxdepth, want_depth=True)
     only = eng.transit_spectrum_batch(eng.dev(ecs), path, rad_d, c['rstar'], itop, ibottom,
                                       maxdepth)
-    assert np.array_equal(host(only), host(spec))
+    if rows:
+        np.testing.assert_allclose(host(only), host(spec), rtol=1e-13)
+    else:
+        assert np.array_equal(host(only), host(spec))
     for w in range(nw):
         wd, wi = orc.optical_depth_transit(ecs[w], radius[w], itop, ibottom, maxdepth)
         ws = orc.transmission(wd, radius[w], c['rstar'], wi, itop)
         assert np.array_equal(host(ideep[w]), wi)
         np.testing.assert_allclose(host(depth[w]), wd, rtol=RTOL, atol=0)
         np.testing.assert_allclose(host(spec[w]), ws, rtol=RTOL)
+        np.testing.assert_allclose(host(only[w]), ws, rtol=RTOL)
 
 
 def test_fused_transit_equals_split(eng):
