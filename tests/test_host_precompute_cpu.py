@@ -1,0 +1,23 @@
+"""Host pre-computes of the callers against the reference's own loops,
+restated in the test.  CPU only."""
+import numpy as np
+
+
+def test_transit_path_host_equals_reference_loop(orc):
+    from pyratbay_amd import engine as eng
+    """engine.transit_path / oracle.transit_path against the reference's scalar loop
+    (atmosphere.py:790-800) written out: the same bits, and never a NaN -- squaring the array
+    with NumPy while the subtrahend is a scalar pow gives sqrt(negative) on the diagonal for one
+    atmosphere in ~30."""
+    rng = np.random.default_rng(12)
+    for _ in range(200):
+        L = int(rng.integers(2, 60))
+        rad = np.sort(rng.uniform(7.0e9, 8.0e9, L))[::-1].copy()
+        nskip = int(rng.integers(0, 3)) if L > 4 else 0
+        got, got_o = eng.transit_path(rad, nskip), orc.transit_path(rad, nskip)
+        r = rad[nskip:]
+        for row in range(len(r)):
+            want = np.array([np.sqrt(r[i]**2 - r[row]**2) - np.sqrt(r[i + 1]**2 - r[row]**2)
+                             for i in range(row)])
+            assert np.array_equal(got[nskip + row], want) and np.array_equal(got_o[nskip + row], want)
+            assert not np.isnan(want).any()
