@@ -25,9 +25,8 @@ constexpr int kBlock = 256;
 
 // ---------------------------------------------------------------------------
 // atmosphere.transit_path: path_r[i] = sqrt(rad_i^2 - rad_r^2) - sqrt(rad_{i+1}^2 - rad_r^2),
-// rad = radius[itop:], packed lower triangle (row r has r entries from r(r-1)/2).  IEEE
-// multiply, subtract and sqrt: the reference squares with libm's pow(x, 2), which is one ulp off
-// x*x for 0.09 % of values -- the paths of those rows differ from the host form by <= 1e-12.
+// rad = radius[itop:], packed lower triangle (row r has r entries from r(r-1)/2).  One multiply per
+// square; the reference's pow(x, 2) is 1 ulp off x*x for 0.09 % of values: those rows agree to 1e-12.
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(kBlock) void k_transit_path(double *raypath, const double *radius,
                                                          int itop, int nlayers, int64_t npath)
