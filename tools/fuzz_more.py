@@ -96,6 +96,44 @@ def batch(eng, orc, rng):
         np.testing.assert_allclose(host(only[w]), ws, rtol=1e-10)
 
 
+def voigt(eng, orc, rng):
+    """Random width grids: log-spaced like voigt.py builds them (with dlratio aliases) and raw
+    random widths with explicit alias columns, random fine step and phase count."""
+    from pyratbay_amd import synth
+    if rng.random() < 0.5:
+        case = synth.lbl_case(int(rng.integers(200, 3000)), int(rng.integers(2, 12)), 10,
+                              wnstep=float(rng.choice([0.01, 0.05, 0.25, 1.0])),
+                              nlor=int(rng.integers(2, 20)), ndop=int(rng.integers(2, 10)),
+                              extent=float(rng.uniform(5, 120)), cutoff=float(rng.uniform(1, 30)),
+                              dlratio=float(rng.choice([0.02, 0.1, 0.5])),
+                              ptop=10.0**rng.uniform(-8, -3), pbottom=10.0**rng.uniform(-1, 2))
+        vg, g = case['voigt'], case['grid']
+        lor, dop, size_in, dwn, osamp = vg['lorentz'], vg['doppler'], vg['size'], g['ownstep'], g['wnosamp']
+    else:
+        nlor, ndop = int(rng.integers(1, 8)), int(rng.integers(1, 6))
+        dwn = 10.0**rng.uniform(-4, -1.5)
+        lor = np.sort(10.0**rng.uniform(-5, 0, nlor))
+        dop = np.sort(10.0**rng.uniform(-3.5, -0.5, ndop))
+        size_in = rng.integers(1, 400, (nlor, ndop))
+        if rng.random() < 0.3:                             # one huge cell: the QUICK regime
+            size_in[rng.integers(0, nlor), rng.integers(0, ndop)] = 50000 + int(rng.integers(0, 300))
+        alias = rng.random((nlor, ndop)) < 0.25
+        alias[:, 0] = False
+        size_in = np.where(alias, 0, size_in)
+        osamp = int(rng.choice([1, 2, 5, 12, 24]))
+    size = np.array(size_in).copy()
+    index = np.zeros_like(size)
+    profile = np.zeros(int(np.sum(2 * np.maximum(size, 1) + 1)) + 8)
+    orc.voigt_grid(profile, size, index, lor, dop, dwn)
+    vt = eng.VoigtTable.build(lor, dop, size_in, dwn, osamp)
+    assert np.array_equal(vt.size, size) and np.array_equal(vt.index, index)
+    np.testing.assert_allclose(vt.flat(), profile[:vt.nprofile], rtol=2e-12)
+    back = eng.VoigtTable.from_flat(profile[:vt.nprofile].copy(), size, index, lor, dop, osamp)
+    assert np.array_equal(back.flat(), profile[:vt.nprofile])
+    vt.close()
+    back.close()
+
+
 def main():
     count = int(sys.argv[1]) if len(sys.argv) > 1 else 100
     import traceback
@@ -106,7 +144,8 @@ def main():
     bad = []
     for seed in range(count):
         for name, fn in (('grouping', lambda r: grouping(engine, r)),
-                         ('batch', lambda r: batch(engine, oracle, r))):
+                         ('batch', lambda r: batch(engine, oracle, r)),
+                         ('voigt', lambda r: voigt(engine, oracle, r))):
             try:
                 fn(np.random.default_rng(9000 + seed))
             except Exception:                              # noqa: BLE001
