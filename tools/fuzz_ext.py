@@ -1,0 +1,134 @@
+"""One-off sweep of pb_lbl_extinction against the UNMODIFIED reference _extcoeff.extinction
+(oracle/_ref) over the options the committed random cases hold fixed: add 0/1 with several output
+rows and skipped isotopes (isoiext -1), ethresh from 1e-30 to 1e-2, cutoff 0 (profile-limited
+windows), the constant-resolution output grid (linterp), every gather kernel.
+usage: python tools/fuzz_ext.py [count]"""
+import os
+import sys
+import traceback
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+RTOL = 1e-10
+
+
+def host(t):
+    return t.cpu().numpy()
+
+
+def one(eng, ref, rng, seed):
+    from pyratbay_amd import synth
+    nwave = int(rng.integers(3, 3000))
+    nlayers = int(rng.integers(1, 5))
+    nlines = int(rng.integers(1, 8000))
+    niso = int(rng.integers(1, 5))
+    wnosamp = int(rng.choice([6, 12, 24, 60]))
+    case = synth.lbl_case(nwave, nlayers, nlines, wnstep=float(rng.choice([0.01, 0.05, 0.2])),
+                          wnosamp=wnosamp, nlor=10, ndop=5,
+                          extent=float(rng.choice([8.0, 40.0, 150.0])),
+                          cutoff=float(rng.choice([0.0, 0.5, 3.0, 30.0])), niso=niso, seed=seed,
+                          ptop=10.0**rng.uniform(-7, -4), pbottom=10.0**rng.uniform(-1, 2))
+    g, atm, ln, iso, vg = (case[k] for k in ('grid', 'atm', 'lines', 'iso', 'voigt'))
+    resolution = rng.random() < 0.3
+    wn = g['wn']
+    if resolution:                       # constant resolving power, wn[0] == own[0]
+        R = float(rng.choice([3000.0, 20000.0]))
+        n = int(np.log(g['own'][-1] / g['own'][0]) / np.log(1 + 1 / R))
+        wn = g['own'][0] * (1 + 1 / R)**np.arange(max(n, 2))
+        wn = wn[wn <= g['own'][-1]]
+        if len(wn) < 2:
+            resolution, wn = False, g['wn']
+    add = bool(rng.random() < 0.5)
+    ethresh = float(rng.choice([1e-30, 1e-6, 1e-2]))
+    isoiext = np.array(iso['isoiext'], np.int32).copy()
+    if not add:
+        isoiext = rng.integers(0, int(rng.integers(1, 4)), niso).astype(np.int32)
+        isoiext[rng.integers(0, niso)] = 0                 # row 0 exists
+    if niso > 1 and rng.random() < 0.3:
+        isoiext[rng.integers(1, niso)] = -1
+    rows = 1 if add else int(isoiext.max()) + 1
+    vt = eng.VoigtTable.build(vg['lorentz'], vg['doppler'], vg['size'], g['ownstep'], wnosamp,
+                              True)
+    ll = eng.LineList(ln['lwn'], ln['elow'], ln['gf'], ln['lid'], niso, g['own'])
+    lbl = eng.LBL(vt, ll, wn, g['divisors'], atm['mol_radius'], atm['mol_mass'], iso['isoimol'],
+                  iso['isomass'], iso['isoratio'], isoiext, vg['cutoff'], ethresh,
+                  resolution=resolution, max_layers=nlayers)
+    t, d, z = eng.dev(atm['temp']), eng.dev(atm['dens']), eng.dev(iso['isoz'])
+    profile, psize, pindex = vt.flat(), np.array(vt.size), np.array(vt.index)
+    want = np.zeros((nlayers, rows, len(wn)))
+    E = ref.module('_extcoeff')
+    for k in range(nlayers):
+        E.extinction(want[k], profile, psize, pindex, vg['lorentz'], vg['doppler'], wn,
+                     g['own'], g['divisors'], atm['dens'][k], atm['mol_radius'],
+                     atm['mol_mass'], iso['isoimol'], iso['isomass'], iso['isoratio'],
+                     iso['isoz'][:, k].copy(), isoiext, ln['lwn'], ln['elow'], ln['gf'],
+                     ln['lid'], vg['cutoff'], ethresh, float(atm['temp'][k]), 0, int(add),
+                     int(resolution))
+    want_strict = None
+    if resolution:
+        # the same call through the oracle's restatement, compiled WITHOUT -ffast-math
+        from oracle import oracle as orc
+        want_strict = np.zeros_like(want)
+        for k in range(nlayers):
+            orc.extinction(want_strict[k], profile, psize, pindex, vg['lorentz'], vg['doppler'],
+                           wn, g['own'], g['divisors'], atm['dens'][k], atm['mol_radius'],
+                           atm['mol_mass'], iso['isoimol'], iso['isomass'], iso['isoratio'],
+                           iso['isoz'][:, k].copy(), isoiext, ln['lwn'], ln['elow'], ln['gf'],
+                           ln['lid'], vg['cutoff'], ethresh, float(atm['temp'][k]), 0, int(add),
+                           1)
+    modes = ['auto'] if resolution else ['auto', 'global', 'staged', 'resident', 'scatter', 'rounds']
+    for mode in modes:
+        lbl.set_gather_mode(mode)
+        got = host(lbl.extinction(t, d, z, add=add))
+        assert got.shape == want.shape, (got.shape, want.shape)
+        tag = f'{mode} add={add} resolution={resolution} rows={rows} ethresh={ethresh}'
+        assert np.array_equal(got == 0, want == 0), f'{tag}: zero pattern'
+        nz = want != 0
+        rel = np.max(np.abs(got[nz] / want[nz] - 1)) if nz.any() else 0.0
+        if rel > RTOL and want_strict is not None:
+            nz2 = want_strict != 0
+            rel_s = np.max(np.abs(got[nz2] / want_strict[nz2] - 1)) if nz2.any() else 0.0
+            rel_rs = np.max(np.abs(want[nz2] / want_strict[nz2] - 1)) if nz2.any() else 0.0
+            print(f'   linterp: kernel vs fast-math reference {rel:.1e}, kernel vs strict oracle '
+                  f'{rel_s:.1e}, reference vs strict oracle {rel_rs:.1e}')
+            if rel_s <= RTOL:
+                continue                                   # the reference build's own reassociation
+        if rel > RTOL:
+            bad = np.abs(got - want) > RTOL * np.abs(want)
+            scale = np.max(np.abs(want), axis=2, keepdims=True) * np.ones_like(want)
+            raise AssertionError(f'{tag}: max rel {rel:.2e} on {bad.sum()} of {nz.sum()} samples; '
+                                 f'largest |diff| / row max = {np.max(np.abs(got - want)[bad] / scale[bad]):.2e}')
+    lbl.close()
+    ll.close()
+    vt.close()
+    return dict(add=add, resolution=resolution, rows=rows, ethresh=ethresh)
+
+
+def main():
+    count = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+    from oracle import ref
+    if not ref.available():
+        sys.exit('oracle/_ref is not built')
+    from pyratbay_amd import engine
+    engine.require_gpu()
+    bad, seen = [], {}
+    for seed in range(count):
+        try:
+            info = one(engine, ref, np.random.default_rng(7000 + seed), seed)
+            key = (info['add'], info['resolution'], info['rows'] > 1)
+            seen[key] = seen.get(key, 0) + 1
+        except Exception:                                  # noqa: BLE001
+            bad.append(seed)
+            print('FAIL seed', seed)
+            traceback.print_exc(limit=3)
+        if seed % 50 == 49:
+            print(f'{seed + 1} seeds, {len(bad)} failures', flush=True)
+    print('covered (add, resolution, several rows):', seen)
+    print('failures:', bad)
+    return 1 if bad else 0
+
+
+if __name__ == '__main__':
+    sys.exit(main())
