@@ -723,8 +723,8 @@ int pb_transit_fused_launch(double *depth_d, int32_t *ideep_d, double *spectrum_
     return PB_OK;
 }
 
-// the blocked ray-path layout for one spectrum in stream-ordered scratch (freed by the caller
-// with hipFreeAsync on the same stream)
+// the blocked ray-path layout for one spectrum in the stream's persistent scratch (pb_core.hip);
+// PB_ERR_NOMEM when there is none: the caller falls back to the LDS form
 int pb_path_blocks_launch(double **blocked_d, int64_t *len, const double *raypath_d, int64_t npath,
                           int rows, int nimpact, hipStream_t s)
 {
@@ -733,17 +733,13 @@ int pb_path_blocks_launch(double **blocked_d, int64_t *len, const double *raypat
     *len = plen;
     if (plen <= 0)
         return PB_ERR_ARG;
-    double *buf = nullptr;
-    if (hipMallocAsync(reinterpret_cast<void **>(&buf), (size_t)plen * 8, s) != hipSuccess) {
-        (void)hipGetLastError();
+    double *buf = reinterpret_cast<double *>(pb::stream_scratch(s, (size_t)plen * 8));
+    if (!buf)
         return PB_ERR_NOMEM;
-    }
     dim3 bgrid((unsigned)std::min<int64_t>(64, pb::div_up(plen, kBlock)), 1);
     k_path_blocks<<<bgrid, kBlock, 0, s>>>(buf, raypath_d, npath, plen, rows, nimpact);
-    if (hipGetLastError() != hipSuccess) {
-        (void)hipFreeAsync(buf, s);
+    if (hipGetLastError() != hipSuccess)
         return PB_ERR_HIP;
-    }
     *blocked_d = buf;
     return PB_OK;
 }

@@ -825,12 +825,17 @@ static int transit_launch(double *depth_d, int32_t *ideep_d, double *spectrum_d,
         pb::set_error("%s: %d layers need %zu B of LDS", who, nrow, lds);
         return PB_ERR_UNSUPPORTED;
     }
-    // the ray paths re-laid per block of rows in stream-ordered scratch, so that the kernel can
+    // the ray paths re-laid per block of rows in the stream's scratch, so that the kernel can
     // take them with scalar loads (PB_TRANSIT_SCALAR=0: packed triangle staged in LDS)
     static const bool no_scalar = getenv("PB_TRANSIT_SCALAR") && atoi(getenv("PB_TRANSIT_SCALAR")) == 0;
     const int nimpact = std::min(ibottom, nlayers) - itop;
     double *blocked = nullptr;
-    if (!no_scalar && nimpact > 1) {
+    // (not while the stream is being captured: a graph must not depend on scratch that other work
+    // on a stream of the same handle may overwrite when the graph is replayed elsewhere)
+    hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(pb::as_stream(stream), &capturing) != hipSuccess)
+        (void)hipGetLastError();
+    if (!no_scalar && nimpact > 1 && capturing == hipStreamCaptureStatusNone) {
         int64_t plen = 0;
         if (pb_path_blocks_launch(&blocked, &plen, raypath_d, ((int64_t)nrow * (nrow - 1)) / 2,
                                   rows, nimpact, pb::as_stream(stream)) != PB_OK)
@@ -843,7 +848,6 @@ static int transit_launch(double *depth_d, int32_t *ideep_d, double *spectrum_d,
         else
             k_transit_tau<kRowsPerThread, true><<<grid, threads, 0, pb::as_stream(stream)>>>(
                 depth_d, ec_d, blocked, itop, ibottom, nlayers, nwave);
-        (void)hipFreeAsync(blocked, pb::as_stream(stream));
     } else if (narrow)
         k_transit_tau<kRowsPerThreadNarrow, false><<<grid, threads, lds, pb::as_stream(stream)>>>(
             depth_d, ec_d, raypath_d, itop, ibottom, nlayers, nwave);

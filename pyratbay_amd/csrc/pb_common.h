@@ -31,6 +31,10 @@ void set_error(const char *fmt, ...);
 
 inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
 
+// per-(device, stream) scratch that persists between calls (pb_core.hip); nullptr when it cannot
+// be provided (out of memory, or it would have to grow while the stream is being captured)
+void *stream_scratch(hipStream_t s, size_t bytes);
+
 #define PB_HIP(expr)                                                              \
     do {                                                                          \
         hipError_t e_ = (expr);                                                   \

@@ -1279,6 +1279,41 @@ __global__ __launch_bounds__(kBlock) void k_work_stats(LblArgs a, unsigned long 
     }
 }
 
+// Test aid (PB_POISON_RECORDS=1): new record buffers are filled with LIVE records of an enormous
+// strength that select the whole grid from table cell 0, instead of zeros (dead records).  A
+// gather kernel that examines a record k_records did not write in this call then shows up as a
+// result of ~1e300, not as silence -- tests/test_gpu_extinction.py::test_shards_never_read_unwritten_records.
+__global__ __launch_bounds__(kBlock) void k_poison_records(Rec16 *rec16, int64_t n16, Rec32 *rec32,
+                                                          int64_t n32, double *rec_k,
+                                                          int32_t *rec_i32, int64_t nsoa)
+{
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n16; i += stride) {
+        Rec16 r;
+        r.k = 1e300;
+        r.ulo = 0;
+        r.lc = 0xfffu;                      // 4095 samples of cell 0
+        rec16[i] = r;
+    }
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n32; i += stride) {
+        Rec32 r;
+        r.k = 1e300;
+        r.off = 0;
+        r.ulo = 0;
+        r.uhi = INT_MAX;
+        r.pad[0] = r.pad[1] = 0;
+        rec32[i] = r;
+    }
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < nsoa; i += stride) {
+        rec_k[i] = 1e300;
+        rec_i32[i] = 0;                     // ulo
+        rec_i32[nsoa + i] = INT_MAX;        // uhi
+        rec_i32[2 * nsoa + i] = 0;          // q
+        rec_i32[3 * nsoa + i] = 0;          // cell
+        rec_i32[4 * nsoa + i] = 0;          // phi
+    }
+}
+
 // Distinct Voigt-table samples the live records of the last launch select: per (layer, isotope,
 // Doppler column, phase) row the longest window any record takes from it (maxlen, zeroed by the
 // caller); the sum of those lengths is what ANY gather must read of the table at least once --
@@ -2486,14 +2521,22 @@ static int lbl_extinction(pb_lbl *p, double *ext_d, int64_t wbegin, int64_t wcou
     a.wcount = wcount;
     a.ext = ext_d;
     {
-        // records are needed for the groups within reach of the shard only
+        // records are needed for the groups within reach of the shard only.  The window must hold
+        // every group ANY gather kernel may examine: the staged / global / round kernels bracket
+        // their candidates by fine position (within min(hmax, cutoff) + osamp + ofactor of a tile),
+        // the resident and scatter kernels through the per-sample index gs_start, which examines
+        // up to two more output samples' worth of groups on either side -- hence 6 (not 2) x osamp
+        // of margin.  A group examined but never written would be whatever the allocation held
+        // (round 2: garbage records of a long-lived process sent the resident kernel out of
+        // bounds; found by tools/fuzz_pipeline.py); the buffers are also zeroed when allocated, so
+        // a record never written is a dead record.
         int64_t hmax_all = 0;
         for (int32_t h : v->psize)
             hmax_all = std::max<int64_t>(hmax_all, h);
         int64_t reach = hmax_all;
         if (a.cutoff > 0.0)
             reach = std::min(reach, (int64_t)(a.cutoff / a.ownstep) + 2 * (int64_t)v->osamp + 2);
-        reach += 2 * (int64_t)v->osamp;
+        reach += 6 * (int64_t)v->osamp;
         const bool whole = wbegin == 0 && wcount == p->nwave;
         a.rec_flo = whole ? INT64_MIN : wbegin * (int64_t)v->osamp - reach;
         a.rec_fhi = whole ? INT64_MAX : (wbegin + wcount - 1) * (int64_t)v->osamp + reach;
@@ -2587,6 +2630,7 @@ static int lbl_extinction(pb_lbl *p, double *ext_d, int64_t wbegin, int64_t wcou
     a.res_cap = resident ? p->res_cap : 0;
     a.rec32 = nullptr;
     a.rec16 = nullptr;
+    const bool poison = getenv("PB_POISON_RECORDS") && atoi(getenv("PB_POISON_RECORDS")) != 0;
     if (!staged || scatter)
         a.nch_max = 1;
     if (staged && !scatter && packable && (a.nch_max > 1 || !getenv("PB_REC_SOA"))) {
@@ -2603,6 +2647,10 @@ static int lbl_extinction(pb_lbl *p, double *ext_d, int64_t wbegin, int64_t wcou
                 return PB_ERR_NOMEM;
             }
             p->rec16_alloc = rec16_bytes;
+            PB_HIP(hipMemsetAsync(p->rec16, 0, rec16_bytes, s));
+            if (poison)
+                k_poison_records<<<1024, kBlock, 0, s>>>(p->rec16, (int64_t)(rec16_bytes / sizeof(Rec16)),
+                                                        nullptr, 0, nullptr, nullptr, 0);
         }
         a.rec16 = p->rec16;
     }
@@ -2616,6 +2664,10 @@ static int lbl_extinction(pb_lbl *p, double *ext_d, int64_t wbegin, int64_t wcou
                               n * sizeof(Rec32));
                 return PB_ERR_NOMEM;
             }
+            PB_HIP(hipMemsetAsync(p->rec32, 0, n * sizeof(Rec32), s));
+            if (poison)
+                k_poison_records<<<1024, kBlock, 0, s>>>(nullptr, 0, p->rec32, (int64_t)n, nullptr,
+                                                        nullptr, 0);
         }
         a.rec32 = p->rec32;
     }
@@ -2626,6 +2678,11 @@ static int lbl_extinction(pb_lbl *p, double *ext_d, int64_t wbegin, int64_t wcou
             pb::set_error("pb_lbl_extinction: cannot allocate %zu B of line records", n * 28);
             return PB_ERR_NOMEM;
         }
+        PB_HIP(hipMemsetAsync(p->rec_k, 0, n * 8, s));
+        PB_HIP(hipMemsetAsync(p->rec_i32, 0, n * 4 * 5, s));
+        if (poison)
+            k_poison_records<<<1024, kBlock, 0, s>>>(nullptr, 0, nullptr, 0, p->rec_k, p->rec_i32,
+                                                    (int64_t)n);
     }
     if (use_records) {
         const size_t n = (size_t)p->max_layers * (size_t)l->ngroups;

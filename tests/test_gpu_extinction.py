@@ -182,6 +182,47 @@ def test_wavenumber_shards_concatenate(eng, orc, gather):
     assert np.array_equal(host(lbl.extinction(t, d, z)), full)
 
 
+@pytest.mark.parametrize('gather', ['auto', 'global', 'staged', 'resident', 'scatter', 'rounds'])
+@pytest.mark.parametrize('wnosamp,cutoff', [(24, 3.0), (12, 30.0), (6, 0.5)])
+def test_shards_never_read_unwritten_records(eng, monkeypatch, gather, wnosamp, cutoff):
+    """A wavenumber shard computes the records of the groups within reach of it only.  Every shard
+    here runs on a FRESH plan whose record buffers start out filled with live records of strength
+    1e300 (PB_POISON_RECORDS): a gather kernel that examined a group outside the window k_records
+    wrote would turn the result into ~1e300 (with the round-2 window, two output samples too
+    narrow for the kernels that find their candidates through the per-sample index, the resident
+    kernel did -- whatever the allocation held, which is how a long-lived process faulted).  Also
+    the two-phase form, whose other groups are not even visited."""
+    from pyratbay_amd import synth
+    case = synth.lbl_case(2001, 4, 5000, wnstep=0.2, wnosamp=wnosamp, nlor=12, ndop=6,
+                          extent=150.0, cutoff=cutoff, niso=2, seed=31)
+    g, atm, ln, iso, vg = (case[k] for k in ('grid', 'atm', 'lines', 'iso', 'voigt'))
+    vt = eng.VoigtTable.build(vg['lorentz'], vg['doppler'], vg['size'], g['ownstep'], wnosamp)
+    ll = eng.LineList(ln['lwn'], ln['elow'], ln['gf'], ln['lid'], 2, g['own'])
+    t, d, z = eng.dev(atm['temp']), eng.dev(atm['dens']), eng.dev(iso['isoz'])
+
+    def plan():
+        lbl = eng.LBL(vt, ll, g['wn'], g['divisors'], atm['mol_radius'], atm['mol_mass'],
+                      iso['isoimol'], iso['isomass'], iso['isoratio'], iso['isoiext'],
+                      vg['cutoff'], 1e-30, max_layers=4)
+        lbl.set_gather_mode(gather)
+        return lbl
+
+    monkeypatch.setenv('PB_STAGE_SPLIT', '1')            # one association of the sums
+    full = host(plan().extinction(t, d, z))
+    assert np.isfinite(full).all() and full.max() < 1e-3
+    monkeypatch.setenv('PB_POISON_RECORDS', '1')
+    bounds = [0, 433, 865, 866, 1500, 2001]
+    for a, b in zip(bounds[:-1], bounds[1:]):
+        part = host(plan().extinction(t, d, z, wbegin=a, wcount=b - a))
+        assert np.array_equal(part, full[:, :, a:b]), (a, b)
+        lbl = plan()
+        out = eng.dev(np.zeros((4, 1, b - a)))
+        lbl.extinction_begin(t, d, z, add=True, out=out, wbegin=a, wcount=b - a)
+        lbl.extinction_end()
+        # (the shard's own maxima: with ethresh = 1e-30 nothing is dropped either way)
+        assert np.array_equal(host(out), full[:, :, a:b]), ('two-phase', a, b)
+
+
 def test_empty_and_out_of_range_lines(eng):
     from pyratbay_amd import synth
     case = synth.lbl_case(513, 3, 50, wnosamp=12, nlor=8, ndop=4, extent=30.0, cutoff=2.0)
