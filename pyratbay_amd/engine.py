@@ -581,6 +581,15 @@ class PassBands:
         return out
 
 
+def default_quadrature():
+    """(mu, weights) of the reference when `quadrature` is unset: raygrid = 0, 20, 40, 60, 80
+    degrees, weights = the solid angle between the mid-points (pyrat/spectrum.py:30-58)."""
+    raygrid = np.radians([0.0, 20.0, 40.0, 60.0, 80.0])
+    bounds = np.linspace(0, 0.5 * np.pi, len(raygrid) + 1)
+    bounds[1:-1] = 0.5 * (raygrid[:-1] + raygrid[1:])
+    return np.cos(raygrid), np.pi * (np.sin(bounds[1:])**2 - np.sin(bounds[:-1])**2)
+
+
 # --------------------------------------------------------------------------
 # Whole-path model: the three timed stages of Pyrat.run() (pyrat_obj.py:203-214)
 # --------------------------------------------------------------------------
@@ -631,11 +640,7 @@ class LBLSpectrum:
         else:
             self.intervals = dev(-np.diff(atm['radius']))
             if quadrature_mu is None:
-                raygrid = np.radians([0.0, 20.0, 40.0, 60.0, 80.0])
-                quadrature_mu = np.cos(raygrid)
-                bounds = np.linspace(0, 0.5 * np.pi, len(raygrid) + 1)
-                bounds[1:-1] = 0.5 * (raygrid[:-1] + raygrid[1:])
-                quadrature_weights = np.pi * (np.sin(bounds[1:])**2 - np.sin(bounds[:-1])**2)
+                quadrature_mu, quadrature_weights = default_quadrature()
             self.mu = dev(quadrature_mu)
             self.weights = dev(quadrature_weights)
         if rt_path == 'two_stream':
@@ -771,6 +776,10 @@ class TableSpectrum:
         self.rstar = float(rstar)
         self.set_radius(radius)
         if rt_path != 'transit':
+            if quadrature_mu is None:
+                quadrature_mu, quadrature_weights = default_quadrature()
+            elif quadrature_weights is None:
+                raise ValueError('quadrature_mu needs quadrature_weights')
             self.mu = dev(quadrature_mu)
             self.weights = dev(quadrature_weights)
         self.ec = torch.zeros((self.nlayers, self.nwave), dtype=torch.float64, device='cuda')

@@ -233,6 +233,15 @@ def test_eval_bands_emission_batch(eng, orc):
     got = host(model.eval_bands(eng.dev(temps), eng.dev(dens), pb, radius=eng.dev(radius),
                                 chunk=8))
     assert np.all(np.isinf(got[4]))
+    # the same model without an explicit quadrature: the reference's default raygrid (it used to
+    # upload None and return NaN)
+    plain = eng.TableSpectrum(etable, ttable, wn, base_radius, 8.8e10, rt_path='emission')
+    got_plain = host(plain.eval_bands(eng.dev(temps), eng.dev(dens), pb, radius=eng.dev(radius),
+                                      chunk=8))
+    assert np.array_equal(got_plain, got)
+    with pytest.raises(ValueError):
+        eng.TableSpectrum(etable, ttable, wn, base_radius, 8.8e10, rt_path='emission',
+                          quadrature_mu=mu)
     for w in (0, 7, 20):
         model.set_radius(radius[w])
         spec = model.eval(temps[w], eng.dev(dens[w]))

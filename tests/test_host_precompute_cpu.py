@@ -21,3 +21,16 @@ def test_transit_path_host_equals_reference_loop(orc):
                              for i in range(row)])
             assert np.array_equal(got[nskip + row], want) and np.array_equal(got_o[nskip + row], want)
             assert not np.isnan(want).any()
+
+
+def test_default_quadrature_is_the_reference_raygrid():
+    """`quadrature` unset: raygrid 0/20/40/60/80 degrees, weights = projected area between the
+    mid-points (pyrat/spectrum.py:47-58, default raygrid of the configuration parser)."""
+    from pyratbay_amd import engine as eng
+    mu, w = eng.default_quadrature()
+    raygrid = np.radians([0.0, 20.0, 40.0, 60.0, 80.0])
+    bounds = np.linspace(0, 0.5 * np.pi, len(raygrid) + 1)
+    bounds[1:-1] = 0.5 * (raygrid[:-1] + raygrid[1:])
+    assert np.array_equal(mu, np.cos(raygrid))
+    assert np.array_equal(w, np.pi * (np.sin(bounds[1:])**2 - np.sin(bounds[:-1])**2))
+    np.testing.assert_allclose(w.sum(), np.pi, rtol=1e-15)
