@@ -132,6 +132,77 @@ def one(rng, lib, ref):
     close(pa, pb_, 'interp_ec_per_mol')
 
 
+def heavy(rng, lib, ref, seed):
+    """vprofile.grid and the per-layer _extcoeff.extinction with HOST arrays in the package's own
+    dtypes (int64 sizes / indices / divisors / isotope maps, read as 32-bit like ind.h)."""
+    from pyratbay_amd import synth
+    V, Vr = lib['vprofile'], ref.module('vprofile')
+    E, Er = lib['_extcoeff'], ref.module('_extcoeff')
+    niso = int(rng.integers(1, 4))
+    osamp = int(rng.choice([6, 12, 24]))
+    case = synth.lbl_case(int(rng.integers(3, 1500)), int(rng.integers(1, 4)),
+                          int(rng.integers(1, 4000)), wnstep=float(rng.choice([0.05, 0.2])),
+                          # (a width grid much coarser than this lets a layer's nearest profile be
+                          # narrower than its dynamic-sampling step: the reference then reads the
+                          # neighbouring profile, _extcoeff.c:302-306 -- a documented deviation)
+                          wnosamp=osamp, nlor=int(rng.integers(10, 16)), ndop=int(rng.integers(4, 7)),
+                          extent=float(rng.choice([8.0, 40.0])), cutoff=float(rng.choice([0.0, 3.0])),
+                          niso=niso, seed=seed)
+    g, atm, ln, iso, vg = (case[k] for k in ('grid', 'atm', 'lines', 'iso', 'voigt'))
+    size_a = np.array(vg['size'], np.int64)                    # voigt.py:109-110 uses int
+    size_b = np.array(vg['size'], np.int64)
+    idx_a, idx_b = np.zeros_like(size_a), np.zeros_like(size_b)
+    n = int(np.sum(2 * np.maximum(size_a, 1) + 1)) + 16
+    prof_a, prof_b = np.zeros(n), np.zeros(n)
+    assert V.grid(prof_a, size_a, idx_a, vg['lorentz'], vg['doppler'], g['ownstep'], 0) == 1
+    Vr.grid(prof_b, size_b, idx_b, vg['lorentz'], vg['doppler'], g['ownstep'], 0)
+    assert np.array_equal(size_a, size_b) and np.array_equal(idx_a, idx_b), 'vprofile sizes'
+    np.testing.assert_allclose(prof_a, prof_b, rtol=2e-12, err_msg='vprofile.grid')
+    add = int(rng.random() < 0.5)
+    isoiext = np.array(iso['isoiext'], np.int64)
+    if not add:
+        isoiext = rng.integers(0, 2, niso).astype(np.int64)
+        isoiext[0] = 0
+    rows = 1 if add else int(isoiext.max()) + 1
+    ethresh = float(rng.choice([1e-30, 1e-4]))
+    nw = g['nwave']
+    for k in range(atm['nlayers']):
+        a, b = np.zeros((rows, nw)), np.zeros((rows, nw))
+        args = (prof_b, size_b, idx_b, vg['lorentz'], vg['doppler'], g['wn'], g['own'],
+                np.array(g['divisors'], np.int64), atm['dens'][k], atm['mol_radius'],
+                atm['mol_mass'], np.array(iso['isoimol'], np.int64), iso['isomass'],
+                iso['isoratio'], iso['isoz'][:, k].copy(), isoiext, ln['lwn'], ln['elow'],
+                ln['gf'], np.array(ln['lid'], np.int64), vg['cutoff'], ethresh,
+                float(atm['temp'][k]), 0, add, 0)
+        assert E.extinction(a, *args) == 1
+        Er.extinction(b, *args)
+        tag = (f'extinction layer {k} of {atm["nlayers"]}: add={add} rows={rows} ethresh={ethresh} '
+               f'cutoff={vg["cutoff"]} niso={niso} isoiext={isoiext.tolist()} nw={nw} '
+               f'nlines={len(ln["lwn"])} osamp={osamp}')
+        if not np.array_equal(a == 0, b == 0) or not np.allclose(a, b, rtol=1e-10, atol=0):
+            bad = np.nonzero(~np.isclose(a, b, rtol=1e-10, atol=0))
+            # a fresh plan for this layer alone: is it the reuse of the cached plan?
+            E.invalidate()
+            c = np.zeros((rows, nw))
+            E.extinction(c, *args)
+            from pyratbay_amd import engine as eng
+            res = {}
+            for name, vt in (('own table', eng.VoigtTable.build(vg['lorentz'], vg['doppler'], vg['size'], g['ownstep'], osamp)),
+                             ('from_flat', eng.VoigtTable.from_flat(prof_b, size_b, idx_b, vg['lorentz'], vg['doppler'], osamp))):
+                ll = eng.LineList(ln['lwn'], ln['elow'], ln['gf'], ln['lid'], niso, g['own'])
+                for ml in (atm['nlayers'], 1):
+                    lb = eng.LBL(vt, ll, g['wn'], g['divisors'], atm['mol_radius'], atm['mol_mass'],
+                                 iso['isoimol'], iso['isomass'], iso['isoratio'], isoiext.astype(np.int32),
+                                 vg['cutoff'], ethresh, max_layers=ml)
+                    e = lb.extinction(eng.dev(atm['temp'][k:k + 1]), eng.dev(atm['dens'][k:k + 1]),
+                                      eng.dev(iso['isoz'][:, k:k + 1].copy()), add=bool(add)).cpu().numpy()[0]
+                    res[f'{name} max_layers={ml}'] = bool(np.allclose(e, b, rtol=1e-10, atol=0))
+            raise AssertionError(f'{tag}: {len(bad[0])} samples differ (rows {np.unique(bad[0]).tolist()}); engine: {res}; '
+                                 f'fresh plan equal to reference: {np.allclose(c, b, rtol=1e-10, atol=0)}; '
+                                 f'first diff a={a[bad][0]:.6e} ref={b[bad][0]:.6e}')
+    E.invalidate()
+
+
 def main():
     count = int(sys.argv[1]) if len(sys.argv) > 1 else 100
     from oracle import ref
@@ -141,11 +212,14 @@ def main():
     engine.require_gpu()
     import importlib
     lib = {n: importlib.import_module('pyratbay_amd.lib.' + n)
-           for n in ('_trapezoid', '_blackbody', '_simpson', 'cutils', '_indices', '_extcoeff')}
+           for n in ('_trapezoid', '_blackbody', '_simpson', 'cutils', '_indices', '_extcoeff',
+                     'vprofile')}
     bad = []
     for seed in range(count):
         try:
             one(np.random.default_rng(4000 + seed), lib, ref)
+            if seed % 5 == 0:
+                heavy(np.random.default_rng(90000 + seed), lib, ref, seed)
         except Exception:                                  # noqa: BLE001
             bad.append(seed)
             print('FAIL seed', seed)
