@@ -74,10 +74,10 @@ def _worker(rank, world, port, nwave, tmp):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('nwave', [1001, 64])
-def test_two_rank_shards_reassemble(tmp_path, orc, nwave):
+@pytest.mark.parametrize('nwave,world', [(1001, 2), (64, 2), (1003, 3), (1001, 8)])
+def test_two_rank_shards_reassemble(tmp_path, orc, nwave, world):
+    """(world 3 and 8: uneven shards and the rank count of the node the driver benches on)"""
     import cases
-    world = 2
     mp.spawn(_worker, args=(world, _free_port(), nwave, str(tmp_path)), nprocs=world,
              join=True)
     c = cases.column_case(seed=21, nlayers=12, nwave=nwave)
@@ -122,10 +122,11 @@ def _worker_layers(rank, world, port, nlayers, nwave, tmp):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('nlayers,nwave', [(7, 101), (8, 64)])
-def test_layer_exchange_two_ranks(tmp_path, nlayers, nwave):
-    """[my layers, all columns] -> [all layers, my columns] through all_to_all_single."""
-    world = 2
+@pytest.mark.parametrize('nlayers,nwave,world', [(7, 101, 2), (8, 64, 2), (13, 257, 3),
+                                                 (80, 1001, 8), (5, 40, 8)])
+def test_layer_exchange_two_ranks(tmp_path, nlayers, nwave, world):
+    """[my layers, all columns] -> [all layers, my columns] through all_to_all_single
+    (also more ranks than some ranks have layers for: 5 layers on 8 ranks)."""
     mp.spawn(_worker_layers, args=(world, _free_port(), nlayers, nwave, str(tmp_path)),
              nprocs=world, join=True)
     for rank in range(world):
@@ -147,8 +148,8 @@ def _worker_walkers(rank, world, port, nwalkers, tmp):
     dist.destroy_process_group()
 
 
-def test_walker_replicas_gather(tmp_path):
-    nwalkers, world = 11, 2
+@pytest.mark.parametrize('nwalkers,world', [(11, 2), (29, 3), (64, 8), (5, 8)])
+def test_walker_replicas_gather(tmp_path, nwalkers, world):
     mp.spawn(_worker_walkers, args=(world, _free_port(), nwalkers, str(tmp_path)),
              nprocs=world, join=True)
     want = np.arange(nwalkers * 3, dtype=float).reshape(nwalkers, 3)
@@ -204,12 +205,12 @@ def _worker_pipeline(rank, world, port, nlayers, nwave, nsteps, tmp):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('nlayers,nwave,nsteps', [(7, 101, 5), (8, 64, 1), (5, 33, 2)])
-def test_exchange_pipeline_two_ranks(tmp_path, nlayers, nwave, nsteps):
+@pytest.mark.parametrize('nlayers,nwave,nsteps,world', [(7, 101, 5, 2), (8, 64, 1, 2), (5, 33, 2, 2),
+                                                        (13, 257, 4, 3), (80, 1001, 3, 8)])
+def test_exchange_pipeline_two_ranks(tmp_path, nlayers, nwave, nsteps, world):
     """The software-pipelined layer-sharded step (submit/flush: all-to-all and all-gather of
     spectrum i beside the production of i+1, double buffers) returns every spectrum, in
     order, on every rank."""
-    world = 2
     mp.spawn(_worker_pipeline,
              args=(world, _free_port(), nlayers, nwave, nsteps, str(tmp_path)),
              nprocs=world, join=True)
