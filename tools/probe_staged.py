@@ -4,6 +4,7 @@ Patches pyratbay_amd/csrc/pb_extinction.hip + pb_ext_args.h IN PLACE (restore th
 `git checkout pyratbay_amd/csrc` afterwards) so that `hipcc -DPB_PROBE=<bits>` builds
     bit 0  the kernel without its row DMA         (timing only, results are wrong)
     bit 1  the kernel without the walk            (timing only, results are wrong)
+    bit 3  the walk stops after the hit search (find_hits)       (timing only)
     bit 2  counters printed to stderr after every launch: segment steps, visits, the sum over
            the steps of the busiest wavefront's visits (what a barrier waits for), batches,
            records, and the shader clock the kernel ran at (clock64 against wall_clock64)
@@ -109,6 +110,16 @@ s = s[:j] + """#if PB_PROBE & 4
     }
 #endif
 """ + s[j:]
+old_fh = """                if ((sg & 63) == 0)
+                    find_hits(sg);
+                // byte address of this lane's first sample in the staged row"""
+assert old_fh in s
+s = s.replace(old_fh, """                if ((sg & 63) == 0)
+                    find_hits(sg);
+#if PB_PROBE & 8
+                return;                                   // bit 3: the hit search alone
+#endif
+                // byte address of this lane's first sample in the staged row""", 1)
 s = s.replace('fprintf(stderr, "probe: segsteps %llu', 'fprintf(stderr, "probe: MHz %.0f segsteps %llu', 1)
 s = s.replace('hh[0], hh[1], hh[2], hh[3], hh[4], grid.x',
               'hh[6] ? 100.0 * (double)hh[5] / (double)hh[6] : 0.0, hh[0], hh[1], hh[2], hh[3], '
