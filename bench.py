@@ -325,8 +325,8 @@ def timed_steps(run_steps, steps, warmup, lbl, world, dist, sync, device_for_red
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=20)
-    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--steps', type=int, default=50)
+    ap.add_argument('--warmup', type=int, default=4)
     ap.add_argument('--workload', default='c2', choices=sorted(WORKLOADS) + ['c5'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-north-star', action='store_true',
@@ -401,9 +401,21 @@ def main():
             pipelined = os.environ.get('PB_PIPELINE', '1') != '0'
         else:
             gather = SpectrumGather(nwave, world, rank, 'cuda')
-            model = engine.LBLSpectrum(case, rt_path=rt_path, wbegin=gather.wbegin,
-                                       wcount=gather.wcount, voigt=shared.get('voigt'),
-                                       lines=shared.get('lines'))
+            # one GPU: consecutive spectra are independent (the temperature loop of
+            # compute_opacity, the walkers of a retrieval), so `streams` of them are kept in
+            # flight on as many HIP streams (engine.SpectrumPipeline; PB_STREAMS=1: one at a
+            # time).  The second one fills the tail of the first one's gather launch.
+            streams = int(os.environ.get('PB_STREAMS', '2')) if world == 1 else 1
+            if streams > 1:
+                pipe = engine.SpectrumPipeline(case, depth=streams, rt_path=rt_path,
+                                               voigt=shared.get('voigt'),
+                                               lines=shared.get('lines'))
+                model = pipe.models[0]
+                res['streams'] = streams
+            else:
+                model = engine.LBLSpectrum(case, rt_path=rt_path, wbegin=gather.wbegin,
+                                           wcount=gather.wcount, voigt=shared.get('voigt'),
+                                           lines=shared.get('lines'))
             if world > 1 and os.environ.get('PB_KMAX_EXCHANGE', '1') != '0':
                 from pyratbay_amd.dist import kmax_allreduce
                 model.kmax_exchange = kmax_allreduce()     # records of the shard's groups only
@@ -414,12 +426,19 @@ def main():
                 # every rank computes its wavenumber shard, then the shards are re-assembled
                 # on every rank (RCCL all-gather over xGMI when world > 1)
                 return gather(model.run())
+            pipelined = streams > 1
         shared.setdefault('voigt', model.voigt)
         shared.setdefault('lines', model.lines)
         torch.cuda.synchronize()
         res['init_seconds'] = round(time.perf_counter() - t0, 3)
 
         def run_steps(k):
+            if pipelined and kind != 'layers':
+                out = None
+                for _ in range(k):
+                    out, _ev = pipe.submit()
+                pipe.flush()
+                return [out]
             if pipelined:
                 for _ in range(k):
                     sharded.submit()
@@ -443,9 +462,13 @@ def main():
                 for _ in range(k):
                     out = step()
                 return [out]
-            el2, _, _ = timed_steps(one_at_a_time, args.steps, 1, model.lbl, world, dist,
-                                    torch.cuda.synchronize, dev_reduce)
+            el2, g2, l2 = timed_steps(one_at_a_time, args.steps, 1, model.lbl, world, dist,
+                                      torch.cuda.synchronize, dev_reduce)
             res['unpipelined_ms_per_spectrum'] = 1e3 * el2 / args.steps
+            if kind != 'layers':
+                # the gather kernel's own duration (roofline) is the one measured with nothing
+                # else on the chip, not the one stretched by the neighbouring stream
+                res.update(gather_ms=g2, launches=l2)
         return res
 
     if world == 1:
@@ -533,7 +556,8 @@ def main():
                                'f64_fma_TFLOPs': 2.0 * work['fma_lanes_useful'] /
                                (kernel_ms * 1e-3) / 1e12}
         if world == 1:
-            par = 'single GPU'
+            par = 'single GPU' + (f", {primary['streams']} independent spectra in flight on "
+                                  f"{primary['streams']} HIP streams" if pipelined else '')
         elif layer_mode:
             par = (f'layer-sharded extinction x{world} + all-to-all + wavenumber-sharded RT + '
                    'all-gather' + (', consecutive spectra pipelined' if pipelined else ''))

@@ -225,7 +225,8 @@ __device__ inline Window group_window(const LblArgs &a, double wavn, int iown, i
                                       double alphad, int ofactor, double dwnstep,
                                       int64_t dnwn, int idop_lo, int idop_hi,
                                       const double *doppler, double cutsteps,
-                                      double inv_ofactor)
+                                      double inv_ofactor, bool clip_lo = true,
+                                      bool clip_hi = true)
 {
     // [idop_lo, idop_hi] brackets the answer (nearest index is monotonic in wavn), which
     // turns the bisection over the whole Doppler grid into 0-2 steps; `doppler` may point
@@ -241,9 +242,11 @@ __device__ inline Window group_window(const LblArgs &a, double wavn, int iown, i
     const int subw = iown - idwn * ofactor;
     w.minj = idwn - trunc_div_inv(w.half - subw, inv_ofactor);
     w.maxj = idwn + trunc_div_inv(w.half + subw, inv_ofactor);
-    if (w.minj < 0)
+    // (the packed records of the staged gathers keep a window that leaves the grid unclipped:
+    // see k_records)
+    if (clip_lo && w.minj < 0)
         w.minj = 0;
-    if (w.maxj > dnwn)
+    if (clip_hi && w.maxj > dnwn)
         w.maxj = dnwn;
     if (a.cutoff > 0.0) {
         const int mincut = (int)(idwn - cutsteps);
@@ -599,17 +602,31 @@ __global__ __launch_bounds__(kBlock) void k_records(LblArgs a)
                         continue;
                     }
                     const int ofactor = uniform_load(a.ls_ofactor, layer);
-                    const Window w = group_window(a, wavn, iown, s_ilor[e], s_alphad[e],
-                                                  ofactor, uniform_load(a.ls_dwnstep, layer), uniform_load(a.ls_dnwn, layer),
-                                                  0, a.ndop - 1, s_dop, uniform_load(a.ls_cutsteps, layer),
-                                                  uniform_load(a.ls_inv_ofactor, layer));
-                    // kept samples: minj <= scale*jo < maxj, inside the profile and the grid
+                    const int64_t dnwn = uniform_load(a.ls_dnwn, layer);
                     const double inv_scale = uniform_load(a.ls_inv_scale, layer);
+                    // The packed records of the staged gathers keep the window of a group that
+                    // leaves the grid UNCLIPPED: their consumers clamp every window to the tile
+                    // (hence to the grid) anyway, and the samples below 0 / at or beyond nwave
+                    // that the reference's clips `minj = 0`, `maxj = dnwn` remove do not exist
+                    // (the upper one only while ceil(dnwn / scale) reaches nwave: checked).
+                    // Clipped, every such group had a row window of its own -- one staged row,
+                    // one barrier step per RECORD: the first and the last tile of a layer ran
+                    // twice as long as the others and ended the launch (904 of 1003 us at C2).
+                    constexpr bool kPacked = (kFmt == 1 || kFmt == 2) && !kPos;
+                    const bool hi_free =
+                        kPacked && -floor_div_inv(-(int)dnwn, inv_scale) >= a.nwave;
+                    const Window w = group_window(a, wavn, iown, s_ilor[e], s_alphad[e],
+                                                  ofactor, uniform_load(a.ls_dwnstep, layer), dnwn,
+                                                  0, a.ndop - 1, s_dop, uniform_load(a.ls_cutsteps, layer),
+                                                  uniform_load(a.ls_inv_ofactor, layer), !kPacked,
+                                                  !hi_free);
+                    // kept samples: minj <= scale*jo < maxj, inside the profile and the grid
                     ulo = -floor_div_inv(-(int)w.minj, inv_scale);
                     uhi = -floor_div_inv(-(int)w.maxj, inv_scale);
                     ulo = max(ulo, -floor_div_inv(w.half - iown, a.inv_osamp));
                     uhi = min(uhi, floor_div_inv(iown + w.half, a.inv_osamp) + 1);
-                    uhi = min(uhi, a.nwave);
+                    if (!hi_free)
+                        uhi = min(uhi, a.nwave);
                     q = floor_div_inv(w.half - iown, a.inv_osamp);
                     phi = (w.half - iown) - q * a.osamp;
                     cell = w.cell;

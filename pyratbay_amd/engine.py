@@ -757,6 +757,64 @@ class LBLSpectrum:
         return self.rt()
 
 
+class SpectrumPipeline:
+    """Consecutive, independent spectra of one line-by-line model kept in flight on `depth` HIP
+    streams (default 2): spectrum i+1 starts while spectrum i is still finishing.
+
+    Why: one spectrum of C2 is a chain of launches whose dominant one, the extinction gather,
+    runs ~2000 workgroups of 0.3-0.7 ms on 1024 slots -- its last fifth is a tail in which most
+    of the chip idles (measured: 79 % of the slot-time busy), and the small launches around it
+    (layer state, records, ray paths, depth, spectrum) cannot fill a chip either.  A second
+    spectrum on another stream fills those holes: +19 % spectra/s at C2 on one MI355X.  The
+    callers this serves compute many independent spectra anyway: the temperature loop of
+    `compute_opacity` (pyrat/extinction.py:100-122), the walkers of a retrieval.
+
+    Every context has its own plan (records, per-layer state, ec, depth) and shares the Voigt
+    table and the line list, which a run only reads.  A context's output buffers are reused by
+    its next submit(): consume (or copy) a result before submitting `depth` more spectra.
+    Results are bit-identical to LBLSpectrum.run() of the same atmosphere
+    (tests/test_gpu_pipeline.py::test_spectrum_pipeline_equals_serial_runs)."""
+
+    def __init__(self, case, depth=2, **kw):
+        require_gpu()
+        first = LBLSpectrum(case, **kw)
+        kw = dict(kw, voigt=first.voigt, lines=first.lines)
+        self.models = [first] + [LBLSpectrum(case, **kw) for _ in range(depth - 1)]
+        self.streams = [torch.cuda.Stream() for _ in range(depth)]
+        self.done = [None] * depth          # completion event of each context's last spectrum
+        self.count = 0
+
+    @property
+    def depth(self):
+        return len(self.models)
+
+    def submit(self, atmosphere=None):
+        """Enqueue one spectrum (optionally of a new atmosphere: the arguments of
+        LBLSpectrum.set_atmosphere as a tuple or dict) and return (spectrum, event): the
+        device tensor is complete once `event` has fired (flush() waits for all of them)."""
+        j = self.count % len(self.models)
+        self.count += 1
+        model, stream = self.models[j], self.streams[j]
+        stream.wait_stream(torch.cuda.current_stream())     # inputs made on the caller's stream
+        with torch.cuda.stream(stream):
+            if isinstance(atmosphere, dict):
+                model.set_atmosphere(**atmosphere)
+            elif atmosphere is not None:
+                model.set_atmosphere(*atmosphere)
+            out = model.run()
+            event = torch.cuda.Event()
+            event.record(stream)
+        self.done[j] = event
+        return out, event
+
+    def flush(self):
+        """Make the caller's stream wait for every spectrum submitted so far."""
+        cur = torch.cuda.current_stream()
+        for event in self.done:
+            if event is not None:
+                cur.wait_event(event)
+
+
 class TableSpectrum:
     """Retrieval inner loop on sampled cross sections (Line_Sample path,
     pyratbay/opacity/line_sampling.py:394-463 -> _extcoeff.interp_ec): the table

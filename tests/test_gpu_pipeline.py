@@ -295,3 +295,44 @@ def test_layer_sharded_set_atmosphere(eng, case):
         assert np.array_equal(sh.step().cpu().numpy(), want)
         sh.set_atmosphere(atm['temp'], atm['dens'], iso['isoz'])
         assert np.array_equal(sh.step().cpu().numpy(), base)
+
+
+@pytest.mark.parametrize('rt_path', ['transit', 'emission'])
+def test_spectrum_pipeline_equals_serial_runs(eng, case, rt_path):
+    """engine.SpectrumPipeline: consecutive spectra of alternating atmospheres in flight on two
+    and three HIP streams -- every spectrum bit-identical to LBLSpectrum.run() of the same
+    atmosphere, in submission order, with the shared Voigt table and line list untouched."""
+    import torch
+    from pyratbay_amd import synth
+    atm, iso = case['atm'], case['iso']
+    atmospheres = []
+    for f in (1.0, 1.1, 0.93, 1.04, 0.97):
+        temp = atm['temp'] * f
+        isoz = synth.partition_function(temp)[None, :].repeat(len(iso['isomass']), 0)
+        atmospheres.append((temp, atm['dens'] / f, isoz, atm['radius'] * (1.0 + 0.01 * (f - 1))))
+    serial = eng.LBLSpectrum(case, rt_path=rt_path)
+    want = []
+    for a in atmospheres:
+        serial.set_atmosphere(*a)
+        want.append(serial.run().cpu().numpy().copy())
+    assert np.max(np.abs(want[1] / want[0] - 1)) > 1e-6
+    for depth in (2, 3):
+        pipe = eng.SpectrumPipeline(case, depth=depth, rt_path=rt_path, voigt=serial.voigt,
+                                    lines=serial.lines)
+        assert pipe.models[1].voigt is serial.voigt and pipe.models[1].lines is serial.lines
+        got = []
+        for rep in range(2):                       # the contexts are reused
+            pending = []
+            for i, a in enumerate(atmospheres):
+                out, event = pipe.submit(a)
+                pending.append((out, event))
+                if len(pending) == depth:          # consume before the context is reused
+                    o, e = pending.pop(0)
+                    e.synchronize()
+                    got.append(o.cpu().numpy().copy())
+            pipe.flush()
+            torch.cuda.current_stream().synchronize()
+            got.extend(o.cpu().numpy().copy() for o, _ in pending)
+        assert len(got) == 2 * len(atmospheres)
+        for i, g_ in enumerate(got):
+            assert np.array_equal(g_, want[i % len(atmospheres)]), (depth, i)

@@ -5,6 +5,8 @@ Patches pyratbay_amd/csrc/pb_extinction.hip + pb_ext_args.h IN PLACE (restore th
     bit 0  the kernel without its row DMA         (timing only, results are wrong)
     bit 1  the kernel without the walk            (timing only, results are wrong)
     bit 3  the walk stops after the hit search (find_hits)       (timing only)
+    bit 8  start and end time of every workgroup (wall_clock64, 100 MHz) written to
+           $PB_PROBE_TIMES (binary, grid x 2 uint64) after every launch: the tail of the launch
     bit 2  counters printed to stderr after every launch: segment steps, visits, the sum over
            the steps of the busiest wavefront's visits (what a barrier waits for), batches,
            records, and the shader clock the kernel ran at (clock64 against wall_clock64)
@@ -124,4 +126,56 @@ s = s.replace('fprintf(stderr, "probe: segsteps %llu', 'fprintf(stderr, "probe: 
 s = s.replace('hh[0], hh[1], hh[2], hh[3], hh[4], grid.x',
               'hh[6] ? 100.0 * (double)hh[5] / (double)hh[6] : 0.0, hh[0], hh[1], hh[2], hh[3], '
               'hh[4], grid.x', 1)
+
+# --- bit 8: workgroup start / end times ---
+old = """    if (layer < 0 || (a.res_cap > 0 && a.ls_resident[layer]))
+        return;
+    const int row = blockIdx.y;"""
+new = """#if PB_PROBE & 256
+    if (threadIdx.x == 0 && blockIdx.y == 0) {
+        a.probe[2 * blockIdx.x] = (unsigned long long)wall_clock64();
+        a.probe[2 * blockIdx.x + 1] = 0ull;
+    }
+#endif
+    if (layer < 0 || (a.res_cap > 0 && a.ls_resident[layer]))
+        return;
+    const int row = blockIdx.y;"""
+i = s.index('void k_ext_staged')
+assert s.count(old) >= 1
+j = s.index(old, i)
+s = s[:j] + new + s[j + len(old):]
+old3 = """    double *out = zsplit == 0
+                      ? a.ext
+                      : a.part + (int64_t)(zsplit - 1) * a.nlayers * a.nrows * a.wcount;"""
+j = s.index(old3, i)
+s = s[:j] + """#if PB_PROBE & 256
+    __syncthreads();
+    if (threadIdx.x == 0 && blockIdx.y == 0)
+        a.probe[2 * blockIdx.x + 1] = (unsigned long long)wall_clock64();
+#endif
+""" + s[j:]
+old = """        kern<<<grid, kStagedThreads, lds, s>>>(a);"""
+new = """#if PB_PROBE & 256
+        static unsigned long long *probe_t = nullptr;
+        static size_t probe_n = 0;
+        if (probe_n < 2 * (size_t)grid.x) {
+            if (probe_t) hipFree(probe_t);
+            probe_n = 2 * (size_t)grid.x;
+            hipMalloc(&probe_t, probe_n * 8);
+        }
+        hipMemsetAsync(probe_t, 0, probe_n * 8, s);
+        a.probe = probe_t;
+#endif
+        kern<<<grid, kStagedThreads, lds, s>>>(a);
+#if PB_PROBE & 256
+        if (const char *f = getenv("PB_PROBE_TIMES")) {
+            std::vector<unsigned long long> hh(2 * (size_t)grid.x);
+            hipMemcpyAsync(hh.data(), probe_t, hh.size() * 8, hipMemcpyDeviceToHost, s);
+            hipStreamSynchronize(s);
+            if (FILE *fp = fopen(f, "wb")) { fwrite(hh.data(), 8, hh.size(), fp); fclose(fp); }
+        }
+#endif"""
+k = s.index(old)   # first occurrence is already patched by the bit-2 code; patch that site
+assert s.count(old) == 1
+s = s.replace(old, new)
 open(p,'w').write(s)
