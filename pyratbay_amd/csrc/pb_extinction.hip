@@ -277,7 +277,11 @@ __device__ inline void decode_block(const LblArgs &a, int &tile, int &layer)
     const int xcd = id & 7;
     const int k = id >> 3;
     tile = k % a.ntiles;
-    const int rank = (k / a.ntiles) * 8 + xcd;
+    const int grp = k / a.ntiles;
+    // dealt to the XCDs in snake order (0..7, 7..0, ...): the cost of a layer falls with height,
+    // and workgroup i always runs on XCD i % 8 -- dealt 0..7 every time, XCD 0 gets the heaviest
+    // layer of every group of eight and finishes last (C3: 44.0 ms of work against 38.4 on XCD 6)
+    const int rank = grp * 8 + ((grp & 1) ? 7 - xcd : xcd);
     layer = a.nlayers - 1 - rank;      // < 0 for the padding blocks
 }
 
@@ -756,7 +760,8 @@ __global__ __launch_bounds__(NW * 64, 8) void k_ext_staged(LblArgs a)
         const int id = blockIdx.x;
         const int k = id >> 3;
         tile = k % a.ntiles;
-        const int unit = (k / a.ntiles) * 8 + (id & 7);
+        const int grp = k / a.ntiles;                  // snake order over the XCDs: decode_block
+        const int unit = grp * 8 + ((grp & 1) ? 7 - (id & 7) : (id & 7));
         layer = a.nlayers - 1 - unit / a.nsplit;       // < 0 for the padding blocks
         zsplit = unit % a.nsplit;
     }

@@ -88,7 +88,8 @@ __global__ __launch_bounds__(kRT) void k_rounds(LblArgs a)
         const int id = blockIdx.x;
         const int k = id >> 3;
         tile = k % a.ntiles;
-        const int unit = (k / a.ntiles) * 8 + (id & 7);
+        const int grp = k / a.ntiles;                  // snake order over the XCDs
+        const int unit = grp * 8 + ((grp & 1) ? 7 - (id & 7) : (id & 7));
         layer = a.nlayers - 1 - unit / a.nsplit;
         zsplit = unit % a.nsplit;
     }
@@ -356,7 +357,8 @@ __global__ __launch_bounds__(NW * 64, OCC) void k_ext_rounds(LblArgs a)
         const int id = blockIdx.x;
         const int k = id >> 3;
         tile = k % a.ntiles;
-        const int unit = (k / a.ntiles) * 8 + (id & 7);
+        const int grp = k / a.ntiles;                  // snake order over the XCDs
+        const int unit = grp * 8 + ((grp & 1) ? 7 - (id & 7) : (id & 7));
         layer = a.nlayers - 1 - unit / a.nsplit;       // < 0 for the padding blocks
         zsplit = unit % a.nsplit;
     }

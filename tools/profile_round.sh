@@ -10,7 +10,9 @@ mkdir -p gpurun_out
 python bench.py > gpurun_out/${tag}_bench_c2.json 2> gpurun_out/${tag}_bench_c2.err || exit 1
 echo "bench c2 done"
 rm -rf gpurun_out/prof_bench
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_bench -- python bench.py --no-cpu-baseline > gpurun_out/prof_bench.log 2>&1 || exit 1
+# one spectrum at a time (PB_STREAMS=1): the kernel durations then agree with roofline.kernel_ms,
+# which bench.py measures in its un-pipelined pass
+PB_STREAMS=1 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_bench -- python bench.py --no-cpu-baseline > gpurun_out/prof_bench.log 2>&1 || exit 1
 cp $(find gpurun_out/prof_bench -name '*kernel_stats.csv' | head -1) gpurun_out/${tag}_kernel_stats.csv
 echo "kernel stats done"
 python bench.py --workload c5 > gpurun_out/${tag}_bench_c5.json 2> gpurun_out/${tag}_bench_c5.err || exit 1
