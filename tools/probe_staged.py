@@ -7,6 +7,9 @@ Patches pyratbay_amd/csrc/pb_extinction.hip + pb_ext_args.h IN PLACE (restore th
     bit 3  the walk stops after the hit search (find_hits)       (timing only)
     bit 8  start and end time of every workgroup (wall_clock64, 100 MHz) written to
            $PB_PROBE_TIMES (binary, grid x 2 uint64) after every launch: the tail of the launch
+    bit 9  (with bit 8) per workgroup also the time spent in the candidate search, in the batch
+           set-up (record decode, segment detection) and in the segment steps: $PB_PROBE_TIMES
+           then holds grid x 6 uint64 (start, end, search, set-up, steps, batches)
     bit 2  counters printed to stderr after every launch: segment steps, visits, the sum over
            the steps of the busiest wavefront's visits (what a barrier waits for), batches,
            records, and the shader clock the kernel ran at (clock64 against wall_clock64)
@@ -178,4 +181,68 @@ new = """#if PB_PROBE & 256
 k = s.index(old)   # first occurrence is already patched by the bit-2 code; patch that site
 assert s.count(old) == 1
 s = s.replace(old, new)
+
+# --- bit 9: phase timers inside a workgroup (thread 0) ---
+s = s.replace("a.probe[2 * blockIdx.x]", "a.probe[PB_PROBE_W * blockIdx.x]")
+s = s.replace("a.probe[2 * blockIdx.x + 1]", "a.probe[PB_PROBE_W * blockIdx.x + 1]")
+s = s.replace("probe_n < 2 * (size_t)grid.x", "probe_n < PB_PROBE_W * (size_t)grid.x")
+s = s.replace("probe_n = 2 * (size_t)grid.x;", "probe_n = PB_PROBE_W * (size_t)grid.x;")
+s = s.replace("std::vector<unsigned long long> hh(2 * (size_t)grid.x);", "std::vector<unsigned long long> hh(PB_PROBE_W * (size_t)grid.x);")
+s = s.replace("#ifndef PB_PROBE\n#define PB_PROBE 0\n#endif\n", "#ifndef PB_PROBE\n#define PB_PROBE 0\n#endif\n#define PB_PROBE_W ((PB_PROBE & 512) ? 6 : 2)\n", 1)
+i = s.index('void k_ext_staged')
+old = """    for (int iso = 0; iso < a.niso; iso++) {
+        const int iext = a.isoiext[iso];
+        if (iext < 0 || (a.add ? 0 : iext) != row)
+            continue;"""
+j = s.index(old, i)
+s = s[:j] + """#if PB_PROBE & 512
+    __shared__ long long s_pt[6];           // search, set-up, steps, batches, mark
+    if (threadIdx.x == 0) { s_pt[0] = s_pt[1] = s_pt[2] = s_pt[3] = 0; s_pt[4] = wall_clock64(); }
+#endif
+""" + s[j:]
+old = """        for (int x0 = 0; x0 < total; x0 += kThreads) {
+            const int nrec = min(kThreads, total - x0);
+            __syncthreads();"""
+j = s.index(old, i)
+s = s[:j] + """#if PB_PROBE & 512
+        if (threadIdx.x == 0) { const long long now = wall_clock64(); s_pt[0] += now - s_pt[4]; s_pt[4] = now; }
+#endif
+""" + s[j:]
+old = """            if (nseg == 0)
+                continue;
+            // ---- rows are double-buffered"""
+j = s.index(old, i)
+s = s[:j] + """#if PB_PROBE & 512
+            if (threadIdx.x == 0) { const long long now = wall_clock64(); s_pt[1] += now - s_pt[4]; s_pt[4] = now; s_pt[3]++; }
+#endif
+""" + s[j:]
+# end of the batch body: after the kDma/else run block -> find the closing of the x0 loop
+old = """            } else if (nseg > 0) {
+                run(std::integral_constant<int, 2>(), std::integral_constant<int, kRowRegs>());
+            }
+        }
+    }
+"""
+j = s.index(old, i)
+new = """            } else if (nseg > 0) {
+                run(std::integral_constant<int, 2>(), std::integral_constant<int, kRowRegs>());
+            }
+#if PB_PROBE & 512
+            if (threadIdx.x == 0) { const long long now = wall_clock64(); s_pt[2] += now - s_pt[4]; s_pt[4] = now; }
+#endif
+        }
+#if PB_PROBE & 512
+        if (threadIdx.x == 0) { const long long now = wall_clock64(); s_pt[0] += now - s_pt[4]; s_pt[4] = now; }
+#endif
+    }
+#if PB_PROBE & 512
+    if (threadIdx.x == 0 && blockIdx.y == 0) {
+        a.probe[PB_PROBE_W * blockIdx.x + 2] = (unsigned long long)s_pt[0];
+        a.probe[PB_PROBE_W * blockIdx.x + 3] = (unsigned long long)s_pt[1];
+        a.probe[PB_PROBE_W * blockIdx.x + 4] = (unsigned long long)s_pt[2];
+        a.probe[PB_PROBE_W * blockIdx.x + 5] = (unsigned long long)s_pt[3];
+    }
+#endif
+"""
+s = s[:j] + new + s[j + len(old):]
 open(p,'w').write(s)
