@@ -547,3 +547,73 @@ def test_two_phase_shards_with_kmax_exchange(eng, monkeypatch, gather, ethresh):
             loose = plan()
             loose.set_ethresh(1e-30)
             assert not np.array_equal(host(loose.extinction(t, d, z, add=add)), full)
+
+
+@pytest.mark.parametrize('gather', ['staged', 'rounds', 'global'])
+@pytest.mark.parametrize('short_own', [False, True])
+@pytest.mark.parametrize('long_rows', [False, True])
+def test_windows_that_leave_the_grid(eng, orc, gather, short_own, long_rows):
+    """Every line within reach of the first or the last sample of the grid, so that nearly every
+    window is clipped by the reference (`minj = 0`, `maxj = dnwn`, _extcoeff.c:286-289).  The
+    packed records of the staged gathers keep such windows unclipped (their consumers clamp to
+    the tile; clipped, every group was a segment of its own and the edge tiles of a layer ran
+    twice as long as the others) -- the sums and the zero pattern must not notice.
+    short_own: the oversampled grid `own` stops 60 samples before `wn` does, so that
+    ceil(dnwn / scale) < nwave and the upper clip is NOT redundant (it must then stay).
+    long_rows: rows of several LDS chunks (the per-(group, chunk) record format)."""
+    from pyratbay_amd import synth
+    if long_rows:
+        kw = dict(wnosamp=12, nlor=10, ndop=5, extent=4000.0, cutoff=80.0, niso=2)
+        nwave, nlines, nl = 4097, 1500, 3
+    else:
+        kw = dict(wnosamp=24, nlor=18, ndop=9, extent=80.0, cutoff=3.0, niso=2)
+        nwave, nlines, nl = 5001, 6000, 4
+    case = synth.lbl_case(nwave, nl, nlines, seed=77, **kw)
+    g, atm, ln, iso, vg = (case[k] for k in ('grid', 'atm', 'lines', 'iso', 'voigt'))
+    osamp = g['wnosamp']
+    own = g['own'][:len(g['own']) - 60 * osamp] if short_own else g['own']
+    # move the lines to within a few window half-widths of either end of `own` (isotope blocks
+    # stay sorted by wavenumber)
+    rng = np.random.default_rng(5)
+    span = own[-1] - own[0]
+    reach = min(0.02 * span, (vg['cutoff'] if vg['cutoff'] > 0 else 1.0) * 1.5)
+    lwn = ln['lwn'].copy()
+    lo = rng.random(len(lwn)) < 0.5
+    lwn[lo] = own[0] + rng.random(lo.sum()) * reach
+    lwn[~lo] = own[-1] - rng.random((~lo).sum()) * reach
+    lid = ln['lid']
+    order = np.lexsort((lwn, lid))
+    lwn, lid = lwn[order], lid[order]
+    elow, gf = ln['elow'][order], ln['gf'][order]
+    vt = eng.VoigtTable.build(vg['lorentz'], vg['doppler'], vg['size'], g['ownstep'], osamp)
+    ll = eng.LineList(lwn, elow, gf, lid, len(iso['isomass']), own)
+    lbl = eng.LBL(vt, ll, g['wn'], g['divisors'], atm['mol_radius'], atm['mol_mass'],
+                  iso['isoimol'], iso['isomass'], iso['isoratio'], iso['isoiext'],
+                  vg['cutoff'], 1e-30, max_layers=nl)
+    lbl.set_gather_mode(gather)
+    t, d, z = eng.dev(atm['temp']), eng.dev(atm['dens']), eng.dev(iso['isoz'])
+    ext = host(lbl.extinction(t, d, z, add=True))
+    profile = vt.flat()
+    worst, touched = 0.0, 0
+    for layer in range(nl):
+        want = np.zeros((1, g['nwave']))
+        orc.extinction(want, profile, vt.size, vt.index, vg['lorentz'], vg['doppler'],
+                       g['wn'], own, g['divisors'], atm['dens'][layer],
+                       atm['mol_radius'], atm['mol_mass'], iso['isoimol'], iso['isomass'],
+                       iso['isoratio'], iso['isoz'][:, layer].copy(), iso['isoiext'],
+                       lwn, elow, gf, lid, vg['cutoff'], 1e-30, atm['temp'][layer], 0, 1, 0)
+        got = ext[layer]
+        assert np.array_equal(got == 0, want == 0), (layer, 'zero pattern')
+        nz = want != 0
+        touched += int(nz.sum())
+        worst = max(worst, np.max(np.abs(got[nz] / want[nz] - 1)))
+        np.testing.assert_allclose(got, want, rtol=RTOL)
+        assert want[0, 0] != 0 and (short_own or want[0, -1] != 0)     # the edges are reached
+        if short_own:
+            assert np.all(want[0, -59:] == 0)      # nothing beyond the oversampled grid
+    # shards cut inside the edge tiles concatenate exactly
+    parts = [host(lbl.extinction(t, d, z, wbegin=a, wcount=b - a))
+             for a, b in ((0, 37), (37, nwave - 45), (nwave - 45, nwave))]
+    assert np.array_equal(np.concatenate(parts, axis=2), ext)
+    print(f'edge windows {gather} short_own={short_own} long_rows={long_rows}: {touched} samples, '
+          f'max rel err vs oracle = {worst:.2e}')
