@@ -795,7 +795,8 @@ class SpectrumPipeline:
         j = self.count % len(self.models)
         self.count += 1
         model, stream = self.models[j], self.streams[j]
-        stream.wait_stream(torch.cuda.current_stream())     # inputs made on the caller's stream
+        caller = torch.cuda.current_stream()
+        stream.wait_stream(caller)                          # inputs made on the caller's stream
         with torch.cuda.stream(stream):
             if isinstance(atmosphere, dict):
                 model.set_atmosphere(**atmosphere)
@@ -804,6 +805,9 @@ class SpectrumPipeline:
             out = model.run()
             event = torch.cuda.Event()
             event.record(stream)
+        # the result was allocated on the side stream and will be read on the caller's: keep the
+        # caching allocator from handing its memory out again before the caller's reads are done
+        out.record_stream(caller)
         self.done[j] = event
         return out, event
 
