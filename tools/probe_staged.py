@@ -10,6 +10,8 @@ Patches pyratbay_amd/csrc/pb_extinction.hip + pb_ext_args.h IN PLACE (restore th
     bit 9  (with bit 8) per workgroup also the time spent in the candidate search, in the batch
            set-up (record decode, segment detection) and in the segment steps: $PB_PROBE_TIMES
            then holds grid x 6 uint64 (start, end, search, set-up, steps, batches)
+    bit 10 the batch set-up (record decode, segment detection) runs TWICE per batch (idempotent,
+           results stay valid): the time it adds is what the set-up costs in throughput
     bit 2  counters printed to stderr after every launch: segment steps, visits, the sum over
            the steps of the busiest wavefront's visits (what a barrier waits for), batches,
            records, and the shader clock the kernel ran at (clock64 against wall_clock64)
@@ -21,6 +23,38 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 p = os.path.join(ROOT, 'pyratbay_amd/csrc/pb_extinction.hip')
 s=open(p).read()
+
+# --- bit 10: batch set-up twice ---
+old = """            __syncthreads();
+            // ---- one record per lane, in (phase, iown) order, from k_records ----
+            long long src = -1;"""
+new = """            __syncthreads();
+            int nseg = 0;
+            for (int rep = 0; rep < ((PB_PROBE & 1024) ? 2 : 1); rep++) {
+            if (rep)
+                __syncthreads();
+            // ---- one record per lane, in (phase, iown) order, from k_records ----
+            long long src = -1;"""
+assert s.count(old) == 1
+s = s.replace(old, new)
+old = """            int nseg = 0;
+            {
+                int before = 0;"""
+new = """            nseg = 0;
+            {
+                int before = 0;"""
+assert s.count(old) == 1
+s = s.replace(old, new)
+old = """            __syncthreads();
+            if (nseg == 0)
+                continue;"""
+new = """            __syncthreads();
+            }
+            if (nseg == 0)
+                continue;"""
+assert s.count(old) == 1
+s = s.replace(old, new)
+
 h = os.path.join(ROOT, 'pyratbay_amd/csrc/pb_ext_args.h')
 t=open(h).read()
 t=t.replace("    int experiment;","    unsigned long long *probe;\n    int experiment;",1)
@@ -245,4 +279,5 @@ new = """            } else if (nseg > 0) {
 #endif
 """
 s = s[:j] + new + s[j + len(old):]
+
 open(p,'w').write(s)
