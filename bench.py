@@ -406,8 +406,8 @@ def main():
             # flight on as many HIP streams (engine.SpectrumPipeline; PB_STREAMS=1: one at a
             # time).  The second one fills the tail of the first one's gather launch.
             # Only where a launch has a tail worth filling: at 1e6 samples a spectrum is tens of
-            # milliseconds of full-chip launches (C3: +2 %) and a second context doubles the
-            # record buffers (C4: 77 GB each -- measured 3x SLOWER), so those run one at a time.
+            # milliseconds of full-chip launches and a second one in flight gains nothing
+            # (C3: 47.5 against 45.6 ms, C4: 254 against 250.5), so those run one at a time.
             streams = 2 if nwave <= 200000 else 1
             streams = int(os.environ.get('PB_STREAMS', streams)) if world == 1 else 1
             if streams > 1:

@@ -498,6 +498,7 @@ __global__ __launch_bounds__(NW * 64) void k_ext_resample(LblArgs a)
 // the global grid -- is computed ONCE here (coalesced, no workgroup synchronisation) and
 // streamed by the gather kernel; the per-row maximum strength (k_kmax) is fused in.
 // ---------------------------------------------------------------------------
+constexpr int kLongLenBits = 14;   // window length in a long-row record (rows of up to 16 x 1024 samples)
 constexpr int kChunkRow = 1024;      // samples per chunk of a long phase row (= kStageRowMax)
 constexpr int kRecLayers = 4;        // layers per thread of k_records (group data loaded once);
                                      // 1 for launches of few layers (multi-GPU ranks)
@@ -647,23 +648,15 @@ __global__ __launch_bounds__(kBlock) void k_records(LblArgs a)
                     r.pad[0] = r.pad[1] = 0;
                     a.rec32[idx] = r;
                 } else if constexpr (kFmt == 2 && !kPos) {
-                    // one record per chunk of the phase row: the part of the window whose row
-                    // coordinates u = sample + q fall into [c0, c0 + kStageRowMax)
-                    const int64_t ps = a.ph_start[(int64_t)iso * (a.osamp + 1) + iown % a.osamp];
-                    const int64_t pe = a.ph_start[(int64_t)iso * (a.osamp + 1) + iown % a.osamp + 1];
-                    const int64_t li = (int64_t)layer * a.niso + iso;
-                    const int nch = (min(a.rowcap, a.li_rowmax[li]) + kChunkRow - 1) / kChunkRow;
-                    const int64_t lbase = (int64_t)layer * a.ngroups * a.nch_max;
-                    const int mlo = ulo + q, mhi = uhi + q;
-                    for (int c = 0; c < nch; c++) {
-                        const int c0 = c * kChunkRow;
-                        const int wlo = max(mlo, c0), whi = min(mhi, c0 + kChunkRow);
-                        Rec16 r;
-                        r.k = k;
-                        r.ulo = whi > wlo ? wlo - q : ulo;
-                        r.lc = (uint32_t)max(whi - wlo, 0) | ((uint32_t)cell << 12);
-                        a.rec16[lbase + ps * a.nch_max + (int64_t)c * (pe - ps) + (g - ps)] = r;
-                    }
+                    // long rows (staged in chunks of kChunkRow samples): ONE record per group with
+                    // its whole window (14-bit length); the gather clips it to the chunk it
+                    // stages.  (Round 2 wrote one record per (group, chunk): 12.8 GB per C3
+                    // spectrum, 77 GB per C4 spectrum, written here and streamed back by the gather.)
+                    Rec16 r;
+                    r.k = k;
+                    r.ulo = ulo;
+                    r.lc = (uint32_t)(uhi - ulo) | ((uint32_t)cell << kLongLenBits);
+                    a.rec16[idx] = r;
                 } else if constexpr (kFmt == 1 && !kPos) {
                     Rec16 r;
                     r.k = k;
@@ -939,13 +932,7 @@ __global__ __launch_bounds__(NW * 64, 8) void k_ext_staged(LblArgs a)
                 const int b1 = (int)min((int64_t)a.ph_nbins - 1, max((int64_t)0, chi + 1) / binw);
                 const int64_t s0 = lower_bound_i32(a.ph_iown, bin[b0], bin[b0 + 1], clo);
                 const int64_t s1 = lower_bound_i32(a.ph_iown, bin[b1], bin[b1 + 1], chi + 1);
-                int64_t first = s0;                // entry of the layer's record array
-                if (a.nch_max > 1) {
-                    const int64_t ps = a.ph_start[(int64_t)iso * (osamp + 1) + p];
-                    const int64_t pe = a.ph_start[(int64_t)iso * (osamp + 1) + p + 1];
-                    first = ps * a.nch_max + (int64_t)c * (pe - ps) + (s0 - ps);
-                }
-                s_phs[pv] = (int)first;
+                s_phs[pv] = (int)s0;               // entry of the layer's record array
                 s_cum[pv] = (int)(s1 - s0);
                 mine += (int)(s1 - s0);
             }
@@ -1001,26 +988,33 @@ __global__ __launch_bounds__(NW * 64, 8) void k_ext_staged(LblArgs a)
                             pup = mid;
                     }
                     const int64_t entry = s_phs[plo] + (x - s_cum[plo]);
-                    int64_t gidx = entry;               // index in the phase-sorted group list
+                    const int64_t gidx = entry;         // index in the phase-sorted group list
                     int c0 = 0;                         // first row sample of my chunk
-                    if (a.nch_max > 1) {
-                        const int p = plo / nch, c = plo - p * nch;
-                        const int64_t ps = a.ph_start[(int64_t)iso * (osamp + 1) + p];
-                        const int64_t pe = a.ph_start[(int64_t)iso * (osamp + 1) + p + 1];
-                        gidx = entry - ps * (a.nch_max - 1) - (int64_t)c * (pe - ps);
-                        c0 = c * kChunkRow;
-                    }
-                    const int64_t idx = recbase * a.nch_max + entry;
+                    if (a.nch_max > 1)
+                        c0 = (plo % nch) * kChunkRow;
+                    const int64_t idx = recbase + entry;
                     int ulo, uhi, q, cell, phi;
                     if (a.rec16) {
                         const Rec16 r = a.rec16[idx];
                         k = r.k;
                         ulo = r.ulo;
-                        uhi = ulo + (int)(r.lc & 0xfffu);
-                        cell = (int)(r.lc >> 12);
+                        const int lbits = a.nch_max > 1 ? kLongLenBits : 12;
+                        uhi = ulo + (int)(r.lc & ((1u << lbits) - 1u));
+                        cell = (int)(r.lc >> lbits);
                         const int d = s_csize[cell - cell0] - a.ph_iown[gidx];   // half - iown
                         q = floor_div_inv(d, a.inv_osamp);
                         phi = d - q * osamp;
+                        if (a.nch_max > 1) {
+                            // the part of the window whose row coordinates u = sample + q fall
+                            // into my chunk [c0, c0 + kChunkRow)
+                            const int wlo = max(ulo + q, c0), whi = min(uhi + q, c0 + kChunkRow);
+                            if (whi > wlo) {
+                                ulo = wlo - q;
+                                uhi = whi - q;
+                            } else {
+                                uhi = ulo;
+                            }
+                        }
                         q -= c0;                        // row index relative to the chunk
                     } else {
                         k = a.rec_k[idx];
@@ -1261,32 +1255,41 @@ __global__ __launch_bounds__(NW * 64, 8) void k_ext_staged(LblArgs a)
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(kBlock) void k_work_stats(LblArgs a, unsigned long long *out)
 {
-    // long rows: one record per (group, chunk of the row), empty ones have length 0; the groups'
-    // entries are not in group order there, so only the one-row (add) form is counted
-    const int64_t per_layer = (int64_t)a.ngroups * a.nch_max;
+    const int64_t per_layer = (int64_t)a.ngroups;
     const int64_t n = (int64_t)a.nlayers * per_layer;
+    const int lbits = a.nch_max > 1 ? kLongLenBits : 12;
     unsigned long long useful = 0, issued = 0, live = 0;
     for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n;
          i += (int64_t)gridDim.x * kBlock) {
         const int layer = (int)(i / per_layer);
-        int row = 0;
-        if (a.nch_max == 1) {
-            const int64_t g = i - (int64_t)layer * a.ngroups;
-            const int iext = a.isoiext[a.ph_iso[g]];
-            if (iext < 0)
-                continue;
-            row = a.add ? 0 : iext;
-        }
+        const int64_t g = i - (int64_t)layer * a.ngroups;
+        const int iext = a.isoiext[a.ph_iso[g]];
+        if (iext < 0)
+            continue;
+        const int row = a.add ? 0 : iext;
         const double kthresh =
             a.ethresh * __longlong_as_double((long long)a.kmax_bits[(int64_t)layer * a.nrows + row]);
         const Rec16 r = a.rec16[i];
-        const int64_t lo = max((int64_t)r.ulo, a.wbegin) - a.wbegin;
-        const int64_t hi = min((int64_t)r.ulo + (int64_t)(r.lc & 0xfffu), a.wbegin + a.wcount) -
-                           a.wbegin;
+        const int64_t ulo = r.ulo, uhi = ulo + (int64_t)(r.lc & ((1u << lbits) - 1u));
+        const int64_t lo = max(ulo, a.wbegin) - a.wbegin;
+        const int64_t hi = min(uhi, a.wbegin + a.wcount) - a.wbegin;
         if (r.k < kthresh || hi <= lo)
             continue;
         useful += (unsigned long long)(hi - lo);
-        issued += (unsigned long long)(((hi - 1) / kStageSpan - lo / kStageSpan + 1) * kStageSpan);
+        if (a.nch_max == 1) {
+            issued += (unsigned long long)(((hi - 1) / kStageSpan - lo / kStageSpan + 1) * kStageSpan);
+        } else {
+            // a long row is visited chunk by chunk: the spans every chunk's part of the window touches
+            const int cell = (int)(r.lc >> lbits);
+            const int q = floor_div_inv(a.psize[cell] - a.ph_iown[g], a.inv_osamp);
+            for (int64_t c0 = 0; c0 < a.rowcap; c0 += kChunkRow) {
+                const int64_t clo = max(max(ulo + q, c0) - q, a.wbegin) - a.wbegin;
+                const int64_t chi = min(min(uhi + q, c0 + kChunkRow) - q, a.wbegin + a.wcount) - a.wbegin;
+                if (chi > clo)
+                    issued += (unsigned long long)(((chi - 1) / kStageSpan - clo / kStageSpan + 1) *
+                                                   kStageSpan);
+            }
+        }
         live++;
     }
     for (int d = 32; d >= 1; d >>= 1) {
@@ -2578,7 +2581,7 @@ static int lbl_extinction(pb_lbl *p, double *ext_d, int64_t wbegin, int64_t wcou
     constexpr int kStagedWaves = 8;
     constexpr int kStagedThreads = kStagedWaves * 64;
     // rows longer than kStageRowMax samples are staged in chunks: (phase, chunk) pairs act as
-    // phases and k_records writes one packed record per (group, chunk)
+    // phases; k_records writes one packed record per group, clipped to the chunk by the gather
     const int nch_max = (int)pb::div_up((int64_t)a.rowcap, (int64_t)kChunkRow);
     a.nch_max = std::max(1, nch_max);
     a.rowlds = (std::min(a.rowcap, kStageRowMax) + 1) & ~1;     // even: 16-byte aligned buffers
@@ -2590,9 +2593,12 @@ static int lbl_extinction(pb_lbl *p, double *ext_d, int64_t wbegin, int64_t wcou
         dma = atoi(e) != 0;
     const size_t lds = (2 * ((size_t)a.rowlds + kStagePad) + kStagePad) * 8 + lds_fixed;
     const double per_phase = (double)l->ngroups / std::max(1, p->nwave) * 2048.0 / v->osamp;
-    const bool packable = v->nlor * v->ndop < (1 << 20);
+    // table cell and window length share 32 bits of a packed record: 20 + 12, for long rows
+    // 18 + kLongLenBits (windows of up to 16 383 samples)
+    const bool packable = v->nlor * v->ndop < (a.nch_max > 1 ? (1 << (32 - kLongLenBits)) : (1 << 20)) &&
+                          a.rowcap < (1 << kLongLenBits);
     // sized for the layers of this call (a layer shard of a multi-GPU run holds few of them)
-    const size_t rec16_bytes = (size_t)nlayers * (size_t)l->ngroups * a.nch_max * sizeof(Rec16);
+    const size_t rec16_bytes = (size_t)nlayers * (size_t)l->ngroups * sizeof(Rec16);
     const bool can_stage = !p->resolution && lds <= 160 * 1024 && l->ngroups > 0 &&
                            (a.nch_max == 1 ||
                             (a.nch_max <= 16 && packable && rec16_bytes <= ((size_t)96 << 30) &&
