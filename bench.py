@@ -400,7 +400,11 @@ def main():
             step = sharded.step
             pipelined = os.environ.get('PB_PIPELINE', '1') != '0'
         else:
-            gather = SpectrumGather(nwave, world, rank, 'cuda')
+            # 'replicas' (N > 1, reported beside the sharded forms, never `value`): every rank
+            # computes whole, independent spectra -- what a caller after spectra/s rather than
+            # after the latency of one spectrum would do with N GPUs; no data-path collective
+            replicas = kind == 'replicas'
+            gather = SpectrumGather(nwave, 1 if replicas else world, 0 if replicas else rank, 'cuda')
             # one GPU: consecutive spectra are independent (the temperature loop of
             # compute_opacity, the walkers of a retrieval), so `streams` of them are kept in
             # flight on as many HIP streams (engine.SpectrumPipeline; PB_STREAMS=1: one at a
@@ -409,7 +413,7 @@ def main():
             # milliseconds of full-chip launches and a second one in flight gains nothing
             # (C3: 47.5 against 45.6 ms, C4: 254 against 250.5), so those run one at a time.
             streams = 2 if nwave <= 200000 else 1
-            streams = int(os.environ.get('PB_STREAMS', streams)) if world == 1 else 1
+            streams = int(os.environ.get('PB_STREAMS', streams)) if world == 1 or replicas else 1
             if streams > 1:
                 pipe = engine.SpectrumPipeline(case, depth=streams, rt_path=rt_path,
                                                voigt=shared.get('voigt'),
@@ -420,7 +424,7 @@ def main():
                 model = engine.LBLSpectrum(case, rt_path=rt_path, wbegin=gather.wbegin,
                                            wcount=gather.wcount, voigt=shared.get('voigt'),
                                            lines=shared.get('lines'))
-            if world > 1 and os.environ.get('PB_KMAX_EXCHANGE', '1') != '0':
+            if world > 1 and not replicas and os.environ.get('PB_KMAX_EXCHANGE', '1') != '0':
                 from pyratbay_amd.dist import kmax_allreduce
                 model.kmax_exchange = kmax_allreduce()     # records of the shard's groups only
             res.update(wcount=gather.wcount, nlayers_rank=nlayers)
@@ -455,8 +459,10 @@ def main():
         elapsed, gather_ms, launches = timed_steps(
             run_steps, args.steps, args.warmup, model.lbl, world, dist, torch.cuda.synchronize,
             dev_reduce)
+        # (replicas: every rank completed `steps` spectra of its own in that time)
         res.update(model=model, elapsed=elapsed, gather_ms=gather_ms, launches=launches,
-                   value=args.steps / elapsed, ms_per_step=1e3 * elapsed / args.steps,
+                   value=args.steps / elapsed * (world if kind == 'replicas' else 1),
+                   ms_per_step=1e3 * elapsed / args.steps,
                    pipelined=pipelined, run_steps=run_steps)
         # the un-pipelined per-spectrum latency (one spectrum complete before the next starts)
         # beside the pipelined throughput, so that the one is not mistaken for the other
@@ -481,7 +487,7 @@ def main():
         order = ['wavenumber']
     else:
         other = 'layers' if args.shard == 'wavenumber' else 'wavenumber'
-        order = [args.shard, other]
+        order = [args.shard, other, 'replicas']
     runs, failed = [], []
     for k in order:
         # a decomposition that fails (a collective the backend rejects, ...) must not take the
@@ -508,8 +514,12 @@ def main():
     # the RCCL all-gather north_star names; they differ in how the extinction is cut); the other
     # one is listed beside it in config.decompositions.  PB_BENCH_PRIMARY=first: the --shard one.
     primary = runs[0]
-    if len(runs) > 1 and os.environ.get('PB_BENCH_PRIMARY') != 'first':
-        primary = max(runs, key=lambda r_: r_['value'])
+    sharded = [r_ for r_ in runs if r_['kind'] != 'replicas']
+    if not sharded:
+        raise SystemExit(f'every sharded decomposition failed: {failed}')
+    primary = sharded[0]
+    if len(sharded) > 1 and os.environ.get('PB_BENCH_PRIMARY') != 'first':
+        primary = max(sharded, key=lambda r_: r_['value'])
     model, elapsed = primary['model'], primary['elapsed']
     gather_ms, launches = primary['gather_ms'], primary['launches']
     wcount, nlayers_rank = primary['wcount'], primary['nlayers_rank']
