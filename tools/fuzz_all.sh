@@ -4,7 +4,7 @@
 # scale 1 is ~6 minutes on one MI355X box.
 s=${1:-1}
 run() { echo "== $*"; timeout -k 10 1000 python "$@" 2>&1 | grep -v amdgpu.ids | tail -2; echo "exit ${PIPESTATUS[0]}"; }
-run tools/fuzz_sweep.py 20000 $((2500 * s))
+run tools/fuzz_sweep.py ${FUZZ_SEED0:-20000} $((2500 * s))
 run tools/fuzz_ext.py $((4000 * s))
 run tools/fuzz_more.py $((4000 * s))
 run tools/fuzz_pipeline.py $((1200 * s)) 7000
