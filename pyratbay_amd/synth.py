@@ -103,6 +103,11 @@ def synthetic_lines(nlines, wnlow, wnhigh, niso=1, seed=42,
     # most lines belong to the main isotopologue, but give the minor ones enough
     counts = np.maximum((nlines * np.maximum(frac, 0.05 if niso > 1 else 1.0)
                          / np.sum(np.maximum(frac, 0.05 if niso > 1 else 1.0))).astype(int), 1)
+    if counts.sum() > nlines:
+        # fewer lines than isotopes (or nearly): one line each for as many isotopes as there are lines
+        counts = (np.arange(niso) < nlines).astype(int) if nlines < niso else counts
+        while counts.sum() > nlines:
+            counts[np.argmax(counts)] -= 1
     counts[0] += nlines - counts.sum()
     lwn, lid = [], []
     for i, c in enumerate(counts):
