@@ -75,6 +75,15 @@ struct LblArgs {
     // reach), and whether groups outside it are left out of the per-row maxima too
     int64_t rec_flo, rec_fhi;
     int kmax_local;
+    // two-phase shard calls (kmax_local): the groups within [rec_flo, rec_fhi] are runs of the
+    // group order k_records walks (one per (isotope, phase) in phase order, one per isotope in
+    // position order); thread t of the launch takes group wm_lo[r] + t - wm_off[r] of the run r
+    // that holds t, and the launch has wm_total threads per layer block instead of ngroups.
+    // Index 0: the order of the phase-walking pass, 1: position order.  Null: every group.
+    const int32_t *wm_lo[2];
+    const int32_t *wm_off[2];
+    int wm_n[2];
+    int64_t wm_total[2];
     // resident-profile kernel: which layers it computes, its LDS capacity (doubles, 0 = off)
     // and, per isotope, the first position-sorted group at or after every output sample
     int32_t *ls_resident;
@@ -158,6 +167,35 @@ __device__ inline int64_t lower_bound_i32(const int32_t *a, int64_t lo, int64_t 
             hi = mid;
     }
     return lo;
+}
+
+// two lower bounds in lock step: the loads of the two bisections are independent, so every trip
+// has both in flight (the candidate search of the staged gather is a chain of dependent global
+// loads: its two bounds one after the other were 21 % of a rank-size launch's slot-time)
+__device__ inline void lower_bound2_i32(const int32_t *a, int64_t lo0, int64_t hi0, int64_t v0,
+                                        int64_t lo1, int64_t hi1, int64_t v1, int64_t &r0,
+                                        int64_t &r1)
+{
+    while (lo0 < hi0 || lo1 < hi1) {
+        const bool go0 = lo0 < hi0, go1 = lo1 < hi1;
+        const int64_t mid0 = go0 ? (lo0 + hi0) >> 1 : lo0 - (lo0 > 0);
+        const int64_t mid1 = go1 ? (lo1 + hi1) >> 1 : mid0;
+        const int32_t x0 = a[mid0], x1 = a[mid1];
+        if (go0) {
+            if (x0 < v0)
+                lo0 = mid0 + 1;
+            else
+                hi0 = mid0;
+        }
+        if (go1) {
+            if (x1 < v1)
+                lo1 = mid1 + 1;
+            else
+                hi1 = mid1;
+        }
+    }
+    r0 = lo0;
+    r1 = lo1;
 }
 
 // floor(a / d) for |a| < 2^31 and 0 < d < 2^20, with inv = 1.0/d: (a + 0.5)/d is never an

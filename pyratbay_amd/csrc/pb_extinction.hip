@@ -525,7 +525,7 @@ __global__ __launch_bounds__(kBlock) void k_records(LblArgs a)
     extern __shared__ unsigned long long s_max[];                 // [kRecLayers][nrows]
     double *s_dop = reinterpret_cast<double *>(s_max + kRecLayers * a.nrows);   // [ndop]
     const int layer0 = blockIdx.y * kRecLayers;
-    const int64_t g = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     for (int r = threadIdx.x; r < kRecLayers * a.nrows; r += kBlock)
         s_max[r] = 0ull;
     for (int d = threadIdx.x; d < a.ndop; d += kBlock)
@@ -550,6 +550,10 @@ __global__ __launch_bounds__(kBlock) void k_records(LblArgs a)
         s_ratio[e] = a.isoratio[e];
         s_iext[e] = a.isoiext[e];
     }
+    int32_t *s_wm = reinterpret_cast<int32_t *>(s_iext + a.niso);  // [wm_n[0] + 1] run offsets
+    if (a.wm_off[0])
+        for (int e = threadIdx.x; e <= a.wm_n[0]; e += kBlock)
+            s_wm[e] = a.wm_off[0][e];
     __syncthreads();
     auto pass = [&](auto posc) {
         constexpr bool kPos = decltype(posc)::value;
@@ -559,6 +563,25 @@ __global__ __launch_bounds__(kBlock) void k_records(LblArgs a)
         // A wavenumber shard needs the records of the groups within reach of it only
         // [rec_flo, rec_fhi]; the others still count for the per-row maximum unless the caller
         // all-reduces the maxima of the shards (kmax_local: they are skipped altogether).
+        int64_t g = t;
+        if (a.wm_off[kPos ? 1 : 0]) {
+            // run of the window map that holds thread t (the offsets of the phase-order map are
+            // in LDS; the position-order map has one run per isotope)
+            const int m = kPos ? 1 : 0;
+            g = a.ngroups;
+            if (t < a.wm_total[m]) {
+                const int32_t *off = kPos ? a.wm_off[1] : s_wm;
+                int lo = 0, hi = a.wm_n[m];                    // last run with off[run] <= t
+                while (hi - lo > 1) {
+                    const int mid = (lo + hi) >> 1;
+                    if (off[mid] <= t)
+                        lo = mid;
+                    else
+                        hi = mid;
+                }
+                g = (int64_t)a.wm_lo[m][lo] + (t - off[lo]);
+            }
+        }
         bool have = g < a.ngroups, inwin = false;
         if (have) {
             iown = (kPos ? a.giown : a.rk_iown)[g];
@@ -930,8 +953,9 @@ __global__ __launch_bounds__(NW * 64, 8) void k_ext_staged(LblArgs a)
                 }
                 const int b0 = (int)min((int64_t)a.ph_nbins - 1, max((int64_t)0, clo) / binw);
                 const int b1 = (int)min((int64_t)a.ph_nbins - 1, max((int64_t)0, chi + 1) / binw);
-                const int64_t s0 = lower_bound_i32(a.ph_iown, bin[b0], bin[b0 + 1], clo);
-                const int64_t s1 = lower_bound_i32(a.ph_iown, bin[b1], bin[b1 + 1], chi + 1);
+                const int32_t l0 = bin[b0], h0 = bin[b0 + 1], l1 = bin[b1], h1 = bin[b1 + 1];
+                int64_t s0, s1;
+                lower_bound2_i32(a.ph_iown, l0, h0, clo, l1, h1, chi + 1, s0, s1);
                 s_phs[pv] = (int)s0;               // entry of the layer's record array
                 s_cum[pv] = (int)(s1 - s0);
                 mine += (int)(s1 - s0);
@@ -1958,6 +1982,16 @@ struct pb_lbl {
     size_t rec16_alloc = 0;
     double *part = nullptr;           // partial sums of a phase-split staged launch
     size_t part_bytes = 0;
+    // window map of two-phase shard calls (LblArgs::wm_*): host copies of the phase-sorted group
+    // positions, the cached map and the window / order it was built for
+    std::vector<int32_t> h_ph_iown;
+    std::vector<int64_t> h_ph_start;
+    std::vector<int32_t> h_wm;
+    int32_t *d_wm = nullptr;
+    size_t wm_cap = 0;
+    int64_t wm_flo = 0, wm_fhi = -1;
+    int wm_staged = -1, wm_n0 = 0, wm_n1 = 0;
+    int64_t wm_total0 = 0, wm_total1 = 0;
     int32_t *gs_start = nullptr;      // [niso][nwave+1]
     int res_cap = 0;                  // LDS doubles of one resident profile block (0 = none fits)
     int gather_mode = 0;     // 0 = choose, 1 = global gather, 2 = LDS-staged, 3 = resident+global
@@ -2310,6 +2344,8 @@ int pb_lbl_create(pb_lbl **out, pb_voigt *voigt, pb_lines *lines, const double *
         if (rc == PB_OK) rc = upload(&p->ph_count, c.data(), ng);
         if (rc == PB_OK) rc = upload(&p->ph_iown, w.data(), ng);
         if (rc == PB_OK) rc = upload(&p->ph_start, start.data(), start.size());
+        p->h_ph_iown = w;
+        p->h_ph_start = start;
         {
             // position index of every (isotope, phase) run, one entry per kBinSamples samples
             const int nbins = (int)pb::div_up((int64_t)nwave, (int64_t)kBinSamples) + 1;
@@ -2684,6 +2720,9 @@ static int lbl_extinction(pb_lbl *p, double *ext_d, int64_t wbegin, int64_t wcou
     }
     a.nsplit = 1;
     a.part = nullptr;
+    a.wm_lo[0] = a.wm_lo[1] = a.wm_off[0] = a.wm_off[1] = nullptr;
+    a.wm_n[0] = a.wm_n[1] = 0;
+    a.wm_total[0] = a.wm_total[1] = 0;
     if (scatter) {
         if (!p->rec32) {
             const size_t n = (size_t)p->max_layers * (size_t)l->ngroups;
@@ -2742,9 +2781,69 @@ static int lbl_extinction(pb_lbl *p, double *ext_d, int64_t wbegin, int64_t wcou
         // (one layer per thread for launches of few layers measured slower: 10 layers of C2
         // 49 us against 27 us with four; PB_REC_LAYERS=1 selects it)
         const int per = getenv("PB_REC_LAYERS") && atoi(getenv("PB_REC_LAYERS")) == 1 ? 1 : kRecLayers;
-        dim3 grid(pb::div_up(l->ngroups, kBlock), pb::div_up(nlayers, per));
+        int64_t rec_threads = l->ngroups;
+        if (a.kmax_local && a.rec_flo != INT64_MIN && !p->h_ph_iown.empty() &&
+            !getenv("PB_NO_WINDOW_MAP")) {
+            // two-phase shard call: only the groups within reach of the shard get a thread
+            const int osamp = v->osamp, niso = a.niso;
+            if (p->wm_flo != a.rec_flo || p->wm_fhi != a.rec_fhi || p->wm_staged != (int)staged) {
+                const int n0 = staged ? niso * osamp : niso, n1 = niso;
+                std::vector<int32_t> &h = p->h_wm;
+                h.assign((size_t)2 * n0 + 1 + 2 * n1 + 1, 0);
+                int32_t *lo0 = h.data(), *off0 = lo0 + n0, *lo1 = off0 + n0 + 1, *off1 = lo1 + n1;
+                const int64_t flo = std::max<int64_t>(a.rec_flo, INT32_MIN);
+                const int64_t fhi = std::min<int64_t>(a.rec_fhi, INT32_MAX);
+                auto run = [&](const std::vector<int32_t> &pos, int64_t b, int64_t e, int32_t *lo,
+                               int32_t *off, int r) {
+                    const auto first = pos.begin() + b, last = pos.begin() + e;
+                    const auto x0 = std::lower_bound(first, last, (int32_t)flo);
+                    const auto x1 = std::upper_bound(x0, last, (int32_t)fhi);
+                    lo[r] = (int32_t)(x0 - pos.begin());
+                    off[r + 1] = off[r] + (int32_t)(x1 - x0);
+                };
+                for (int i = 0; i < niso; i++) {
+                    run(l->h_giown, l->iso_gstart[(size_t)i], l->iso_gstart[(size_t)i + 1], lo1, off1, i);
+                    if (staged)
+                        for (int ph = 0; ph < osamp; ph++)
+                            run(p->h_ph_iown, p->h_ph_start[(size_t)i * (osamp + 1) + ph],
+                                p->h_ph_start[(size_t)i * (osamp + 1) + ph + 1], lo0, off0,
+                                i * osamp + ph);
+                    else
+                        run(l->h_giown, l->iso_gstart[(size_t)i], l->iso_gstart[(size_t)i + 1], lo0, off0, i);
+                }
+                if (h.size() > p->wm_cap) {
+                    (void)hipFree(p->d_wm);
+                    p->d_wm = nullptr;
+                    p->wm_cap = 0;
+                    if (hipMalloc(&p->d_wm, h.size() * 4) != hipSuccess) {
+                        pb::set_error("pb_lbl_extinction: cannot allocate the window map");
+                        return PB_ERR_NOMEM;
+                    }
+                    p->wm_cap = h.size();
+                }
+                PB_HIP(hipMemcpyAsync(p->d_wm, h.data(), h.size() * 4, hipMemcpyHostToDevice, s));
+                p->wm_flo = a.rec_flo;
+                p->wm_fhi = a.rec_fhi;
+                p->wm_staged = (int)staged;
+                p->wm_n0 = n0;
+                p->wm_n1 = n1;
+                p->wm_total0 = off0[n0];
+                p->wm_total1 = off1[n1];
+            }
+            a.wm_n[0] = p->wm_n0;
+            a.wm_n[1] = p->wm_n1;
+            a.wm_lo[0] = p->d_wm;
+            a.wm_off[0] = p->d_wm + p->wm_n0;
+            a.wm_lo[1] = p->d_wm + 2 * p->wm_n0 + 1;
+            a.wm_off[1] = a.wm_lo[1] + p->wm_n1;
+            a.wm_total[0] = p->wm_total0;
+            a.wm_total[1] = p->wm_total1;
+            rec_threads = std::max<int64_t>(1, std::max(p->wm_total0, p->wm_total1));
+        }
+        dim3 grid(pb::div_up(rec_threads, kBlock), pb::div_up(nlayers, per));
         const size_t rlds = (size_t)per * a.nrows * 8 + (size_t)a.ndop * 8 +
-                            (size_t)per * a.niso * (8 + 8 + 4) + (size_t)a.niso * (8 + 4) + 16;
+                            (size_t)per * a.niso * (8 + 8 + 4) + (size_t)a.niso * (8 + 4) + 16 +
+                            ((size_t)a.wm_n[0] + 2) * 4;
         const int fmt = a.rec32 ? 3 : (a.rec16 && a.nch_max > 1) ? 2 : a.rec16 ? 1 : 0;
         void (*krec)(LblArgs) =
             per == 1 ? (fmt == 3   ? k_records<3, 1>
@@ -2826,6 +2925,7 @@ static int lbl_extinction(pb_lbl *p, double *ext_d, int64_t wbegin, int64_t wcou
             const size_t need = (size_t)(rsplit - 1) * nlayers * a.nrows * wcount * 8;
             if (need > p->part_bytes) {
                 (void)hipFree(p->part);
+    (void)hipFree(p->d_wm);
                 p->part = nullptr;
                 p->part_bytes = 0;
                 if (hipMalloc(&p->part, need) != hipSuccess) {
