@@ -73,9 +73,10 @@ Full-size parity of the same runs (`cpu_baseline.parity`): C2 ec {par['ec_max_re
 {par['layers_compared']} layers, identical zero pattern, spectrum {par['spectrum_max_rel_err']:.1e}.
 
 Per-rank compute of the multi-GPU decompositions on one GPU, collectives aside
-(`tools/bench_rank.py`, `tools/bench_wshard.py`): layer-sharded N=8 0.234 ms (C2); wavenumber
-shard N=2 / 4 / 8: 0.685 / 0.441 / 0.331 ms in one call, 0.669 / 0.416 / 0.301 ms in two phases (records
-of the shard's groups only; the all-reduce of the maxima left out); 1e6 lines N=8 wavenumber
+(`tools/bench_rank.py`, `tools/bench_wshard.py`): layer-sharded N=8 0.237-0.242 ms (C2); wavenumber
+shard N=2 / 4 / 8 in two phases (records and `k_records` threads for the shard's groups only; the
+all-reduce of the maxima left out): 0.613 / 0.383 / 0.262 ms (0.669 / 0.416 / 0.301 before the window
+map of the last session, 0.685 / 0.441 / 0.331 in the one-call form); 1e6 lines N=8 wavenumber
 1.97 -> 1.28 ms.  Init (`tools/bench_init.py`): 1e7 lines `pb_lines_create` 0.342 -> 0.074 s (device
 grouping), `pb_lbl_create` 1.498 -> 0.284 s.
 """
