@@ -325,7 +325,8 @@ def timed_steps(run_steps, steps, warmup, lbl, world, dist, sync, device_for_red
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=50)
+    ap.add_argument('--steps', type=int, default=None,
+                    help='timed steps (default 50; c5: 157 batches of 64 walkers = 1e4 evals)')
     ap.add_argument('--warmup', type=int, default=4)
     ap.add_argument('--workload', default='c2', choices=sorted(WORKLOADS) + ['c5'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -344,6 +345,8 @@ def main():
     if args.workload == 'c5':
         from tools import bench_c5
         return bench_c5.main(args)
+    if args.steps is None:
+        args.steps = 50
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))

@@ -151,7 +151,7 @@ def main(args):
     model = engine.TableSpectrum(inp['etable'], inp['ttable'], g['wn'], atm['radius'],
                                  atm['rstar'])
     pb = engine.PassBands(g['wn'], inp['bands'])
-    steps = args.steps if args.steps != 20 else 157        # default: 1e4 evals in batches of 64
+    steps = args.steps if args.steps not in (None, 20) else 157   # default: 1e4 evals in batches of 64
     nbatch_distinct = 4
     batches = []
     for b in range(nbatch_distinct):
