@@ -131,6 +131,79 @@ __global__ __launch_bounds__(kBlock) void k_interp_ec_batch(
     }
 }
 
+// Two adjacent samples per thread (16 bytes per lane and access: 1 KiB per wavefront store instead of
+// 512 B).  The rows of ec and of the table start at layer * nwave samples, 8-byte aligned only when
+// nwave is odd, so the pairs start at the first EVEN absolute element of the row: the accesses are
+// then 16-byte aligned; the odd sample in front of / behind the pairs is done by one lane on its own.
+template <int kS, bool kFull>
+__global__ __launch_bounds__(kBlock) void k_interp_ec_batch2(
+    double *ec, const double *etable, const int32_t *tlo, const double *coef, int nmol,
+    int ntemp, int nlayers, int nwave, int nwalkers, int chunk)
+{
+    typedef const double __attribute__((address_space(4))) *ccoef_t;
+    typedef const int32_t __attribute__((address_space(4))) *ctlo_t;
+    typedef double d2 __attribute__((ext_vector_type(2)));
+    const ctlo_t ctlo = (ctlo_t)(unsigned long long)tlo;
+    const int k = blockIdx.y;
+    const int w0 = blockIdx.z * chunk, w1 = min(w0 + chunk, nwalkers);
+    int bmin = ntemp, bmax = -1;
+    for (int w = w0; w < w1; w++) {
+        const int b = ctlo[(int64_t)w * nlayers + k];
+        bmin = min(bmin, b);
+        bmax = max(bmax, b);
+    }
+    const int64_t slice = (int64_t)nlayers * nwave;
+    // first sample of the row whose absolute element index is even (all slices / walkers share
+    // the parity when slice and nlayers * nwave are of one parity -- checked by the launcher)
+    const int head = (int)(((int64_t)k * nwave) & 1);
+    const int gt = blockIdx.x * kBlock + threadIdx.x;
+    // thread 0 of a row that starts at an odd element takes that sample alone; the pairs follow
+    const int ii = head ? (gt == 0 ? 0 : 1 + 2 * (gt - 1)) : 2 * gt;
+    if (ii >= nwave)
+        return;
+    const bool pair = !(head && gt == 0) && ii + 1 < nwave;
+    const double *tab = etable + (int64_t)k * nwave + ii;
+    d2 lo[kS], hi[kS];
+    auto load = [&](int j, int b) -> d2 {
+        const double *p = tab + ((int64_t)j * ntemp + b) * slice;
+        if (pair)
+            return *reinterpret_cast<const d2 *>(p);
+        d2 v;
+        v.x = p[0];
+        v.y = 0.0;
+        return v;
+    };
+#pragma unroll
+    for (int j = 0; j < kS; j++)
+        hi[j] = kFull || j < nmol ? load(j, bmin) : d2{0.0, 0.0};
+    for (int b = bmin; b <= bmax; b++) {
+#pragma unroll
+        for (int j = 0; j < kS; j++) {
+            lo[j] = hi[j];
+            hi[j] = kFull || j < nmol ? load(j, b + 1) : d2{0.0, 0.0};
+        }
+        for (int w = w0; w < w1; w++) {
+            const int64_t wk = (int64_t)w * nlayers + k;
+            if (ctlo[wk] != b)
+                continue;                                   // wave-uniform
+            const ccoef_t co = (ccoef_t)(unsigned long long)(coef + wk * 2 * kS);
+            d2 acc = {0.0, 0.0};
+#pragma unroll
+            for (int j = 0; j < kS; j++)
+                if (kFull || j < nmol) {
+                    // same products and sums per sample as the one-sample kernel
+                    acc.x += lo[j].x * co[j] + hi[j].x * co[kS + j];
+                    acc.y += lo[j].y * co[j] + hi[j].y * co[kS + j];
+                }
+            double *dst = ec + wk * nwave + ii;
+            if (pair)
+                *reinterpret_cast<d2 *>(dst) = acc;
+            else
+                dst[0] = acc.x;
+        }
+    }
+}
+
 // Ray paths re-laid for the fused kernel: for every block of kRows impact parameters the segments
 // [i][row], zero where segment >= row -- contiguous per (block, segment), so that the kernel can
 // take them with wide SCALAR loads (they are wave-uniform) and feed v_fma_f64 from SGPRs.
@@ -792,9 +865,22 @@ int pb_interp_ec_batch(double *ec_d, const double *etable_d, const double *ttabl
     while (chunk > 1 && (int64_t)pb::div_up(nwave, kBlock) * nlayers * pb::div_up(nwalkers, chunk) < 2048)
         chunk /= 2;
     dim3 grid(pb::div_up(nwave, kBlock), nlayers, pb::div_up(nwalkers, chunk));
+    // two samples per thread when every row of every slice / walker has the parity of its layer
+    // index times nwave (slice = nlayers * nwave even, or nwave even), and 16-byte aligned bases
+    static const bool pairs_on = !(getenv("PB_INTERP_PAIRS") && atoi(getenv("PB_INTERP_PAIRS")) == 0);
+    const bool pairs = pairs_on && nwave >= 4 && (((int64_t)nlayers * nwave) % 2 == 0) &&
+                       ((uintptr_t)ec_d % 16 == 0) && ((uintptr_t)etable_d % 16 == 0);
+    if (pairs)
+        grid.x = pb::div_up(nwave / 2 + 2, kBlock);
 #define PB_INTERP(S, FULL)                                                                     \
-    k_interp_ec_batch<S, FULL><<<grid, kBlock, 0, s>>>(ec_d, etable_d, tlo, coef, nmol, ntemp,  \
-                                                       nlayers, nwave, nwalkers, chunk)
+    do {                                                                                       \
+        if (pairs)                                                                             \
+            k_interp_ec_batch2<S, FULL><<<grid, kBlock, 0, s>>>(ec_d, etable_d, tlo, coef, nmol, \
+                                                                ntemp, nlayers, nwave, nwalkers, chunk); \
+        else                                                                                   \
+            k_interp_ec_batch<S, FULL><<<grid, kBlock, 0, s>>>(ec_d, etable_d, tlo, coef, nmol,  \
+                                                               ntemp, nlayers, nwave, nwalkers, chunk); \
+    } while (0)
     static const bool no_full = getenv("PB_INTERP_FULL") && atoi(getenv("PB_INTERP_FULL")) == 0;
     if (nmol == 4 && !no_full)
         PB_INTERP(4, true);

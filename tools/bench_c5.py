@@ -221,7 +221,7 @@ def main(args):
             {'kernel': 'k_transit_pair<16>', 'kernel_ms': transit_ms,
              'kernel_bytes': transit_bytes, 'bound_by': 'FP64 vector ALU (3160 fma + 80 exp per '
              'column), not HBM'},
-            {'kernel': 'k_interp_ec_batch<4,true>', 'kernel_ms': interp_ms,
+            {'kernel': 'k_interp_ec_batch2<4,true>' if os.environ.get('PB_INTERP_PAIRS', '1') != '0' else 'k_interp_ec_batch<4,true>', 'kernel_ms': interp_ms,
              'kernel_bytes': interp_bytes, 'bound_by': 'HBM (ec written per walker)'}]
         for k in kernels:
             k['achieved'] = k['kernel_bytes'] / (k['kernel_ms'] * 1e-3) / 1e9
