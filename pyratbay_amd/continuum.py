@@ -383,7 +383,9 @@ class Continuum:
         if self.hminus:
             parts.append(np.asarray(density['H'], float) * np.asarray(density['e-'], float))
         parts += [np.asarray(density[m.species], float) for m in self.alkali]
-        packed = dev(np.concatenate([np.broadcast_to(p, nlayers) for p in parts]))
+        # ... | the alkali models' Voigt values at the detuning distance [nlayers, nlines] each
+        vds = [np.ascontiguousarray(m.voigt_det(temperature), float).ravel() for m in self.alkali]
+        packed = dev(np.concatenate([np.broadcast_to(p, nlayers) for p in parts] + vds))
         row = [packed[i * nlayers:(i + 1) * nlayers] for i in range(len(parts))]
         temp_d = row[0]
         f_d = packed[nlayers:(1 + nr1) * nlayers] if nr1 else None
@@ -407,10 +409,11 @@ class Continuum:
                  hptr(ntemp), hptr(lo), hptr(hi), _ptr(cia_f_d), _ptr(hm[0]), _ptr(hm[1]),
                  _ptr(hm[2]), _stream())
         keep = [packed]
+        vd_at = len(parts) * nlayers
         for ia, m in enumerate(self.alkali):
-            vd = dev(m.voigt_det(temperature))
+            vd = packed[vd_at:vd_at + len(vds[ia])]
+            vd_at += len(vds[ia])
             dens_d = row[nxt + ia]
-            keep.append(vd)
             wn0, gf = np.array(m.wn0, float), np.array(m.gf, float)
             call('pb_alkali_cross_section', _ptr(ec), _ptr(self.pressure_barye), _ptr(self.wn),
                  _ptr(temp_d), _ptr(vd), float(m.detuning), float(m.mass), float(m.lpar),

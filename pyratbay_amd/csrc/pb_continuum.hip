@@ -45,18 +45,27 @@ struct ContArgs {
     const double *hm_sigma_bf, *hm_ff, *hm_f;   // [nwave], [6][nwave], [nlayers]; null = no H-
 };
 
-// One workgroup = one layer x 256 samples.  Per-layer scalars (CIA brackets, H- powers) are
-// prepared by the first lanes in LDS.
+// One workgroup = kContLayers layers x 256 samples.  Per-layer scalars (CIA brackets, H- powers)
+// are prepared by the first lanes in LDS.  A thread keeps the layer-independent operands of its
+// sample -- the rank-1 cross sections, the H- bound-free cross section, the six free-free rows and
+// the wavenumber -- in registers across the layers (one layer per workgroup re-read those ~1.1 GB
+// per C2-shaped call from L2, once per layer: 2.0 TB/s on the 394 MB the pass must move); per
+// (layer, sample) the same products are added in the same order.
+constexpr int kContLayers = 8;
+constexpr int kContRank1 = 8;          // rank-1 terms kept in registers (more are re-read per layer)
+
 __global__ __launch_bounds__(kBlock) void k_continuum(ContArgs a)
 {
-    __shared__ int s_idx[kMaxCia];
-    __shared__ double s_dt[kMaxCia], s_inv[kMaxCia], s_beta[6], s_bfpre, s_ffpost;
-    const int l = blockIdx.y;
-    const double temp = a.temp[l];
-    if ((int)threadIdx.x < a.ncia) {
+    __shared__ int s_idx[kContLayers][kMaxCia];
+    __shared__ double s_dt[kContLayers][kMaxCia], s_inv[kContLayers][kMaxCia], s_beta[kContLayers][6],
+        s_bfpre[kContLayers], s_ffpost[kContLayers];
+    const int l0 = blockIdx.y * kContLayers;
+    const int nl = min(kContLayers, a.nlayers - l0);
+    if ((int)threadIdx.x < a.ncia * kContLayers && (int)threadIdx.x / a.ncia < nl) {
         // _spline.c:235-251: index = nearest node, stepped down unless it is at or below
         // the temperature; a temperature on a node takes that row unchanged
-        const int c = threadIdx.x;
+        const int q = threadIdx.x / a.ncia, c = threadIdx.x % a.ncia;
+        const double temp = a.temp[l0 + q];
         const double *t = a.cia_temps[c];
         const int n = a.cia_ntemp[c];
         int idx = -1;
@@ -70,61 +79,82 @@ __global__ __launch_bounds__(kBlock) void k_continuum(ContArgs a)
                 inv = t[idx + 1] - t[idx];
             }
         }
-        s_idx[c] = idx;
-        s_dt[c] = dt;
-        s_inv[c] = inv;
+        s_idx[q][c] = idx;
+        s_dt[q][c] = dt;
+        s_inv[q][c] = inv;
     }
-    if (a.hm_sigma_bf && threadIdx.x >= 32 && threadIdx.x < 38) {
-        const int i = threadIdx.x - 32;
+    if (a.hm_sigma_bf && threadIdx.x >= 64 && threadIdx.x < 64 + 6 * kContLayers &&
+        (int)(threadIdx.x - 64) / 6 < nl) {
+        const int q = (threadIdx.x - 64) / 6, i = (threadIdx.x - 64) % 6;
+        const double temp = a.temp[l0 + q];
         const double tc = fmin(fmax(temp, 1000.0), 10080.0);
-        s_beta[i] = pow(sqrt(5040.0 / tc), (double)(i + 2));
+        s_beta[q][i] = pow(sqrt(5040.0 / tc), (double)(i + 2));
         if (i == 0) {
             const double alpha = kPcH * kPcC / kPcK;
-            s_bfpre = 0.75 * pow(temp, -1.5) * kPcK * exp(kWn0Bf * alpha / temp);
-            s_ffpost = kPcK * tc;
+            s_bfpre[q] = 0.75 * pow(temp, -1.5) * kPcK * exp(kWn0Bf * alpha / temp);
+            s_ffpost[q] = kPcK * tc;
         }
     }
     __syncthreads();
     const int w = blockIdx.x * kBlock + threadIdx.x;
     if (w >= a.nwave)
         return;
-    const int64_t at = (int64_t)l * a.nwave + w;
-    double ec = a.ec[at];
-    for (int m = 0; m < a.nrank1; m++)
-        ec += a.cs[(int64_t)m * a.nwave + w] * a.f[(int64_t)m * a.nlayers + l];
-    for (int c = 0; c < a.ncia; c++) {
-        if (w < a.cia_lo[c] || w >= a.cia_hi[c])
-            continue;
-        const int idx = s_idx[c];
-        double cs;
-        if (idx < 0) {
-            cs = NAN;                       // temperature off the table (the reference raises)
-        } else {
-            const double y0 = a.cia_tab[c][(int64_t)idx * a.nwave + w];
-            cs = y0;
-            if (s_inv[c] != 0.0) {
-                const double y1 = a.cia_tab[c][(int64_t)(idx + 1) * a.nwave + w];
-                cs = y0 + s_dt[c] * ((y1 - y0) / s_inv[c]);
-            }
-        }
-        ec += cs * a.cia_f[(int64_t)c * a.nlayers + l];
-    }
+    // layer-independent operands of this sample
+    double csv[kContRank1];
+#pragma unroll
+    for (int m = 0; m < kContRank1; m++)
+        csv[m] = m < a.nrank1 ? a.cs[(int64_t)m * a.nwave + w] : 0.0;
+    double wn = 0.0, sig = 0.0, ffv[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
     if (a.hm_sigma_bf) {
-        const double alpha = kPcH * kPcC / kPcK;
-        const double wn = a.wn[w];
-        const double bf = s_bfpre * (1.0 - exp(-wn * alpha / temp)) * a.hm_sigma_bf[w];
-        // short-wavelength branch uses beta[0..3], the long one beta[1..5]; the unused
-        // rows of hm_ff are zero.  Sum in ascending power like np.sum over that axis.
-        double ff = 0.0;
-        for (int i = 0; i < 6; i++) {
-            const double fi = a.hm_ff[(int64_t)i * a.nwave + w];
-            if (fi != 0.0)
-                ff += s_beta[i] * fi;
-        }
-        ff *= s_ffpost;
-        ec += (bf + ff) * a.hm_f[l];
+        wn = a.wn[w];
+        sig = a.hm_sigma_bf[w];
+#pragma unroll
+        for (int i = 0; i < 6; i++)
+            ffv[i] = a.hm_ff[(int64_t)i * a.nwave + w];
     }
-    a.ec[at] = ec;
+    for (int q = 0; q < nl; q++) {
+        const int l = l0 + q;
+        const double temp = a.temp[l];
+        const int64_t at = (int64_t)l * a.nwave + w;
+        double ec = a.ec[at];
+#pragma unroll
+        for (int m = 0; m < kContRank1; m++)
+            if (m < a.nrank1)
+                ec += csv[m] * a.f[(int64_t)m * a.nlayers + l];
+        for (int m = kContRank1; m < a.nrank1; m++)
+            ec += a.cs[(int64_t)m * a.nwave + w] * a.f[(int64_t)m * a.nlayers + l];
+        for (int c = 0; c < a.ncia; c++) {
+            if (w < a.cia_lo[c] || w >= a.cia_hi[c])
+                continue;
+            const int idx = s_idx[q][c];
+            double cs;
+            if (idx < 0) {
+                cs = NAN;                   // temperature off the table (the reference raises)
+            } else {
+                const double y0 = a.cia_tab[c][(int64_t)idx * a.nwave + w];
+                cs = y0;
+                if (s_inv[q][c] != 0.0) {
+                    const double y1 = a.cia_tab[c][(int64_t)(idx + 1) * a.nwave + w];
+                    cs = y0 + s_dt[q][c] * ((y1 - y0) / s_inv[q][c]);
+                }
+            }
+            ec += cs * a.cia_f[(int64_t)c * a.nlayers + l];
+        }
+        if (a.hm_sigma_bf) {
+            const double alpha = kPcH * kPcC / kPcK;
+            const double bf = s_bfpre[q] * (1.0 - exp(-wn * alpha / temp)) * sig;
+            // short-wavelength branch uses beta[0..3], the long one beta[1..5]; the unused
+            // rows of hm_ff are zero.  Sum in ascending power like np.sum over that axis.
+            double ff = 0.0;
+#pragma unroll
+            for (int i = 0; i < 6; i++)
+                if (ffv[i] != 0.0)
+                    ff += s_beta[q][i] * ffv[i];
+            ff *= s_ffpost[q];
+            ec += (bf + ff) * a.hm_f[l];
+        }
+        a.ec[at] = ec;
+    }
 }
 
 struct AlkaliArgs {
@@ -142,11 +172,18 @@ __global__ __launch_bounds__(kBlock) void k_alkali(AlkaliArgs a)
     const double kAtm = 1010000.0, kC2 = 1.4387768775039338, kC3 = 8.852821681767784e-13;
     const int w = blockIdx.x * kBlock + threadIdx.x;
     const int l = blockIdx.y;
+    const double temp = a.temp[l];
+    // the layer's Lorentz width and detuning distance: two pow() per LAYER, evaluated once per
+    // workgroup (every thread evaluating them was most of the pass on grids far from the lines)
+    __shared__ double s_lorentz, s_dsigma;
+    if (threadIdx.x == 0) {
+        s_lorentz = a.lpar * pow(temp / 2000.0, -0.7) * a.pressure[l] / kAtm;
+        s_dsigma = a.detuning * pow(temp / 500.0, 0.6);
+    }
+    __syncthreads();
     if (w >= a.nwave)
         return;
-    const double temp = a.temp[l];
-    const double lorentz = a.lpar * pow(temp / 2000.0, -0.7) * a.pressure[l] / kAtm;
-    const double dsigma = a.detuning * pow(temp / 500.0, 0.6);
+    const double lorentz = s_lorentz, dsigma = s_dsigma;
     const double wn = a.wn[w];
     double acc = 0.0;
     for (int j = 0; j < a.nlines; j++) {
@@ -213,7 +250,7 @@ int pb_continuum(double *ec_d, const double *wn_d, const double *temp_d, int nla
     a.hm_sigma_bf = hm_sigma_bf_d;
     a.hm_ff = hm_ff_d;
     a.hm_f = hm_f_d;
-    dim3 grid((unsigned)pb::div_up(nwave, kBlock), (unsigned)nlayers);
+    dim3 grid((unsigned)pb::div_up(nwave, kBlock), (unsigned)pb::div_up(nlayers, kContLayers));
     k_continuum<<<grid, kBlock, 0, pb::as_stream(stream)>>>(a);
     PB_LAUNCH_CHECK();
     return PB_OK;
