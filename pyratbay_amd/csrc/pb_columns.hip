@@ -645,8 +645,25 @@ __device__ inline double exp1_real(double x)
     return pb::exp_s(-x) * (1.0 / (x + t0));
 }
 
-// One column per thread.  The downward sweep parks trans[i] in flux_up[i] so that the
-// upward sweep does not evaluate exp1 again; Planck values are recomputed in registers.
+// The diffusivity transmission of every (layer interval, sample), trans[i][j] written to
+// flux_up[i][j]: the expensive part of the two-stream solver (exp1: a series or a continued
+// fraction of 20 + 80/x terms, one division each) has no dependence between layers, so it gets a
+// thread per (interval, sample) instead of sitting in the column sweeps (one thread per column =
+// 1.5 wavefronts per SIMD at 1e5 samples).  Same expression as the sweep evaluated before.
+__global__ __launch_bounds__(kBlock) void k_two_stream_trans(double *flux_up, const double *depth,
+                                                            int nlayers, int nwave)
+{
+    const int j = blockIdx.x * kBlock + threadIdx.x;
+    const int i = blockIdx.y;
+    if (j >= nwave || i >= nlayers - 1)
+        return;
+    const double dtau0 = depth[(int64_t)(i + 1) * nwave + j] - depth[(int64_t)i * nwave + j];
+    flux_up[(int64_t)i * nwave + j] =
+        (1 - dtau0) * pb::exp_s(-dtau0) + dtau0 * dtau0 * exp1_real(dtau0);
+}
+
+// One column per thread.  trans[i] comes from k_two_stream_trans (parked in flux_up[i], which
+// the upward sweep then overwrites); Planck values are recomputed in registers.
 __global__ __launch_bounds__(kBlock) void k_two_stream(
     double *flux_down, double *flux_up, const double *depth, const double *wn,
     const double *temp, const double *f_int, const double *flux_top, int rtop, int nlayers,
@@ -668,12 +685,11 @@ __global__ __launch_bounds__(kBlock) void k_two_stream(
         const double dnext = depth[(int64_t)(i + 1) * nwave + j];
         const double bnext = planck(factor, w, temp[i + 1]);
         const double dtau0 = dnext - dprev;
-        const double trans = (1 - dtau0) * pb::exp_s(-dtau0) + dtau0 * dtau0 * exp1_real(dtau0);
+        const double trans = flux_up[(int64_t)i * nwave + j];
         const double bp = (bnext - bprev) / dtau0;
         down = trans * down + pi * bprev * (1 - trans) +
                pi * bp * (-2.0 / 3 * (1 - pb::exp_s(-dtau0)) + dtau0 * (1 - trans / 3));
         flux_down[(int64_t)(i + 1) * nwave + j] = down;
-        flux_up[(int64_t)i * nwave + j] = trans;
         dprev = dnext;
         bprev = bnext;
     }
@@ -1046,6 +1062,12 @@ int pb_two_stream(double *flux_down_d, double *flux_up_d, const double *depth_d,
         return PB_OK;
     PB_REQUIRE(flux_down_d && flux_up_d && depth_d && wn_d && temp_d,
                "pb_two_stream: null pointer");
+    if (nlayers > 1) {
+        dim3 tgrid((unsigned)pb::div_up(nwave, kBlock), (unsigned)(nlayers - 1));
+        k_two_stream_trans<<<tgrid, kBlock, 0, pb::as_stream(stream)>>>(flux_up_d, depth_d,
+                                                                         nlayers, nwave);
+        PB_LAUNCH_CHECK();
+    }
     k_two_stream<<<pb::div_up(nwave, kBlock), kBlock, 0, pb::as_stream(stream)>>>(
         flux_down_d, flux_up_d, depth_d, wn_d, temp_d, f_int_d, flux_top_d, rtop, nlayers,
         nwave);
