@@ -440,19 +440,25 @@ def main():
             pipelined = streams > 1
         shared.setdefault('voigt', model.voigt)
         shared.setdefault('lines', model.lines)
-        if kind in ('single', 'replicas') and nwave <= 200000:
+        if nwave <= 200000:
             # part of the set-up: a few dozen spectra so that every context's workspaces exist
             # and the chip is at its working clocks before the W warm-up steps -- with W = 5 on
             # a box that was idle the timed steps otherwise start cold (20 steps: 1020 against
             # 1075 spectra/s with a longer warm-up).  Counted in init_seconds, never timed.
             prime = int(os.environ.get('PB_PRIME', '32'))
-            for _ in range(prime):
+            if kind == 'layers':
+                for _ in range(prime):
+                    sharded.submit() if pipelined else sharded.step()
+                if pipelined:
+                    sharded.flush()
+            else:
+                for _ in range(prime):
+                    if streams > 1:
+                        pipe.submit()
+                    else:
+                        step()
                 if streams > 1:
-                    pipe.submit()
-                else:
-                    model.run()
-            if streams > 1:
-                pipe.flush()
+                    pipe.flush()
             res['priming_spectra'] = prime
         torch.cuda.synchronize()
         res['init_seconds'] = round(time.perf_counter() - t0, 3)
