@@ -617,3 +617,49 @@ def test_windows_that_leave_the_grid(eng, orc, gather, short_own, long_rows):
     assert np.array_equal(np.concatenate(parts, axis=2), ext)
     print(f'edge windows {gather} short_own={short_own} long_rows={long_rows}: {touched} samples, '
           f'max rel err vs oracle = {worst:.2e}')
+
+
+@pytest.mark.parametrize('gather', ['staged', 'global'])
+def test_window_map_of_two_phase_shards(eng, monkeypatch, gather):
+    """k_records of a two-phase shard call walks only the groups within reach of the shard (the
+    window map: runs of in-window groups per (isotope, phase) resp. per isotope, thread -> group by
+    a bisection over the run offsets).  With the map switched off (a thread per group of the whole
+    list, out-of-window ones returning at once) the records, the local maxima and the sums must be
+    the same bit for bit -- also when a plan is reused for another shard (the map is cached per
+    window) and for a shard that no group reaches."""
+    import torch
+    from pyratbay_amd import synth
+    monkeypatch.setenv('PB_STAGE_SPLIT', '1')
+    case = synth.lbl_case(9001, 4, 30000, wnosamp=24, nlor=18, ndop=9, extent=80.0,
+                          cutoff=3.0, niso=3, seed=9)
+    g, atm, ln, iso, vg = (case[k] for k in ('grid', 'atm', 'lines', 'iso', 'voigt'))
+    # no lines in the last tenth of the grid: a shard there has an empty window
+    keep = ln['lwn'] < g['wn'][0] + 0.85 * (g['wn'][-1] - g['wn'][0])
+    lwn, elow, gf, lid = (ln[k][keep] for k in ('lwn', 'elow', 'gf', 'lid'))
+    vt = eng.VoigtTable.build(vg['lorentz'], vg['doppler'], vg['size'], g['ownstep'], 24)
+    ll = eng.LineList(lwn, elow, gf, lid, 3, g['own'])
+    t, d, z = eng.dev(atm['temp']), eng.dev(atm['dens']), eng.dev(iso['isoz'])
+
+    def shard_results(with_map):
+        if with_map:
+            monkeypatch.delenv('PB_NO_WINDOW_MAP', raising=False)
+        else:
+            monkeypatch.setenv('PB_NO_WINDOW_MAP', '1')
+        lbl = eng.LBL(vt, ll, g['wn'], g['divisors'], atm['mol_radius'], atm['mol_mass'],
+                      iso['isoimol'], iso['isomass'], iso['isoratio'], iso['isoiext'],
+                      vg['cutoff'], 1e-30, max_layers=4)
+        lbl.set_gather_mode(gather)
+        out = []
+        for a, b in ((0, 2000), (2000, 5000), (0, 2000), (8700, 9001), (5000, 8700)):
+            ext = lbl.extinction_begin(t, d, z, add=True, wbegin=a, wcount=b - a)
+            kmax = lbl.kmax_tensor().clone()
+            lbl.extinction_end()
+            out.append((kmax, ext.clone()))
+        return out
+
+    on, off = shard_results(True), shard_results(False)
+    for (k1, e1), (k0, e0) in zip(on, off):
+        assert torch.equal(k1, k0)
+        assert torch.equal(e1, e0)
+    assert torch.count_nonzero(on[3][1]) == 0          # the empty shard
+    assert torch.count_nonzero(on[1][1]) > 0
