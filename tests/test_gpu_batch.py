@@ -48,9 +48,15 @@ def test_transit_path_device(eng, orc):
             np.testing.assert_allclose(got[w], want, rtol=1e-11)
 
 
-def test_interp_ec_batch_vs_single_and_oracle(eng, orc):
+@pytest.mark.parametrize('L,W', [(9, 1500), (9, 1501), (8, 1501), (8, 5), (8, 3), (10, 258)])
+def test_interp_ec_batch_vs_single_and_oracle(eng, orc, L, W):
+    """The batched interpolation against the per-walker kernel (bit for bit) and the oracle.
+    (L, W): even rows -- pairs of samples from sample 0; L * W odd -- the one-sample kernel; odd W
+    with even L -- every other row starts at an odd element, its first sample is taken alone and
+    the pairs follow (16-byte aligned accesses); W = 5 / 3 -- the smallest grids with / without
+    pairs; W = 258 -- a pair in the second workgroup."""
     rng = np.random.default_rng(4)
-    nmol, ntemp, L, W, nw = 4, 7, 9, 1500, 37
+    nmol, ntemp, nw = 4, 7, 37
     ttable = np.linspace(300.0, 3000.0, ntemp)
     etable = 10.0**rng.uniform(-30, -20, (nmol, ntemp, L, W))
     temps = rng.uniform(300.0, 3000.0, (nw, L))
