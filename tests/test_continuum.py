@@ -168,6 +168,37 @@ def test_hip_all_terms_fused(eng, g):
 
 
 @pytest.mark.gpu
+def test_hip_many_rank1_terms_and_layer_subsets(eng, g):
+    """The fused pass keeps eight rank-1 cross sections of a sample in registers over blocks of
+    eight layers: eleven rank-1 terms (the last three are re-read per layer) and layer counts that
+    are not multiples of eight (1, 7, 9, all) must give the sums of the one-family fixtures."""
+    from pyratbay_amd import continuum as ct
+    wn, pressure, temp = g['wn'], g['pressure'], g['temp']
+    d = density_dict(g)
+    lec = ct.Lecavelier(pressure, wn=wn)
+    lec.calc_cross_section(g['lec_pars'])
+    models = [ct.Kurucz(wn, s) for s in ('H', 'He', 'H2', 'e-', 'H2', 'He', 'H', 'H2', 'e-', 'He')]
+    models += [lec] + cia_models(g, ct) + [ct.Hydrogen_Ion(wn)]
+    keys = ['ray_H_ec', 'ray_He_ec', 'ray_H2_ec', 'ray_e_ec', 'ray_H2_ec', 'ray_He_ec', 'ray_H_ec',
+            'ray_H2_ec', 'ray_e_ec', 'ray_He_ec', 'lec_ec', 'cia_h2h2_ec', 'cia_h2he_ec', 'hm_ec']
+    want = sum(g[k] for k in keys)
+    L = len(temp)
+    full = eng.dev(np.zeros((L, len(wn))))
+    ct.Continuum(wn, pressure, models).add(full, temp, d)
+    np.testing.assert_allclose(full.cpu().numpy(), want, rtol=1e-11)
+    for n in (1, 7, 9):
+        if n > L:
+            continue
+        lec_n = ct.Lecavelier(pressure[:n], wn=wn)
+        lec_n.calc_cross_section(g['lec_pars'])
+        models_n = models[:10] + [lec_n] + models[11:]
+        sub = eng.dev(np.zeros((n, len(wn))))
+        ct.Continuum(wn, pressure[:n], models_n).add(sub, temp[:n], {k: v[:n] for k, v in d.items()})
+        # the same per-(layer, sample) sums whatever the block a layer falls into
+        assert np.array_equal(sub.cpu().numpy(), full.cpu().numpy()[:n]), n
+
+
+@pytest.mark.gpu
 def test_hip_alkali_dropin(eng, g):
     """pyratbay_amd.lib._alkali.alkali_cross_section: the reference's positional signature."""
     from pyratbay_amd.lib import _alkali
