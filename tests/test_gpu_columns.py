@@ -256,3 +256,30 @@ def test_random_rt_configurations(eng, orc, seed):
     flux = eng.emission_flux(d3, i3, eng.dev(c['wn']), eng.dev(c['temp']), eng.dev(c['mu']),
                              eng.dev(weights), itop, cloud_tsurf=tsurf, cloud_itop=deck_itop)
     np.testing.assert_allclose(host(flux), want_f, rtol=RTOL)
+
+
+@pytest.mark.parametrize('nlayers', [1, 2, 9, 17, 40])
+def test_plane_parallel_depth_stop_rules(eng, orc, nlayers):
+    """k_plane_depth fetches its rows eight at a time before it applies the reference's in-order
+    stop (maxdepth reached, ibottom, last layer): every top layer (the last one included: no row
+    is examined), every bottom, stops in the first / a middle / the last row of a fetch group and
+    no stop at all, against the oracle -- depth bit for bit (same sums), ideep exact."""
+    rng = np.random.default_rng(nlayers)
+    W = 777
+    ec = 10.0**rng.uniform(-11, -8, (nlayers, W))
+    radius = np.linspace(7.5e9, 7.0e9, max(nlayers, 2))[:nlayers]
+    h = -np.diff(radius) if nlayers > 1 else np.zeros(0)
+    col_total = 0.5 * np.sum(h[:, None] * (ec[1:] + ec[:-1]), axis=0) if nlayers > 1 else np.zeros(W)
+    ec_d, h_d = eng.dev(ec), eng.dev(h if nlayers > 1 else np.zeros(1))
+    tops = sorted({0, 1, nlayers // 2, nlayers - 2, nlayers - 1} & set(range(nlayers)))
+    for itop in tops:
+        for ibottom in sorted({itop, itop + 1, nlayers // 2, nlayers - 1, nlayers} & set(range(nlayers + 1))):
+            for maxdepth in (0.0, float(np.median(col_total)) * 0.03, float(np.median(col_total)) * 0.5,
+                             np.inf):
+                wd, wi = np.zeros((nlayers, W)), np.full(W, nlayers - 1, np.int32)
+                orc.plane_parallel_optical_depth(wd, wi, ec, h if nlayers > 1 else np.zeros(1),
+                                                 maxdepth, itop, ibottom)
+                d, i = eng.plane_parallel_optical_depth(ec_d, h_d, itop, ibottom, maxdepth)
+                what = (nlayers, itop, ibottom, maxdepth)
+                assert np.array_equal(host(i), wi), what
+                assert np.array_equal(host(d), wd), what
