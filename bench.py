@@ -301,9 +301,74 @@ def measured_traffic(workload):
         return None
 
 
-def timed_steps(run_steps, steps, warmup, lbl, world, dist, sync, device_for_reduce):
+def free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sock:
+        sock.bind(('127.0.0.1', 0))
+        return sock.getsockname()[1]
+
+
+def self_launch(argv, nranks):
+    """`python bench.py --gpus N` without a launcher: this process -- which has NOT touched
+    the GPU (no HIP call, no torch.cuda query) and never will -- starts N fresh children, one
+    per GPU, with the rendezvous variables torch.distributed.run would set, relays rank 0's
+    output, and returns the first non-zero exit code (terminating the other ranks: a rank
+    that died leaves its peers waiting in a collective).  Children are started with
+    subprocess (fork + exec of a process that never initialised HIP); nothing is exec'd over a
+    process that uses the GPU."""
+    port = int(os.environ.get('MASTER_PORT', 0)) or free_port()
+    procs = []
+    for r in range(nranks):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(nranks),
+                   LOCAL_WORLD_SIZE=str(nranks), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv),
+                                      env=env, cwd=os.getcwd(),
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    pending = set(range(nranks))
+    while pending:
+        for r in sorted(pending):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            pending.discard(r)
+            if code != 0 and rc == 0:
+                rc = code
+                print(f'bench.py: rank {r} exited with code {code}; stopping the other ranks',
+                      file=sys.stderr, flush=True)
+                for q in sorted(pending):
+                    procs[q].terminate()         # exactly the children started above
+        time.sleep(0.05)
+    return rc
+
+
+def launch_selftest(mode):
+    """Child body of `--selftest-launch` (tests/test_dist_gloo.py): a gloo rendezvous on the CPU
+    with the variables self_launch() set, one all-reduce, rank 0 prints one JSON line.  mode
+    'fail': rank 1 exits with code 3 before the rendezvous."""
+    rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
+    if mode == 'fail' and rank == 1:
+        sys.exit(3)
+    import torch
+    import torch.distributed as dist
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    t = torch.tensor([float(rank + 1)], dtype=torch.float64)
+    dist.all_reduce(t)
+    if rank == 0:
+        print(json.dumps({'selftest': True, 'world': world, 'sum': float(t.item()),
+                          'local_rank': int(os.environ['LOCAL_RANK']),
+                          'master': f"{os.environ['MASTER_ADDR']}:{os.environ['MASTER_PORT']}"}),
+              flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+    return 0
+
+
+def timed_steps(run_steps, steps, warmup, lbl, world, dist, sync, device_for_reduce,
+                kernel_events=True):
     run_steps(warmup)
-    lbl.timing_begin(steps)
+    lbl.timing_begin(steps if kernel_events else 0)
     sync()
     if world > 1:
         dist.barrier()
@@ -339,9 +404,20 @@ def main():
     ap.add_argument('--cpu-layers', type=int, default=None,
                     help='layers of the one-core CPU leg (default: all at c2, 16 otherwise)')
     ap.add_argument('--cpu-worker', action='store_true', help=argparse.SUPPRESS)
+    ap.add_argument('--selftest-launch', default=None, choices=['ok', 'fail'],
+                    help=argparse.SUPPRESS)
+    ap.add_argument('--sustain-seconds', type=float, default=3.0,
+                    help='length of the sustained legs at N=1 (config.sustained; 0: skip)')
     args = ap.parse_args()
     if args.cpu_worker:
         return cpu_worker()
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        # plain `python bench.py --gpus N`: start the ranks ourselves (before any GPU call)
+        sys.exit(self_launch(sys.argv[1:], args.gpus))
+    if args.selftest_launch:
+        if int(os.environ.get('WORLD_SIZE', '1')) != args.gpus:
+            raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={os.environ.get("WORLD_SIZE")}')
+        return launch_selftest(args.selftest_launch)
     if args.workload == 'c5':
         from tools import bench_c5
         return bench_c5.main(args)
@@ -440,6 +516,29 @@ def main():
             pipelined = streams > 1
         shared.setdefault('voigt', model.voigt)
         shared.setdefault('lines', model.lines)
+
+        def run_steps(k):
+            if pipelined and kind != 'layers':
+                out = None
+                for _ in range(k):
+                    out, _ev = pipe.submit()
+                pipe.flush()
+                return [out]
+            if pipelined:
+                for _ in range(k):
+                    sharded.submit()
+                return sharded.flush()
+            out = None
+            for _ in range(k):
+                out = step()
+            return [out]
+
+        if world == 1 and nwave <= 200000:
+            # the same W + K steps BEFORE the priming spectra below (config.cold_value): what a
+            # caller sees who runs a few dozen spectra on a chip that was idle
+            el0, _, _ = timed_steps(run_steps, args.steps, args.warmup, model.lbl, world, dist,
+                                    torch.cuda.synchronize, dev_reduce, kernel_events=False)
+            res['cold_value'] = args.steps / el0
         if nwave <= 200000:
             # part of the set-up: a few dozen spectra so that every context's workspaces exist
             # and the chip is at its working clocks before the W warm-up steps -- with W = 5 on
@@ -462,22 +561,6 @@ def main():
             res['priming_spectra'] = prime
         torch.cuda.synchronize()
         res['init_seconds'] = round(time.perf_counter() - t0, 3)
-
-        def run_steps(k):
-            if pipelined and kind != 'layers':
-                out = None
-                for _ in range(k):
-                    out, _ev = pipe.submit()
-                pipe.flush()
-                return [out]
-            if pipelined:
-                for _ in range(k):
-                    sharded.submit()
-                return sharded.flush()
-            out = None
-            for _ in range(k):
-                out = step()
-            return [out]
 
         elapsed, gather_ms, launches = timed_steps(
             run_steps, args.steps, args.warmup, model.lbl, world, dist, torch.cuda.synchronize,
@@ -502,6 +585,27 @@ def main():
                 # the gather kernel's own duration (roofline) is the one measured with nothing
                 # else on the chip, not the one stretched by the neighbouring stream
                 res.update(gather_ms=g2, launches=l2)
+        if world == 1 and args.sustain_seconds > 0:
+            # sustained legs: >= sustain_seconds of back-to-back spectra in ONE timed region
+            # (steady clocks and power state), for the pipelined form and one at a time
+            def one_by_one(k):
+                out = None
+                for _ in range(k):
+                    out = step()
+                return [out]
+            sus = {'seconds_target': args.sustain_seconds}
+            n = max(args.steps, int(np.ceil(1.05 * args.sustain_seconds * args.steps / elapsed)))
+            el, _, _ = timed_steps(run_steps, n, 0, model.lbl, world, dist,
+                                   torch.cuda.synchronize, dev_reduce, kernel_events=False)
+            key = f"in_flight_{res.get('streams', 1)}"
+            sus[key] = {'spectra_per_s': n / el, 'spectra': n, 'seconds': el}
+            if pipelined:
+                n1 = max(args.steps, int(np.ceil(1.05 * args.sustain_seconds /
+                                                 (1e-3 * res['unpipelined_ms_per_spectrum']))))
+                el1, _, _ = timed_steps(one_by_one, n1, 0, model.lbl, world, dist,
+                                        torch.cuda.synchronize, dev_reduce, kernel_events=False)
+                sus['one_at_a_time'] = {'spectra_per_s': n1 / el1, 'spectra': n1, 'seconds': el1}
+            res['sustained'] = sus
         return res
 
     if world == 1:
@@ -618,6 +722,10 @@ def main():
             out['config']['unpipelined_ms_per_spectrum'] = latency_ms
         if primary.get('priming_spectra'):
             out['config']['priming_spectra_in_init'] = primary['priming_spectra']
+        if primary.get('cold_value') is not None:
+            out['config']['cold_value'] = primary['cold_value']
+        if primary.get('sustained') is not None:
+            out['config']['sustained'] = primary['sustained']
         if world > 1:
             # both decompositions of the same run
             out['config']['value_from'] = primary['kind']

@@ -39,6 +39,30 @@ int pb_device_count(int *count);
 int pb_set_device(int device);
 
 /* =========================================================================
+ * Stage timers and profiler ranges  (Pyrat.timestamps['extinction'|'odepth'|'spectrum'],
+ * pyratbay/pyrat/pyrat_obj.py:203-214 with the Timer of pyratbay/tools/tools.py:832-843)
+ * ========================================================================= */
+typedef struct pb_timer pb_timer;
+
+/* A timer holds max_stages + 1 HIP events.  pb_timer_start records the first one on `stream`
+ * (and opens a rocTX range `first_stage` when not NULL); pb_timer_mark records the END of the
+ * stage `name` and opens the range of `next_stage` (NULL: none).  Entry points that fuse two of
+ * the reference's stages (pb_transit_spectrum*: optical depth, then transmission) mark the
+ * boundary themselves on the timer most recently started by the calling thread, under the
+ * reference's stage name ("odepth").  Nothing synchronises until pb_timer_read, which waits for
+ * the stage's closing event and returns its duration in seconds. */
+int pb_timer_create(pb_timer **out, int max_stages);
+int pb_timer_start(pb_timer *t, const char *first_stage, void *stream);
+int pb_timer_mark(pb_timer *t, const char *name, const char *next_stage, void *stream);
+int pb_timer_count(const pb_timer *t, int *nstages);
+int pb_timer_read(pb_timer *t, int stage, char *name_out, int name_cap, double *seconds);
+void pb_timer_destroy(pb_timer *t);
+/* rocTX ranges for rocprofv3 --marker-trace (no-ops when the marker library is absent) */
+int pb_range_push(const char *name);
+int pb_range_pop(void);
+int pb_roctx_available(void);
+
+/* =========================================================================
  * Voigt profile table  (vprofile.grid, src_c/vprofile.c:42-114;
  *                       voigtn/voigtxy, src_c/include/voigt.h:147-359)
  * ========================================================================= */

@@ -28,6 +28,15 @@ _PROTOS = {
     'pb_version': [],
     'pb_device_count': [C.POINTER(C.c_int)],
     'pb_set_device': [i32],
+    'pb_timer_create': [C.POINTER(vp), i32],
+    'pb_timer_start': [vp, C.c_char_p, vp],
+    'pb_timer_mark': [vp, C.c_char_p, C.c_char_p, vp],
+    'pb_timer_count': [vp, C.POINTER(i32)],
+    'pb_timer_read': [vp, i32, C.c_char_p, i32, C.POINTER(f64)],
+    'pb_timer_destroy': [vp],
+    'pb_range_push': [C.c_char_p],
+    'pb_range_pop': [],
+    'pb_roctx_available': [],
     'pb_voigt_create': [C.POINTER(vp), vp, i32, vp, i32, vp, f64, i32, i32, vp],
     'pb_voigt_from_flat': [C.POINTER(vp), vp, i64, vp, i32, vp, i32, vp, vp, i32, i32, vp],
     'pb_voigt_meta': [vp, vp, vp, C.POINTER(i64)],
@@ -88,8 +97,8 @@ _PROTOS = {
     'pb_band_integrate': [vp, vp, vp, vp, vp, vp, vp, i32, i64, i64, vp],
 }
 _RESTYPES = {'pb_transit_work_doubles': C.c_int64, 'pb_voigt_destroy': None, 'pb_lines_destroy': None, 'pb_lbl_destroy': None,
-             'pb_voigt_device_bytes': i64}
-_NO_CHECK = set(_RESTYPES) | {'pb_version'}
+             'pb_voigt_device_bytes': i64, 'pb_timer_destroy': None}
+_NO_CHECK = set(_RESTYPES) | {'pb_version', 'pb_roctx_available'}
 
 
 def exported_names():

@@ -882,6 +882,10 @@ static int transit_launch(double *depth_d, int32_t *ideep_d, double *spectrum_d,
         k_transit_tau<kRowsPerThread, false><<<grid, threads, lds, pb::as_stream(stream)>>>(
             depth_d, ec_d, raypath_d, itop, ibottom, nlayers, nwave);
     PB_LAUNCH_CHECK();
+    // end of the reference's 'odepth' stage when this call also integrates the spectrum (the
+    // finish pass resolves the early exit AND integrates: it is counted as 'spectrum')
+    if (spectrum_d)
+        pb::stage_boundary("odepth", "spectrum", pb::as_stream(stream));
     // radiative_transfer.py:63: the deck matters only when it lies below the top layer
     const int deck_row = deck_itop > itop ? deck_itop - itop : -1;
     k_transit_finish<<<pb::div_up(nwave, threads), threads, 0, pb::as_stream(stream)>>>(

@@ -35,6 +35,13 @@ inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s);
 // be provided (out of memory, or it would have to grow while the stream is being captured)
 void *stream_scratch(hipStream_t s, size_t bytes);
 
+// rocTX range around a stage or a collective (no-ops without the profiler's marker library);
+// stage_boundary: a fused entry point tells the calling thread's running pb_timer, if any, that
+// the stage `name` ends here (pb_core.hip)
+void range_push(const char *name);
+void range_pop();
+void stage_boundary(const char *name, const char *next_stage, hipStream_t s);
+
 #define PB_HIP(expr)                                                              \
     do {                                                                          \
         hipError_t e_ = (expr);                                                   \

@@ -1,10 +1,14 @@
 // Library-level entry points: error reporting, device selection.
 #include "pb_common.h"
 
+#include <dlfcn.h>
+
 #include <algorithm>
 #include <map>
 #include <mutex>
+#include <string>
 #include <utility>
+#include <vector>
 
 namespace pb {
 
@@ -55,9 +59,202 @@ void *stream_scratch(hipStream_t s, size_t bytes)
     return e.p;
 }
 
+// ---------------------------------------------------------------------------
+// rocTX ranges (what rocprofv3 --marker-trace shows): resolved once from the profiler SDK's
+// marker library when it is on the loader path, otherwise no-ops.  This is a profiling aid
+// only -- nothing on the compute path depends on it.
+// ---------------------------------------------------------------------------
+namespace {
+struct Roctx {
+    int (*push)(const char *) = nullptr;
+    int (*pop)() = nullptr;
+    Roctx()
+    {
+        if (const char *e = getenv("PB_ROCTX"))
+            if (atoi(e) == 0)
+                return;
+        for (const char *name : {"librocprofiler-sdk-roctx.so.1", "librocprofiler-sdk-roctx.so",
+                                 "libroctx64.so.4", "libroctx64.so"}) {
+            void *h = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+            if (!h)
+                continue;
+            push = reinterpret_cast<int (*)(const char *)>(dlsym(h, "roctxRangePushA"));
+            pop = reinterpret_cast<int (*)()>(dlsym(h, "roctxRangePop"));
+            if (push && pop)
+                return;
+            push = nullptr;
+            pop = nullptr;
+        }
+    }
+};
+const Roctx &roctx()
+{
+    static const Roctx r;
+    return r;
+}
+thread_local pb_timer *t_timer = nullptr;    // timer the fused calls of this thread mark
+}  // namespace
+
+void range_push(const char *name)
+{
+    if (roctx().push)
+        roctx().push(name);
+}
+
+void range_pop()
+{
+    if (roctx().pop)
+        roctx().pop();
+}
+
+}  // namespace pb
+
+// Stage timer: HIP events recorded on the caller's stream at the END of each named stage, read
+// back lazily (Pyrat.timestamps: pyratbay/pyrat/pyrat_obj.py:203-214, tools/tools.py:832-843).
+struct pb_timer {
+    std::vector<hipEvent_t> ev;          // ev[0] = start, ev[i + 1] = end of stage i
+    std::vector<std::string> names;
+    int used = 0;                        // events recorded since the last start
+    int open_ranges = 0;
+};
+
+namespace pb {
+
+// called by fused entry points between their internal stages
+void stage_boundary(const char *name, const char *next_stage, hipStream_t s)
+{
+    pb_timer *t = t_timer;
+    if (!t || t->used == 0 || t->used >= (int)t->ev.size())
+        return;
+    if (hipEventRecord(t->ev[t->used], s) != hipSuccess) {
+        (void)hipGetLastError();
+        return;
+    }
+    t->names[t->used - 1] = name;
+    t->used++;
+    if (t->open_ranges > 0) {
+        range_pop();
+        t->open_ranges--;
+        if (next_stage) {
+            range_push(next_stage);
+            t->open_ranges++;
+        }
+    }
+}
+
 }  // namespace pb
 
 extern "C" {
+
+int pb_range_push(const char *name)
+{
+    PB_REQUIRE(name, "pb_range_push: null name");
+    pb::range_push(name);
+    return PB_OK;
+}
+
+int pb_range_pop(void)
+{
+    pb::range_pop();
+    return PB_OK;
+}
+
+int pb_roctx_available(void) { return pb::roctx().push != nullptr ? 1 : 0; }
+
+int pb_timer_create(pb_timer **out, int max_stages)
+{
+    PB_REQUIRE(out && max_stages >= 1 && max_stages <= 64, "pb_timer_create: bad argument");
+    *out = nullptr;
+    pb_timer *t = new (std::nothrow) pb_timer();
+    if (!t)
+        return PB_ERR_NOMEM;
+    for (int i = 0; i <= max_stages; i++) {
+        hipEvent_t e;
+        if (hipEventCreate(&e) != hipSuccess) {
+            pb::set_error("pb_timer_create: hipEventCreate failed");
+            pb_timer_destroy(t);
+            return PB_ERR_HIP;
+        }
+        t->ev.push_back(e);
+    }
+    t->names.assign((size_t)max_stages, std::string());
+    *out = t;
+    return PB_OK;
+}
+
+int pb_timer_start(pb_timer *t, const char *first_stage, void *stream)
+{
+    PB_REQUIRE(t, "pb_timer_start: null timer");
+    while (t->open_ranges > 0) {
+        pb::range_pop();
+        t->open_ranges--;
+    }
+    PB_HIP(hipEventRecord(t->ev[0], pb::as_stream(stream)));
+    t->used = 1;
+    pb::t_timer = t;
+    if (first_stage) {
+        pb::range_push(first_stage);
+        t->open_ranges = 1;
+    }
+    return PB_OK;
+}
+
+int pb_timer_mark(pb_timer *t, const char *name, const char *next_stage, void *stream)
+{
+    PB_REQUIRE(t && name, "pb_timer_mark: null pointer");
+    PB_REQUIRE(t->used >= 1, "pb_timer_mark: timer not started");
+    PB_REQUIRE(t->used < (int)t->ev.size(), "pb_timer_mark: more than %d stages",
+               (int)t->ev.size() - 1);
+    PB_HIP(hipEventRecord(t->ev[t->used], pb::as_stream(stream)));
+    t->names[t->used - 1] = name;
+    t->used++;
+    if (t->open_ranges > 0) {
+        pb::range_pop();
+        t->open_ranges--;
+    }
+    if (next_stage) {
+        pb::range_push(next_stage);
+        t->open_ranges++;
+    }
+    return PB_OK;
+}
+
+int pb_timer_count(const pb_timer *t, int *nstages)
+{
+    PB_REQUIRE(t && nstages, "pb_timer_count: null pointer");
+    *nstages = t->used > 0 ? t->used - 1 : 0;
+    return PB_OK;
+}
+
+int pb_timer_read(pb_timer *t, int stage, char *name_out, int name_cap, double *seconds)
+{
+    PB_REQUIRE(t && seconds, "pb_timer_read: null pointer");
+    PB_REQUIRE(stage >= 0 && stage + 1 < t->used, "pb_timer_read: stage %d was not recorded", stage);
+    PB_HIP(hipEventSynchronize(t->ev[stage + 1]));
+    float ms = 0.f;
+    PB_HIP(hipEventElapsedTime(&ms, t->ev[stage], t->ev[stage + 1]));
+    *seconds = 1e-3 * (double)ms;
+    if (name_out && name_cap > 0) {
+        strncpy(name_out, t->names[stage].c_str(), (size_t)name_cap - 1);
+        name_out[name_cap - 1] = 0;
+    }
+    return PB_OK;
+}
+
+void pb_timer_destroy(pb_timer *t)
+{
+    if (!t)
+        return;
+    if (pb::t_timer == t)
+        pb::t_timer = nullptr;
+    while (t->open_ranges > 0) {
+        pb::range_pop();
+        t->open_ranges--;
+    }
+    for (hipEvent_t e : t->ev)
+        (void)hipEventDestroy(e);
+    delete t;
+}
 
 const char *pb_last_error(void) { return pb::g_error; }
 

@@ -83,6 +83,7 @@ struct LblArgs {
     const int32_t *wm_lo[2];
     const int32_t *wm_off[2];
     int wm_n[2];
+    int wm_lds;                       // the offsets of map 0 are copied to LDS (else bisected in global memory)
     int64_t wm_total[2];
     // resident-profile kernel: which layers it computes, its LDS capacity (doubles, 0 = off)
     // and, per isotope, the first position-sorted group at or after every output sample

@@ -551,7 +551,7 @@ __global__ __launch_bounds__(kBlock) void k_records(LblArgs a)
         s_iext[e] = a.isoiext[e];
     }
     int32_t *s_wm = reinterpret_cast<int32_t *>(s_iext + a.niso);  // [wm_n[0] + 1] run offsets
-    if (a.wm_off[0])
+    if (a.wm_off[0] && a.wm_lds)
         for (int e = threadIdx.x; e <= a.wm_n[0]; e += kBlock)
             s_wm[e] = a.wm_off[0][e];
     __syncthreads();
@@ -570,7 +570,7 @@ __global__ __launch_bounds__(kBlock) void k_records(LblArgs a)
             const int m = kPos ? 1 : 0;
             g = a.ngroups;
             if (t < a.wm_total[m]) {
-                const int32_t *off = kPos ? a.wm_off[1] : s_wm;
+                const int32_t *off = (kPos || !a.wm_lds) ? a.wm_off[m] : s_wm;
                 int lo = 0, hi = a.wm_n[m];                    // last run with off[run] <= t
                 while (hi - lo > 1) {
                     const int mid = (lo + hi) >> 1;
@@ -2304,6 +2304,10 @@ int pb_lbl_create(pb_lbl **out, pb_voigt *voigt, pb_lines *lines, const double *
     alloc((void **)&p->kmax_bits, L * (size_t)rows * 8);
     alloc((void **)&p->ls_resident, L * 4);
     alloc((void **)&p->ls_block, L * 4);
+    // the whole buffer is what a multi-GPU run all-reduces (pb_lbl_kmax_buffer): slots beyond the
+    // rows of a call must not hold whatever the allocation did
+    if (rc == PB_OK && hipMemset(p->kmax_bits, 0, L * (size_t)rows * 8) != hipSuccess)
+        rc = PB_ERR_HIP;
     if (rc == PB_OK && !resolution) {
         // groups re-sorted by (isotope, iown mod osamp, iown): all lines that read the same
         // phase row of a profile become neighbours (k_ext_staged)
@@ -2481,14 +2485,22 @@ static int lbl_extinction(pb_lbl *p, double *ext_d, int64_t wbegin, int64_t wcou
                           int64_t z_iso_stride, int64_t z_layer_stride, int nlayers, int add,
                           void *stream, int phase)
 {
-    PB_REQUIRE(p && ext_d && temp_d && dens_d && isoz_d, "pb_lbl_extinction: null pointer");
+    PB_REQUIRE(p, "pb_lbl_extinction: null handle");
+    PB_REQUIRE(wcount == 0 || (ext_d && temp_d && dens_d && isoz_d),
+               "pb_lbl_extinction: null pointer");
     PB_REQUIRE(nlayers >= 1 && nlayers <= p->max_layers,
                "pb_lbl_extinction: nlayers=%d outside [1,%d]", nlayers, p->max_layers);
     PB_REQUIRE(wbegin >= 0 && wcount >= 0 && wbegin + wcount <= p->nwave,
                "pb_lbl_extinction: shard [%lld,+%lld) outside the %d-sample grid",
                (long long)wbegin, (long long)wcount, p->nwave);
-    if (wcount == 0)
+    if (wcount == 0) {
+        // an empty shard of a two-phase call still takes part in the all-reduce(MAX) of the
+        // per-row maxima: it must contribute zeros, not what its previous call left behind
+        if (phase == 1)
+            PB_HIP(hipMemsetAsync(p->kmax_bits, 0, (size_t)p->max_layers * p->kmax_rows * 8,
+                                  pb::as_stream(stream)));
         return PB_OK;
+    }
     const pb_voigt *v = p->voigt;
     const pb_lines *l = p->lines;
     hipStream_t s = pb::as_stream(stream);
@@ -2841,9 +2853,19 @@ static int lbl_extinction(pb_lbl *p, double *ext_d, int64_t wbegin, int64_t wcou
             rec_threads = std::max<int64_t>(1, std::max(p->wm_total0, p->wm_total1));
         }
         dim3 grid(pb::div_up(rec_threads, kBlock), pb::div_up(nlayers, per));
-        const size_t rlds = (size_t)per * a.nrows * 8 + (size_t)a.ndop * 8 +
-                            (size_t)per * a.niso * (8 + 8 + 4) + (size_t)a.niso * (8 + 4) + 16 +
-                            ((size_t)a.wm_n[0] + 2) * 4;
+        // the run offsets of the phase-order window map go to LDS while they fit beside the rest
+        // in 48 KiB (niso * osamp + 1 words: the reference's default wnosamp of 2160 with 8
+        // isotopes is already 69 KiB); larger maps are bisected in global memory
+        const size_t rlds0 = (size_t)per * a.nrows * 8 + (size_t)a.ndop * 8 +
+                             (size_t)per * a.niso * (8 + 8 + 4) + (size_t)a.niso * (8 + 4) + 16;
+        const size_t wm_bytes = ((size_t)a.wm_n[0] + 2) * 4;
+        size_t wm_cap_lds = 48 * 1024;
+        if (const char *e = getenv("PB_WM_LDS_CAP"))
+            wm_cap_lds = (size_t)atol(e);
+        a.wm_lds = a.wm_off[0] && rlds0 + wm_bytes <= wm_cap_lds ? 1 : 0;
+        const size_t rlds = rlds0 + (a.wm_lds ? wm_bytes : 8);
+        PB_REQUIRE(rlds <= 64 * 1024, "pb_lbl_extinction: %zu B of LDS for the record kernel "
+                   "(too many isotopes / output rows)", rlds);
         const int fmt = a.rec32 ? 3 : (a.rec16 && a.nch_max > 1) ? 2 : a.rec16 ? 1 : 0;
         void (*krec)(LblArgs) =
             per == 1 ? (fmt == 3   ? k_records<3, 1>
@@ -2925,7 +2947,6 @@ static int lbl_extinction(pb_lbl *p, double *ext_d, int64_t wbegin, int64_t wcou
             const size_t need = (size_t)(rsplit - 1) * nlayers * a.nrows * wcount * 8;
             if (need > p->part_bytes) {
                 (void)hipFree(p->part);
-    (void)hipFree(p->d_wm);
                 p->part = nullptr;
                 p->part_bytes = 0;
                 if (hipMalloc(&p->part, need) != hipSuccess) {
@@ -3271,6 +3292,7 @@ void pb_lbl_destroy(pb_lbl *p)
     (void)hipFree(p->rec32);
     (void)hipFree(p->rec16);
     (void)hipFree(p->part);
+    (void)hipFree(p->d_wm);
     (void)hipFree(p->gs_start);
     (void)hipFree(p->ls_dnwn);
     (void)hipFree(p->ls_dwnstep);

@@ -29,6 +29,25 @@ import torch
 import torch.distributed as dist
 
 
+def _range(name):
+    """rocTX range around a collective (engine.profiler_range; the import is deferred so that the
+    gloo tests of this module run without the HIP library)."""
+    from .engine import profiler_range
+    return profiler_range(name)
+
+
+class _NoRange:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        return False
+
+
+def _coll_range(name, tensor):
+    return _range(name) if tensor.is_cuda else _NoRange()
+
+
 def _via_host(group=None):
     """True when the process group cannot move device tensors (gloo): used only to
     rehearse the multi-rank path on a box with fewer GPUs than ranks."""
@@ -36,21 +55,23 @@ def _via_host(group=None):
 
 
 def all_gather_flat(recv, send, group=None):
-    if _via_host(group) and send.is_cuda:
-        r, s_ = recv.cpu(), send.cpu()
-        dist.all_gather_into_tensor(r, s_, group=group)
-        recv.copy_(r)
-    else:
-        dist.all_gather_into_tensor(recv, send, group=group)
+    with _coll_range('all_gather', send):
+        if _via_host(group) and send.is_cuda:
+            r, s_ = recv.cpu(), send.cpu()
+            dist.all_gather_into_tensor(r, s_, group=group)
+            recv.copy_(r)
+        else:
+            dist.all_gather_into_tensor(recv, send, group=group)
 
 
 def all_to_all_flat(recv, send, group=None):
-    if _via_host(group) and send.is_cuda:
-        r, s_ = recv.cpu(), send.cpu()
-        dist.all_to_all_single(r, s_, group=group)
-        recv.copy_(r)
-    else:
-        dist.all_to_all_single(recv, send, group=group)
+    with _coll_range('all_to_all', send):
+        if _via_host(group) and send.is_cuda:
+            r, s_ = recv.cpu(), send.cpu()
+            dist.all_to_all_single(r, s_, group=group)
+            recv.copy_(r)
+        else:
+            dist.all_to_all_single(recv, send, group=group)
 
 
 class _Done:
@@ -69,7 +90,8 @@ def all_gather_flat_async(recv, send, group=None):
     if _via_host(group) and send.is_cuda:
         all_gather_flat(recv, send, group)
         return _Done()
-    return dist.all_gather_into_tensor(recv, send, group=group, async_op=True)
+    with _coll_range('all_gather_start', send):
+        return dist.all_gather_into_tensor(recv, send, group=group, async_op=True)
 
 
 def all_to_all_flat_async(recv, send, group=None):
@@ -79,7 +101,8 @@ def all_to_all_flat_async(recv, send, group=None):
     if _via_host(group) and send.is_cuda:
         all_to_all_flat(recv, send, group)
         return _Done()
-    return dist.all_to_all_single(recv, send, group=group, async_op=True)
+    with _coll_range('all_to_all_start', send):
+        return dist.all_to_all_single(recv, send, group=group, async_op=True)
 
 
 def shard_bounds(nwave, world):
@@ -132,12 +155,13 @@ def kmax_allreduce(group=None):
     nlayers x rows words, the only mid-path collective of the wavenumber decomposition
     (SURVEY 8e option 1; _extcoeff.c:225,265)."""
     def exchange(kmax):
-        if _via_host(group):
-            host = kmax.cpu()
-            dist.all_reduce(host, op=dist.ReduceOp.MAX, group=group)
-            kmax.copy_(host)
-        else:
-            dist.all_reduce(kmax, op=dist.ReduceOp.MAX, group=group)
+        with _coll_range('all_reduce_kmax', kmax):
+            if _via_host(group):
+                host = kmax.cpu()
+                dist.all_reduce(host, op=dist.ReduceOp.MAX, group=group)
+                kmax.copy_(host)
+            else:
+                dist.all_reduce(kmax, op=dist.ReduceOp.MAX, group=group)
     return exchange
 
 
@@ -145,7 +169,8 @@ def allreduce_bandflux(partial, heights=None, group=None):
     """Sum the per-shard partial band integrals, then apply the pass-band heights
     (spec_tools.py:232-233) -> bandflux on every rank."""
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
-        dist.all_reduce(partial, op=dist.ReduceOp.SUM, group=group)
+        with _coll_range('all_reduce_bandflux', partial):
+            dist.all_reduce(partial, op=dist.ReduceOp.SUM, group=group)
     return partial * heights if heights is not None else partial
 
 

@@ -48,6 +48,69 @@ def require_gpu():
 
 
 # --------------------------------------------------------------------------
+# Stage timers and profiler ranges
+# --------------------------------------------------------------------------
+class StageTimer:
+    """The reference's `pyrat.timestamps` for the device path (pyrat_obj.py:203-214 with the
+    Timer of tools/tools.py:832-843): seconds spent in each named stage since the previous
+    mark, measured with HIP events on the launch stream and resolved lazily -- start() and
+    mark() only enqueue an event, read() waits for the last one.  Every stage is also a rocTX
+    range (rocprofv3 --marker-trace)."""
+
+    def __init__(self, max_stages=8):
+        self._h = C.c_void_p()
+        call('pb_timer_create', C.byref(self._h), int(max_stages))
+
+    def start(self, first_stage=None):
+        call('pb_timer_start', self._h, None if first_stage is None else first_stage.encode(),
+             _stream())
+
+    def mark(self, name, next_stage=None):
+        call('pb_timer_mark', self._h, name.encode(),
+             None if next_stage is None else next_stage.encode(), _stream())
+
+    def read(self):
+        """{stage: seconds} of the stages marked since the last start(), in order."""
+        n = C.c_int(0)
+        call('pb_timer_count', self._h, C.byref(n))
+        out = {}
+        buf = C.create_string_buffer(64)
+        for i in range(n.value):
+            sec = C.c_double(0)
+            call('pb_timer_read', self._h, i, buf, 64, C.byref(sec))
+            key = buf.value.decode()
+            out[key] = out.get(key, 0.0) + sec.value
+        return out
+
+    def close(self):
+        if self._h:
+            call('pb_timer_destroy', self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class profiler_range:
+    """with profiler_range('all_gather'): ...  -- a rocTX range (no-op without the marker
+    library; rocprofv3 --marker-trace shows it beside the kernels)."""
+
+    def __init__(self, name):
+        self.name = name.encode()
+
+    def __enter__(self):
+        call('pb_range_push', self.name)
+        return self
+
+    def __exit__(self, *exc):
+        call('pb_range_pop')
+        return False
+
+
+# --------------------------------------------------------------------------
 # Voigt table
 # --------------------------------------------------------------------------
 class VoigtTable:
@@ -603,8 +666,11 @@ class LBLSpectrum:
     def __init__(self, case, rt_path='transit', wbegin=0, wcount=None, itop=0,
                  quadrature_mu=None, quadrature_weights=None, keep_flat=False,
                  voigt=None, lines=None, tint=0.0, flux_top=None, continuum=None,
-                 continuum_density=None):
+                 continuum_density=None, timestamps=True):
         require_gpu()
+        # per-stage HIP-event timers behind the `timestamps` property (the reference's
+        # pyrat.timestamps keys); timestamps=False: run() records no events
+        self._timer = StageTimer() if timestamps else None
         g, atm, ln, iso, vg = (case['grid'], case['atm'], case['lines'], case['iso'],
                                case['voigt'])
         self.case = case
@@ -746,15 +812,35 @@ class LBLSpectrum:
 
     def run(self):
         """One spectrum: the 'extinction', 'odepth' and 'spectrum' stages (the last two
-        fused for the transit geometry)."""
+        in one library call for the transit geometry, which marks their boundary itself)."""
+        t = self._timer
+        if t is not None:
+            t.start('extinction')
         self.extinction()
+        if t is not None:
+            t.mark('extinction', 'odepth')
         if self.rt_path == 'transit':
             self.spectrum, self.depth, self.ideep = transit_spectrum(
                 self.ec.view(self.nlayers, self.wcount), self.raypath, self.radius,
                 self.rstar, self.itop, self.nlayers, self.maxdepth)
+            if t is not None:
+                t.mark('spectrum')
             return self.spectrum
         self.optical_depth()
-        return self.rt()
+        if t is not None:
+            t.mark('odepth', 'spectrum')
+        out = self.rt()
+        if t is not None:
+            t.mark('spectrum')
+        return out
+
+    @property
+    def timestamps(self):
+        """Seconds of the last run() by stage, with the reference's keys 'extinction',
+        'odepth', 'spectrum' (pyrat_obj.py:203-214).  Waits for that run to finish."""
+        if self._timer is None:
+            raise _capi.PbError('this model was built with timestamps=False')
+        return self._timer.read()
 
 
 class SpectrumPipeline:
@@ -826,8 +912,10 @@ class TableSpectrum:
     layer temperatures, weights by the species densities, and runs optical depth + RT."""
 
     def __init__(self, etable, ttable, wn, radius, rstar, rt_path='transit', itop=0,
-                 maxdepth=10.0, quadrature_mu=None, quadrature_weights=None, continuum=None):
+                 maxdepth=10.0, quadrature_mu=None, quadrature_weights=None, continuum=None,
+                 timestamps=True):
         require_gpu()
+        self._timer = StageTimer() if timestamps else None
         self.continuum = continuum          # pyratbay_amd.continuum.Continuum or None
         self.etable = etable if isinstance(etable, torch.Tensor) else dev(etable)
         self.nspec, self.ntemp, self.nlayers, self.nwave = self.etable.shape
@@ -866,6 +954,9 @@ class TableSpectrum:
                              'line_sampling.py:426-427)')
         self.temp = temp if isinstance(temp, torch.Tensor) else dev(temp)
         dens = dens if isinstance(dens, torch.Tensor) else dev(dens)
+        t = self._timer
+        if t is not None:
+            t.start('extinction')
         interp_ec(self.ec, self.etable, self.ttable, self.temp, dens, 0, self.nlayers,
                   assign=True)
         if self.continuum is not None:
@@ -873,6 +964,8 @@ class TableSpectrum:
             # temperatures when the caller has them (no device -> host copy in the loop)
             self.continuum.add(self.ec, temp_host if temp_host is not None
                                else self.temp.cpu().numpy(), continuum_density)
+        if t is not None:
+            t.mark('extinction', 'odepth')
         if self.rt_path == 'transit':
             self.spectrum, self.depth, self.ideep = transit_spectrum(
                 self.ec, self.raypath, self.radius, self.rstar, self.itop, self.nlayers,
@@ -880,9 +973,21 @@ class TableSpectrum:
         else:
             self.depth, self.ideep = plane_parallel_optical_depth(
                 self.ec, self.intervals, self.itop, self.nlayers, self.maxdepth)
+            if t is not None:
+                t.mark('odepth', 'spectrum')
             self.spectrum = emission_flux(self.depth, self.ideep, self.wn, self.temp, self.mu,
                                           self.weights, self.itop)
+        if t is not None:
+            t.mark('spectrum')
         return self.spectrum
+
+    @property
+    def timestamps(self):
+        """Seconds of the last eval() by stage: 'extinction' (interpolation of the table +
+        continuum terms), 'odepth', 'spectrum' -- the reference's keys (pyrat_obj.py:203-214)."""
+        if self._timer is None:
+            raise _capi.PbError('this model was built with timestamps=False')
+        return self._timer.read()
 
     def eval_bands(self, temps, dens, bands, radius=None, chunk=64):
         """Batched-walker evaluation (the inner loop of a retrieval, pyrat_obj.py:225-385

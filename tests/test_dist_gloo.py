@@ -246,3 +246,39 @@ def test_kmax_exchange_two_ranks(tmp_path):
     want = np.maximum(local[0], local[1])
     for rank in range(world):
         assert np.array_equal(np.load(tmp_path / f'k{rank}.npy'), want)
+
+
+def _bench(*argv, env=None):
+    import subprocess
+    e = dict(os.environ)
+    for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_PORT', 'MASTER_ADDR'):
+        e.pop(k, None)
+    e.update(env or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py')] + list(argv),
+                          capture_output=True, text=True, timeout=300, env=e, cwd=ROOT)
+
+
+def test_bench_self_launcher_two_ranks():
+    """`python bench.py --gpus 2` with no launcher around it: the parent (which never touches
+    the GPU) starts the two ranks itself with the rendezvous variables of
+    torch.distributed.run, relays rank 0's single JSON line and returns 0.  The child body here
+    is the launcher's CPU self-test (gloo all-reduce of rank + 1)."""
+    import json
+    r = _bench('--gpus', '2', '--selftest-launch', 'ok')
+    assert r.returncode == 0, r.stderr
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1                              # rank 0 only
+    rec = json.loads(lines[0])
+    assert rec['world'] == 2 and rec['sum'] == 3.0 and rec['local_rank'] == 0
+    assert rec['master'].startswith('127.0.0.1:')
+
+
+def test_bench_self_launcher_propagates_failure():
+    """A rank that dies takes the job down with its exit code (the others are terminated, not
+    left waiting in a rendezvous), and a launcher-provided WORLD_SIZE that disagrees with
+    --gpus is still refused."""
+    r = _bench('--gpus', '3', '--selftest-launch', 'fail')
+    assert r.returncode == 3
+    assert 'rank 1 exited with code 3' in r.stderr
+    r = _bench('--gpus', '2', '--selftest-launch', 'ok', env={'WORLD_SIZE': '4', 'RANK': '0'})
+    assert r.returncode != 0

@@ -190,3 +190,80 @@ def test_cutils_and_indices_like_test_src(hip, golden):
     np.testing.assert_allclose(out, g5['cumsum_out'], rtol=1e-14)
     idx = hip.cutils.arrbinsearch(np.array([0.1, 2.4, 2.6, 9.0]), np.array([1., 2., 3., 4.]))
     assert list(idx) == [0, 1, 2, 3] and idx.dtype == np.int32
+
+
+def _dropin_case():
+    from pyratbay_amd import engine, synth
+    case = synth.lbl_case(6001, 3, 30000, wnosamp=24, nlor=12, ndop=6, extent=60.0, cutoff=3.0,
+                          niso=2, seed=21)
+    g, vg = case['grid'], case['voigt']
+    vt = engine.VoigtTable.build(vg['lorentz'], vg['doppler'], vg['size'], g['ownstep'], 24, True)
+    profile, psize, pindex = vt.flat(), np.array(vt.size, int), np.array(vt.index, int)
+    vt.close()
+    return case, profile, psize, pindex
+
+
+def _dropin_call(hip, case, profile, psize, pindex, layer, lines=None):
+    g, atm, ln, iso, vg = (case[k] for k in ('grid', 'atm', 'lines', 'iso', 'voigt'))
+    ln = lines or ln
+    ext = np.zeros((1, g['nwave']))
+    hip._extcoeff.extinction(ext, profile, psize, pindex, vg['lorentz'], vg['doppler'], g['wn'],
+                             g['own'], g['divisors'].astype(int), atm['dens'][layer],
+                             atm['mol_radius'], atm['mol_mass'], iso['isoimol'].astype(int),
+                             iso['isomass'], iso['isoratio'], iso['isoz'][:, layer],
+                             iso['isoiext'].astype(int), ln['lwn'], ln['elow'], ln['gf'],
+                             ln['lid'].astype(int), vg['cutoff'], case['ethresh'],
+                             float(atm['temp'][layer]), 0, 1, 0)
+    return ext
+
+
+def test_extinction_cache_sees_in_place_edits(hip, monkeypatch):
+    """The drop-in keeps the Voigt table and the line list on the device between the per-layer
+    calls, keyed on the caller's buffers: identity + a 64-KiB probe per call, a full content
+    hash only for a buffer not seen before or whose probe changed.  An in-place edit of a cached
+    array (here: all line strengths scaled; the table scaled) must still be seen, an unchanged
+    buffer must not be re-hashed, and a different array of equal content must hit the cache."""
+    mod = hip._extcoeff
+    mod.invalidate()
+    case, profile, psize, pindex = _dropin_case()
+    full = []
+    real_digest = mod._digest
+    monkeypatch.setattr(mod, '_digest', lambda a: (full.append(np.asarray(a).nbytes),
+                                                   real_digest(a))[1])
+    base = _dropin_call(hip, case, profile, psize, pindex, 1)
+    first = len(full)
+    assert first >= 5                                   # table, own, the line arrays
+    again = _dropin_call(hip, case, profile, psize, pindex, 1)
+    assert np.array_equal(again, base) and len(full) == first      # probes only
+    voigt_before = mod._cache['voigt']
+    # equal content at another address: full hash of the new buffer, cached device copy kept
+    copy = {k: v.copy() for k, v in case['lines'].items()}
+    assert np.array_equal(_dropin_call(hip, case, profile, psize, pindex, 1, lines=copy), base)
+    assert len(full) > first and mod._cache['voigt'] is voigt_before
+    lines_before = mod._cache['lines']
+    # in-place edit of the line strengths: seen, and the result follows
+    case['lines']['gf'] *= 2.0
+    doubled = _dropin_call(hip, case, profile, psize, pindex, 1)
+    assert mod._cache['lines'] is not lines_before
+    nz = base != 0
+    np.testing.assert_allclose(doubled[nz], 2.0 * base[nz], rtol=1e-12)
+    # in-place edit of the table
+    profile *= 3.0
+    tripled = _dropin_call(hip, case, profile, psize, pindex, 1)
+    assert mod._cache['voigt'] is not voigt_before
+    np.testing.assert_allclose(tripled[nz], 6.0 * base[nz], rtol=1e-12)
+    mod.invalidate()
+    assert not mod._seen and not mod._cache
+
+
+def test_extinction_cache_without_xxhash(hip, monkeypatch):
+    """xxhash is optional: without it the content hashes come from hashlib (same results)."""
+    mod = hip._extcoeff
+    mod.invalidate()
+    case, profile, psize, pindex = _dropin_case()
+    want = _dropin_call(hip, case, profile, psize, pindex, 2)
+    mod.invalidate()
+    monkeypatch.setattr(mod, '_xxhash', None)
+    assert np.array_equal(_dropin_call(hip, case, profile, psize, pindex, 2), want)
+    assert np.array_equal(_dropin_call(hip, case, profile, psize, pindex, 2), want)
+    mod.invalidate()

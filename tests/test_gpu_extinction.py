@@ -663,3 +663,108 @@ def test_window_map_of_two_phase_shards(eng, monkeypatch, gather):
         assert torch.equal(e1, e0)
     assert torch.count_nonzero(on[3][1]) == 0          # the empty shard
     assert torch.count_nonzero(on[1][1]) > 0
+
+
+def test_rounds_split_keeps_the_window_map(eng, monkeypatch):
+    """Round 2 defect (ADVICE): the partial-sum reallocation of the `rounds` gather freed the
+    window map of two-phase shard calls while the plan's cache still described it; the next
+    begin() handed the dangling pointer to k_records.  Two begin/end calls on ONE plan with the
+    round gather split three ways (the second call re-uses the cached map after the partial sums
+    were allocated) must equal the one-call form bit for bit."""
+    import torch
+    from pyratbay_amd import synth
+    monkeypatch.setenv('PB_STAGE_SPLIT', '3')
+    case = synth.lbl_case(9001, 4, 30000, wnosamp=24, nlor=18, ndop=9, extent=80.0,
+                          cutoff=3.0, niso=3, seed=10)
+    g, atm, ln, iso, vg = (case[k] for k in ('grid', 'atm', 'lines', 'iso', 'voigt'))
+    vt = eng.VoigtTable.build(vg['lorentz'], vg['doppler'], vg['size'], g['ownstep'], 24)
+    ll = eng.LineList(ln['lwn'], ln['elow'], ln['gf'], ln['lid'], 3, g['own'])
+
+    def plan():
+        lbl = eng.LBL(vt, ll, g['wn'], g['divisors'], atm['mol_radius'], atm['mol_mass'],
+                      iso['isoimol'], iso['isomass'], iso['isoratio'], iso['isoiext'],
+                      vg['cutoff'], 1e-30, max_layers=4)
+        lbl.set_gather_mode('rounds')
+        return lbl
+    t, d, z = eng.dev(atm['temp']), eng.dev(atm['dens']), eng.dev(iso['isoz'])
+    a, b = 2000, 6500
+    one = plan()
+    want = one.extinction(t, d, z, add=True, wbegin=a, wcount=b - a).clone()
+    two = plan()
+    for trip in range(3):
+        got = two.extinction_begin(t, d, z, add=True, wbegin=a, wcount=b - a)
+        # a single "rank": its own maxima are NOT the global ones, so take them from the
+        # one-call plan (what the all-reduce would deliver)
+        two.kmax_tensor().copy_(one.kmax_tensor())
+        two.extinction_end()
+        assert torch.equal(got, want), trip
+
+
+@pytest.mark.parametrize('gather', ['staged', 'global'])
+def test_window_map_too_large_for_lds(eng, monkeypatch, gather):
+    """The run offsets of the phase-order window map are niso * osamp + 1 words: 16 isotopes at
+    wnosamp 840 are 54 KB, more than k_records keeps in LDS (nothing capped the
+    size; 20 isotopes at the reference's default wnosamp of 2160 exceeded the CU's 160 KB and the
+    launch failed).  Such maps are bisected in global memory: same records, maxima and sums as
+    with the map switched off, and as with the LDS form forced off on a small map."""
+    import torch
+    from pyratbay_amd import synth
+    monkeypatch.setenv('PB_STAGE_SPLIT', '1')
+    sp = ('H2', 'He', 'H2O', 'CO', 'CO2', 'CH4')
+    case = synth.lbl_case(1201, 3, 1500, wnosamp=840, nlor=6, ndop=4, extent=20.0, cutoff=1.0,
+                          niso=4, seed=11, species=sp, vmr=(0.85, 0.149, 4e-4, 5e-4, 1e-7, 1e-4),
+                          line_species=('H2O', 'CO', 'CO2', 'CH4'))
+    g, atm, ln, iso, vg = (case[k] for k in ('grid', 'atm', 'lines', 'iso', 'voigt'))
+    niso = len(iso['isomass'])
+    assert niso * g['wnosamp'] * 4 > 48 * 1024
+    iso['isoiext'] = np.zeros(niso, np.int32)
+    vt = eng.VoigtTable.build(vg['lorentz'], vg['doppler'], vg['size'], g['ownstep'], g['wnosamp'])
+    ll = eng.LineList(ln['lwn'], ln['elow'], ln['gf'], ln['lid'], niso, g['own'])
+    t, d, z = eng.dev(atm['temp']), eng.dev(atm['dens']), eng.dev(iso['isoz'])
+
+    def shard_results(env):
+        for k in ('PB_NO_WINDOW_MAP', 'PB_WM_LDS_CAP'):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        lbl = eng.LBL(vt, ll, g['wn'], g['divisors'], atm['mol_radius'], atm['mol_mass'],
+                      iso['isoimol'], iso['isomass'], iso['isoratio'], iso['isoiext'],
+                      vg['cutoff'], 1e-30, max_layers=3)
+        lbl.set_gather_mode(gather)
+        out = []
+        for a, b in ((0, 400), (400, 1000), (1000, 1201)):
+            ext = lbl.extinction_begin(t, d, z, add=True, wbegin=a, wcount=b - a)
+            kmax = lbl.kmax_tensor().clone()
+            lbl.extinction_end()
+            out.append((kmax, ext.clone()))
+        return out
+    big, off, huge_cap = (shard_results({}), shard_results({'PB_NO_WINDOW_MAP': '1'}),
+                          shard_results({'PB_WM_LDS_CAP': '65000'}))
+    for (k1, e1), (k0, e0), (k2, e2) in zip(big, off, huge_cap):
+        assert torch.equal(k1, k0) and torch.equal(e1, e0)
+        assert torch.equal(k2, k0) and torch.equal(e2, e0)
+    assert torch.count_nonzero(big[1][1]) > 0
+
+
+def test_empty_shard_contributes_zero_maxima(eng):
+    """An empty wavenumber shard (more ranks than samples, or a caller's uneven split) still
+    takes part in the all-reduce(MAX) of the per-row maxima: begin() must leave zeros there, not
+    the maxima of the plan's previous, hotter call."""
+    import torch
+    from pyratbay_amd import synth
+    case = synth.lbl_case(3001, 3, 4000, wnosamp=24, nlor=12, ndop=6, extent=60.0, cutoff=3.0,
+                          niso=2, seed=12)
+    g, atm, ln, iso, vg = (case[k] for k in ('grid', 'atm', 'lines', 'iso', 'voigt'))
+    vt = eng.VoigtTable.build(vg['lorentz'], vg['doppler'], vg['size'], g['ownstep'], 24)
+    ll = eng.LineList(ln['lwn'], ln['elow'], ln['gf'], ln['lid'], 2, g['own'])
+    lbl = eng.LBL(vt, ll, g['wn'], g['divisors'], atm['mol_radius'], atm['mol_mass'],
+                  iso['isoimol'], iso['isomass'], iso['isoratio'], iso['isoiext'],
+                  vg['cutoff'], 1e-30, max_layers=3)
+    t, d, z = eng.dev(atm['temp']), eng.dev(atm['dens']), eng.dev(iso['isoz'])
+    lbl.extinction_begin(t, d, z, add=True, wbegin=0, wcount=3001)
+    assert torch.count_nonzero(lbl.kmax_tensor()) > 0
+    lbl.extinction_end()
+    lbl.extinction_begin(t, d, z, add=True, wbegin=3001, wcount=0,
+                         out=torch.empty((3, 1, 0), dtype=torch.float64, device='cuda'))
+    assert torch.count_nonzero(lbl.kmax_tensor()) == 0
+    lbl.extinction_end()

@@ -336,3 +336,56 @@ def test_spectrum_pipeline_equals_serial_runs(eng, case, rt_path):
         assert len(got) == 2 * len(atmospheres)
         for i, g_ in enumerate(got):
             assert np.array_equal(g_, want[i % len(atmospheres)]), (depth, i)
+
+
+@pytest.mark.parametrize('rt_path', ['transit', 'emission'])
+def test_stage_timestamps_like_the_reference(eng, case, rt_path):
+    """run() fills `timestamps` with the reference's keys -- 'extinction', 'odepth', 'spectrum'
+    (pyrat_obj.py:203-214), seconds per stage -- from HIP events resolved when read.  Their sum
+    is bracketed by the wall time of a synchronised run; switching the timers off changes no
+    result bit; the transit geometry (ONE library call for optical depth + transmission) still
+    reports the two stages separately."""
+    import time
+    import torch
+    model = eng.LBLSpectrum(case, rt_path=rt_path)
+    model.run()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    want = model.run().clone()
+    ts = model.timestamps                      # waits for the run
+    wall = time.perf_counter() - t0
+    assert list(ts) == ['extinction', 'odepth', 'spectrum']
+    assert all(v > 0.0 for v in ts.values())
+    assert sum(ts.values()) <= wall * 1.05 + 1e-4
+    assert ts['extinction'] > ts['spectrum'] * 0.2      # the line-by-line stage is not a no-op
+    plain = eng.LBLSpectrum(case, rt_path=rt_path, voigt=model.voigt, lines=model.lines,
+                            timestamps=False)
+    assert torch.equal(plain.run(), want)
+    with pytest.raises(Exception):
+        plain.timestamps
+    # a second run replaces the first one's stamps; a range can be opened around anything
+    with eng.profiler_range('second run'):
+        model.run()
+    assert list(model.timestamps) == ['extinction', 'odepth', 'spectrum']
+
+
+def test_stage_timer_api(eng):
+    """The C-ABI timer on its own: stages in order, duplicates summed, errors for a timer that
+    was not started or is full."""
+    import torch
+    t = eng.StageTimer(max_stages=3)
+    with pytest.raises(Exception):
+        t.mark('early')
+    t.start('a')
+    x = torch.ones(1 << 20, device='cuda')
+    t.mark('a', 'b')
+    x = (x * 2).sum()
+    t.mark('b', 'a')
+    t.mark('a')
+    with pytest.raises(Exception):
+        t.mark('overflow')
+    got = t.read()
+    assert list(got) == ['a', 'b'] and all(v >= 0.0 for v in got.values())
+    t.start()
+    assert t.read() == {}
+    t.close()
