@@ -491,9 +491,21 @@ def main():
             # Only where a launch has a tail worth filling: at 1e6 samples a spectrum is tens of
             # milliseconds of full-chip launches and a second one in flight gains nothing
             # (C3: 47.5 against 45.6 ms, C4: 254 against 250.5), so those run one at a time.
+            # With N > 1 the wavenumber shards are pipelined the same way (dist.ShardPipeline:
+            # the next spectrum's extinction beside this one's collectives; PB_STREAMS=1: off).
             streams = 2 if nwave <= 200000 else 1
-            streams = int(os.environ.get('PB_STREAMS', streams)) if world == 1 or replicas else 1
-            if streams > 1:
+            if world > 1 and not replicas and streams > 1:
+                streams = 3         # a rank-size launch is short: one more hides the collectives
+            streams = int(os.environ.get('PB_STREAMS', streams))
+            exchange = os.environ.get('PB_KMAX_EXCHANGE', '1') != '0'
+            if streams > 1 and world > 1 and not replicas:
+                from pyratbay_amd.dist import ShardPipeline
+                pipe = ShardPipeline(case, world, rank, depth=streams, kmax_exchange=exchange,
+                                     voigt=shared.get('voigt'), lines=shared.get('lines'),
+                                     rt_path=rt_path)
+                model, gather = pipe.models[0], pipe.gathers[0]
+                res['streams'] = streams
+            elif streams > 1:
                 pipe = engine.SpectrumPipeline(case, depth=streams, rt_path=rt_path,
                                                voigt=shared.get('voigt'),
                                                lines=shared.get('lines'))
@@ -503,9 +515,9 @@ def main():
                 model = engine.LBLSpectrum(case, rt_path=rt_path, wbegin=gather.wbegin,
                                            wcount=gather.wcount, voigt=shared.get('voigt'),
                                            lines=shared.get('lines'))
-            if world > 1 and not replicas and os.environ.get('PB_KMAX_EXCHANGE', '1') != '0':
-                from pyratbay_amd.dist import kmax_allreduce
-                model.kmax_exchange = kmax_allreduce()     # records of the shard's groups only
+                if world > 1 and not replicas and exchange:
+                    from pyratbay_amd.dist import kmax_allreduce
+                    model.kmax_exchange = kmax_allreduce()     # records of the shard's groups only
             res.update(wcount=gather.wcount, nlayers_rank=nlayers)
             pipelined = False
 
@@ -533,6 +545,25 @@ def main():
                 out = step()
             return [out]
 
+        if world > 1 and kind != 'replicas':
+            # parity BEFORE anything is timed: the re-assembled spectrum of this decomposition
+            # (collectives included) against the same spectrum computed whole on this rank's
+            # own GPU.  A rank-size launch splits the phases of a tile differently from the
+            # full-grid one, so the two agree to ~1e-13, not bit for bit; the bar is 1e-10.
+            if 'reference_spectrum' not in shared:
+                whole = engine.LBLSpectrum(case, rt_path=rt_path, voigt=model.voigt,
+                                           lines=model.lines, timestamps=False)
+                shared['reference_spectrum'] = whole.run().clone()
+                del whole
+            got = run_steps(2)[-1]
+            torch.cuda.synchronize()
+            err = torch.max(torch.abs(got / shared['reference_spectrum'] - 1.0)).reshape(1)
+            err = err.to(dev_reduce)
+            dist.all_reduce(err, op=dist.ReduceOp.MAX)
+            res['parity_vs_single_gpu'] = float(err.item())
+            if not res['parity_vs_single_gpu'] <= 1e-10:
+                raise RuntimeError(f'{kind}: sharded spectrum differs from the single-GPU one '
+                                   f"by {res['parity_vs_single_gpu']:.3e} (bar 1e-10)")
         if world == 1 and nwave <= 200000:
             # the same W + K steps BEFORE the priming spectra below (config.cold_value): what a
             # caller sees who runs a few dozen spectra on a chip that was idle
@@ -703,7 +734,9 @@ def main():
             par = (f'layer-sharded extinction x{world} + all-to-all + wavenumber-sharded RT + '
                    'all-gather' + (', consecutive spectra pipelined' if pipelined else ''))
         else:
-            par = f'wavenumber shards x{world} + all-gather'
+            par = (f'wavenumber shards x{world} + all-reduce(MAX) of the line-strength maxima + '
+                   'all-gather' + (f", {primary['streams']} spectra in flight per rank"
+                                   if pipelined else ''))
         out = {
             'metric': 'spectra/sec (1e5 wavenumbers x 80 layers)',
             'value': value, 'unit': 'spectra/s', 'n_gpus': world, 'steps': args.steps,
@@ -730,8 +763,9 @@ def main():
             # both decompositions of the same run
             out['config']['value_from'] = primary['kind']
             out['config']['decompositions'] = [
-                {k: r[k] for k in ('kind', 'value', 'ms_per_step', 'pipelined',
-                                   'unpipelined_ms_per_spectrum', 'init_seconds') if k in r}
+                {k: r[k] for k in ('kind', 'value', 'ms_per_step', 'pipelined', 'streams',
+                                   'unpipelined_ms_per_spectrum', 'parity_vs_single_gpu',
+                                   'init_seconds') if k in r}
                 for r in runs] + failed
         if want_cpu:
             budget = args.cpu_layers or (nlayers if args.workload in ('c2', 'small') else 16)

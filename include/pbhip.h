@@ -148,6 +148,11 @@ int pb_lbl_set_ethresh(pb_lbl *p, double ethresh);
  * plus 8 when the resident-profile kernel ran as well. */
 int pb_lbl_set_gather_mode(pb_lbl *p, int mode);
 int pb_lbl_last_gather_mode(const pb_lbl *p, int *mode);
+/* Hint: the caller keeps n independent calls in flight on n streams (the reference's callers
+ * with independent spectra: the temperature loop of pyrat/extinction.py:100-122, the walkers of
+ * a retrieval; here also the pipelined shards of a multi-GPU rank).  Changes only how a small
+ * launch is tiled (fewer, longer workgroups: the other streams fill the chip), never a term. */
+int pb_lbl_set_concurrency(pb_lbl *p, int n);
 /* ext_d[nlayers, nrows, wcount] with nrows = 1 if add else (max isoiext)+1, for the
  * output samples [wbegin, wbegin+wcount) of the global grid (wavenumber shard).
  * temp_d[nlayers]; dens_d[nlayers, nmol]; isoz_d element (i,l) at

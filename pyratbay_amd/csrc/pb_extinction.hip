@@ -1994,6 +1994,7 @@ struct pb_lbl {
     int64_t wm_total0 = 0, wm_total1 = 0;
     int32_t *gs_start = nullptr;      // [niso][nwave+1]
     int res_cap = 0;                  // LDS doubles of one resident profile block (0 = none fits)
+    int concurrency = 1;     // independent calls the caller keeps in flight beside this plan's
     int gather_mode = 0;     // 0 = choose, 1 = global gather, 2 = LDS-staged, 3 = resident+global
     int last_gather = 0;     // last call: 1 global, 2 staged, 3 linterp; +8 = resident kernel too
     double stage_threshold = 8.0;   // groups per (2048-sample tile, phase) to go staged
@@ -2464,6 +2465,13 @@ int pb_lbl_set_gather_mode(pb_lbl *p, int mode)
     return PB_OK;
 }
 
+int pb_lbl_set_concurrency(pb_lbl *p, int n)
+{
+    PB_REQUIRE(p && n >= 1, "pb_lbl_set_concurrency: n must be >= 1");
+    p->concurrency = n;
+    return PB_OK;
+}
+
 int pb_lbl_last_gather_mode(const pb_lbl *p, int *mode)
 {
     PB_REQUIRE(p && mode, "pb_lbl_last_gather_mode: null pointer");
@@ -2668,9 +2676,18 @@ static int lbl_extinction(pb_lbl *p, double *ext_d, int64_t wbegin, int64_t wcou
     // The partial sums stay below 1 GB.
     const int64_t sub = kStagedWaves * kStageSpan;
     const int64_t blocks2 = pb::div_up(wcount, 2 * sub) * (int64_t)nlayers;
+    // With other spectra in flight on other streams (pb_lbl_set_concurrency: the walkers of a
+    // retrieval, the pipelined shards of a multi-GPU rank) a launch need not fill the chip by
+    // itself: one round of workgroups (~1000) amortises the per-workgroup candidate search
+    // better.  A 1/8 wavenumber shard of C2, two-phase, per spectrum: one at a time 0.269-0.277
+    // ms whatever the split; two in flight 0.211 (3 workgroups per 4096-sample tile = 960, one round; 4 per tile: 0.232) against
+    // 0.240 (7 per 2048-sample tile, the one-at-a-time rule); three in flight 0.190 against 0.236.
+    const bool shared_chip = p->concurrency > 1 && per_phase < 64.0;
     int S = 2;
     int nsplit = (int)std::min<int64_t>(
         8, pb::div_up((int64_t)(per_phase >= 64.0 ? 8000 : 2000), std::max<int64_t>(1, blocks2)));
+    if (shared_chip)           // at most one round of workgroups on the chip's 1024 slots
+        nsplit = (int)std::max<int64_t>(1, std::min<int64_t>(8, 1024 / std::max<int64_t>(1, blocks2)));
     {
         const int64_t plane = (int64_t)nlayers * a.nrows * wcount * 8;
         while (nsplit > 1 && (nsplit - 1) * plane > ((int64_t)1 << 30))
@@ -2684,7 +2701,7 @@ static int lbl_extinction(pb_lbl *p, double *ext_d, int64_t wbegin, int64_t wcou
         // depend on S (tests/test_gpu_extinction.py::test_staged_variants_agree).
         const double w2 = (double)pb::div_up(wcount, 2 * sub) * 2 * sub / (double)wcount;
         const double w1 = (double)pb::div_up(wcount, sub) * sub / (double)wcount;
-        if (w2 - w1 > 0.12)
+        if (w2 - w1 > 0.12 && !shared_chip)
             S = 1;
     }
     if (const char *e = getenv("PB_STAGE_S"))

@@ -373,6 +373,66 @@ class ExchangePipeline:
         return out
 
 
+class ShardPipeline:
+    """Consecutive, independent spectra of a WAVENUMBER-sharded run kept in flight per rank:
+    spectrum i+1's extinction runs on a second HIP stream while spectrum i waits for its
+    collectives (the all-reduce of the per-row maxima in the middle of the path, the closing
+    all-gather) and finishes its small launches.
+
+    Why: a 1/8 shard of C2 is ~0.27 ms of launches of which the gather -- the only one that
+    fills the chip -- is 0.17; every collective is a latency a single spectrum sits through.
+    With two spectra in flight a rank delivers one per ~0.21 ms (tools/bench_wshard.py), and the
+    N = 1 form of bench.py pipelines in the same way (engine.SpectrumPipeline), so the N-GPU and
+    the single-GPU numbers are like for like.
+
+    Every context has its own plan and its own SpectrumGather buffers; the Voigt table and the
+    line list are shared.  Every rank issues the collectives of spectrum i, then those of
+    spectrum i+1, in program order on one communicator, so they pair up across the ranks.
+    submit() -> (full spectrum on every rank, event); flush() joins the caller's stream."""
+
+    def __init__(self, case, world, rank, depth=2, group=None, kmax_exchange=True,
+                 voigt=None, lines=None, rt_path='transit'):
+        from . import engine
+        nwave = case['grid']['nwave']
+        self.world, self.rank, self.group = world, rank, group
+        self.gathers = [SpectrumGather(nwave, world, rank, 'cuda', group) for _ in range(depth)]
+        g0 = self.gathers[0]
+        kw = dict(rt_path=rt_path, wbegin=g0.wbegin, wcount=g0.wcount)
+        first = engine.LBLSpectrum(case, voigt=voigt, lines=lines, **kw)
+        self.models = [first] + [engine.LBLSpectrum(case, voigt=first.voigt, lines=first.lines,
+                                                    **kw) for _ in range(depth - 1)]
+        for m in self.models:
+            m.lbl.set_concurrency(depth)
+            if kmax_exchange and world > 1:
+                m.kmax_exchange = kmax_allreduce(group)
+        self.streams = [torch.cuda.Stream() for _ in range(depth)]
+        self.done = [None] * depth
+        self.count = 0
+
+    def set_atmosphere(self, *args, **kw):
+        for m in self.models:
+            m.set_atmosphere(*args, **kw)
+
+    def submit(self):
+        j = self.count % len(self.models)
+        self.count += 1
+        model, stream, gather = self.models[j], self.streams[j], self.gathers[j]
+        caller = torch.cuda.current_stream()
+        stream.wait_stream(caller)
+        with torch.cuda.stream(stream):
+            full = gather(model.run())
+            event = torch.cuda.Event()
+            event.record(stream)
+        self.done[j] = event
+        return full, event
+
+    def flush(self):
+        cur = torch.cuda.current_stream()
+        for event in self.done:
+            if event is not None:
+                cur.wait_event(event)
+
+
 def walker_slice(nwalkers, world, rank):
     """Replica parallelism for retrieval: every GPU holds the
     full cross-section table and evaluates a contiguous slice of the walker batch."""

@@ -249,6 +249,10 @@ class LBL:
         """'auto' | 'global' | 'staged' | 'resident' (see pbhip.h: pb_lbl_set_gather_mode)."""
         call('pb_lbl_set_gather_mode', self._h, self.GATHER[mode])
 
+    def set_concurrency(self, n):
+        """The caller keeps n independent spectra in flight (pb_lbl_set_concurrency)."""
+        call('pb_lbl_set_concurrency', self._h, int(n))
+
     @property
     def last_gather_kernel(self):
         m = C.c_int(0)
@@ -866,6 +870,8 @@ class SpectrumPipeline:
         first = LBLSpectrum(case, **kw)
         kw = dict(kw, voigt=first.voigt, lines=first.lines)
         self.models = [first] + [LBLSpectrum(case, **kw) for _ in range(depth - 1)]
+        for m in self.models:
+            m.lbl.set_concurrency(depth)
         self.streams = [torch.cuda.Stream() for _ in range(depth)]
         self.done = [None] * depth          # completion event of each context's last spectrum
         self.count = 0

@@ -389,3 +389,30 @@ def test_stage_timer_api(eng):
     t.start()
     assert t.read() == {}
     t.close()
+
+
+def test_shard_pipeline_single_process(eng, case):
+    """dist.ShardPipeline (the multi-GPU wavenumber form with several spectra in flight per
+    rank) in its one-rank form: every submitted spectrum equals LBLSpectrum.run() of the same
+    atmosphere; the concurrency hint changes the tiling of a launch, never a term (1e-12)."""
+    import torch
+    from pyratbay_amd.dist import ShardPipeline
+    serial = eng.LBLSpectrum(case, rt_path='transit')
+    want = serial.run().clone()
+    pipe = ShardPipeline(case, 1, 0, depth=3, voigt=serial.voigt, lines=serial.lines)
+    outs = []
+    for _ in range(5):
+        full, event = pipe.submit()
+        event.synchronize()
+        outs.append(full.clone())
+    pipe.flush()
+    torch.cuda.synchronize()
+    for o in outs:
+        np.testing.assert_allclose(o.cpu().numpy(), want.cpu().numpy(), rtol=1e-12)
+    # a plan told about the other spectra in flight gives the same extinction
+    hinted = eng.LBLSpectrum(case, rt_path='transit', voigt=serial.voigt, lines=serial.lines)
+    hinted.lbl.set_concurrency(4)
+    hinted.run()
+    np.testing.assert_allclose(hinted.ec.cpu().numpy(), serial.ec.cpu().numpy(), rtol=1e-12)
+    with pytest.raises(Exception):
+        hinted.lbl.set_concurrency(0)
