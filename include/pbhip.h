@@ -153,6 +153,16 @@ int pb_lbl_last_gather_mode(const pb_lbl *p, int *mode);
  * a retrieval; here also the pipelined shards of a multi-GPU rank).  Changes only how a small
  * launch is tiled (fewer, longer workgroups: the other streams fill the chip), never a term. */
 int pb_lbl_set_concurrency(pb_lbl *p, int n);
+/* Out-of-core line lists.  The reference walks any number of lines sequentially
+ * (src_c/_extcoeff.c:203-309; the "computer-intensive" opacity-table run,
+ * pyratbay/pyrat/extinction.py:100-122, reads whole line databases).  Here a call keeps one
+ * 16-byte record per (layer, co-add group); when those exceed `bytes` (default 96 GiB) the call
+ * is made in chunks of the line list: one pass for the per-species maxima of all lines
+ * (_extcoeff.c:203-226), then per chunk the records and a gather that continues the running
+ * sums -- the same terms in the same order as an unchunked call with one workgroup per tile
+ * (PB_STAGE_SPLIT=1), hence bit-identical to it.  last_chunks: chunks of the last call (0 = none). */
+int pb_lbl_set_record_budget(pb_lbl *p, int64_t bytes);
+int pb_lbl_last_chunks(const pb_lbl *p, int *chunks);
 /* ext_d[nlayers, nrows, wcount] with nrows = 1 if add else (max isoiext)+1, for the
  * output samples [wbegin, wbegin+wcount) of the global grid (wavenumber shard).
  * temp_d[nlayers]; dens_d[nlayers, nmol]; isoz_d element (i,l) at

@@ -54,6 +54,8 @@ _PROTOS = {
     'pb_lbl_set_ethresh': [vp, f64],
     'pb_lbl_set_gather_mode': [vp, i32],
     'pb_lbl_set_concurrency': [vp, i32],
+    'pb_lbl_set_record_budget': [vp, i64],
+    'pb_lbl_last_chunks': [vp, C.POINTER(i32)],
     'pb_lbl_last_gather_mode': [vp, C.POINTER(i32)],
     'pb_lbl_extinction': [vp, vp, i64, i64, vp, vp, vp, i64, i64, i32, i32, vp],
     'pb_lbl_extinction_begin': [vp, vp, i64, i64, vp, vp, vp, i64, i64, i32, i32, vp],

@@ -100,6 +100,15 @@ struct LblArgs {
     // treats (phase, chunk) as a phase of its own.  Layout of a layer's records:
     // [phase p][chunk k][position] = ps*nch_max + k*cnt_p + (g - ps).  1 = no chunking.
     int nch_max;
+    // line lists whose packed records exceed the plan's record budget are walked in CHUNKS of
+    // consecutive (isotope, phase) keys of the phase-sorted group list: k_records and the staged
+    // gather then see the groups [grp_lo, grp_hi) only (records at rec16[layer*rec_pitch + g -
+    // grp_lo]), the gather walks the keys iso*osamp + phase in [key_lo, key_hi) and, from the
+    // second chunk on (accumulate), continues the running sums it finds in ext -- the same terms
+    // in the same order as one launch over every key.  Unchunked: grp = [0, ngroups),
+    // rec_pitch = ngroups, key = [0, niso*osamp), accumulate = 0.
+    int64_t grp_lo, grp_hi, rec_pitch;
+    int key_lo, key_hi, accumulate;
     // staged kernel, small launches: the phases of a tile are split between nsplit workgroups
     // (see the kernel's block decoding); split 0 writes ext, the others part[split-1][layer][row][sample]
     int nsplit;

@@ -563,7 +563,7 @@ __global__ __launch_bounds__(kBlock) void k_records(LblArgs a)
         // A wavenumber shard needs the records of the groups within reach of it only
         // [rec_flo, rec_fhi]; the others still count for the per-row maximum unless the caller
         // all-reduces the maxima of the shards (kmax_local: they are skipped altogether).
-        int64_t g = t;
+        int64_t g = kPos ? t : t + a.grp_lo;                    // (chunked calls: no kPos pass)
         if (a.wm_off[kPos ? 1 : 0]) {
             // run of the window map that holds thread t (the offsets of the phase-order map are
             // in LDS; the position-order map has one run per isotope)
@@ -582,7 +582,7 @@ __global__ __launch_bounds__(kBlock) void k_records(LblArgs a)
                 g = (int64_t)a.wm_lo[m][lo] + (t - off[lo]);
             }
         }
-        bool have = g < a.ngroups, inwin = false;
+        bool have = g < (kPos ? a.ngroups : a.grp_hi), inwin = false;
         if (have) {
             iown = (kPos ? a.giown : a.rk_iown)[g];
             inwin = iown >= a.rec_flo && iown <= a.rec_fhi;
@@ -661,7 +661,9 @@ __global__ __launch_bounds__(kBlock) void k_records(LblArgs a)
                     if (uhi < ulo)
                         uhi = ulo;
                 }
-                const int64_t idx = (int64_t)layer * a.ngroups + g;
+                const int64_t idx = (kFmt == 1 || kFmt == 2) && !kPos
+                                        ? (int64_t)layer * a.rec_pitch + (g - a.grp_lo)
+                                        : (int64_t)layer * a.ngroups + g;
                 if constexpr (kFmt == 3) {
                     Rec32 r;
                     r.k = k;
@@ -795,12 +797,29 @@ __global__ __launch_bounds__(NW * 64, 8) void k_ext_staged(LblArgs a)
 
     const double kthresh =
         a.ethresh * __longlong_as_double((long long)a.kmax_bits[(int64_t)layer * a.nrows + row]);
-    const int64_t recbase = (int64_t)layer * a.ngroups;
+    // packed records of this layer, indexed by the position in the phase-sorted group list
+    const int64_t recbase = a.rec16 ? (int64_t)layer * a.rec_pitch - a.grp_lo
+                                    : (int64_t)layer * a.ngroups;
+    double *const out = zsplit == 0
+                            ? a.ext
+                            : a.part + (int64_t)(zsplit - 1) * a.nlayers * a.nrows * a.wcount;
+    double *const dst = out + ((int64_t)layer * a.nrows + row) * a.wcount + (t0 - a.wbegin);
 
     double acc[S][4];
 #pragma unroll
     for (int u = 0; u < S; u++)
         acc[u][0] = acc[u][1] = acc[u][2] = acc[u][3] = 0.0;
+    if (a.accumulate) {
+        // a later chunk of the line list: go on from the running sums of the earlier ones
+#pragma unroll
+        for (int u = 0; u < S; u++)
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                const int j = rlo + u * kSub + c * 64 + lane;
+                if (j < tlen)
+                    acc[u][c] = dst[j];
+            }
+    }
     for (int i = tid; i < kNB * rowspan + kStagePad; i += kThreads)
         s_row[i] = 0.0;                            // the pads stay zero for good
 
@@ -895,6 +914,8 @@ __global__ __launch_bounds__(NW * 64, 8) void k_ext_staged(LblArgs a)
         const int iext = a.isoiext[iso];
         if (iext < 0 || (a.add ? 0 : iext) != row)
             continue;
+        if ((iso + 1) * osamp <= a.key_lo || iso * osamp >= a.key_hi)
+            continue;                              // no key of this isotope in the chunk
         const int64_t li = (int64_t)layer * a.niso + iso;
         const double dens = a.li_dens[li];
         int64_t reach = a.li_hmax[li];
@@ -931,8 +952,9 @@ __global__ __launch_bounds__(NW * 64, 8) void k_ext_staged(LblArgs a)
         for (int r = 0; r < per; r++) {
             const int pv = tid * per + r;
             const int p = pv / nch, c = pv - p * nch;
-            if (pv < nvirt && a.nsplit > 1 && p * a.nsplit / osamp != zsplit) {
-                s_phs[pv] = 0;                     // another workgroup's phase
+            if (pv < nvirt && ((a.nsplit > 1 && p * a.nsplit / osamp != zsplit) ||
+                               iso * osamp + p < a.key_lo || iso * osamp + p >= a.key_hi)) {
+                s_phs[pv] = 0;                     // another workgroup's, or another chunk's, phase
                 s_cum[pv] = 0;
             } else if (pv < nvirt) {
                 // two table lookups bracket each bound to within one bin (a fraction of a
@@ -1256,10 +1278,6 @@ __global__ __launch_bounds__(NW * 64, 8) void k_ext_staged(LblArgs a)
         }
     }
 
-    double *out = zsplit == 0
-                      ? a.ext
-                      : a.part + (int64_t)(zsplit - 1) * a.nlayers * a.nrows * a.wcount;
-    double *dst = out + ((int64_t)layer * a.nrows + row) * a.wcount + (t0 - a.wbegin);
 #pragma unroll
     for (int u = 0; u < S; u++) {
 #pragma unroll
@@ -1994,6 +2012,10 @@ struct pb_lbl {
     int64_t wm_total0 = 0, wm_total1 = 0;
     int32_t *gs_start = nullptr;      // [niso][nwave+1]
     int res_cap = 0;                  // LDS doubles of one resident profile block (0 = none fits)
+    // packed (layer, group) records above this many bytes are produced and consumed in chunks of
+    // the line list (pb_lbl_set_record_budget; PB_RECORD_BUDGET overrides)
+    size_t record_budget = (size_t)96 << 30;
+    int last_chunks = 0;     // chunks of the last call (0 = records of every group at once)
     int concurrency = 1;     // independent calls the caller keeps in flight beside this plan's
     int gather_mode = 0;     // 0 = choose, 1 = global gather, 2 = LDS-staged, 3 = resident+global
     int last_gather = 0;     // last call: 1 global, 2 staged, 3 linterp; +8 = resident kernel too
@@ -2465,6 +2487,20 @@ int pb_lbl_set_gather_mode(pb_lbl *p, int mode)
     return PB_OK;
 }
 
+int pb_lbl_set_record_budget(pb_lbl *p, int64_t bytes)
+{
+    PB_REQUIRE(p && bytes >= (int64_t)sizeof(Rec16), "pb_lbl_set_record_budget: bad budget");
+    p->record_budget = (size_t)bytes;
+    return PB_OK;
+}
+
+int pb_lbl_last_chunks(const pb_lbl *p, int *chunks)
+{
+    PB_REQUIRE(p && chunks, "pb_lbl_last_chunks: null pointer");
+    *chunks = p->last_chunks;
+    return PB_OK;
+}
+
 int pb_lbl_set_concurrency(pb_lbl *p, int n)
 {
     PB_REQUIRE(p && n >= 1, "pb_lbl_set_concurrency: n must be >= 1");
@@ -2657,8 +2693,7 @@ static int lbl_extinction(pb_lbl *p, double *ext_d, int64_t wbegin, int64_t wcou
     const size_t rec16_bytes = (size_t)nlayers * (size_t)l->ngroups * sizeof(Rec16);
     const bool can_stage = !p->resolution && lds <= 160 * 1024 && l->ngroups > 0 &&
                            (a.nch_max == 1 ||
-                            (a.nch_max <= 16 && packable && rec16_bytes <= ((size_t)96 << 30) &&
-                             !getenv("PB_NO_LONG_ROWS")));
+                            (a.nch_max <= 16 && packable && !getenv("PB_NO_LONG_ROWS")));
     // the staged kernel needs enough workgroups to hide its per-segment latency; launches that
     // stay below 750 even when split eight ways go to the global gather with record splitting.
     // Tiling of the staged kernel: S = 2 sub-tiles of 2048 samples per workgroup (1 measured
@@ -2726,7 +2761,63 @@ static int lbl_extinction(pb_lbl *p, double *ext_d, int64_t wbegin, int64_t wcou
     const bool poison = getenv("PB_POISON_RECORDS") && atoi(getenv("PB_POISON_RECORDS")) != 0;
     if (!staged || scatter)
         a.nch_max = 1;
-    if (staged && !scatter && packable && (a.nch_max > 1 || !getenv("PB_REC_SOA"))) {
+    a.grp_lo = 0;
+    a.grp_hi = l->ngroups;
+    a.rec_pitch = l->ngroups;
+    a.key_lo = 0;
+    a.key_hi = a.niso * v->osamp;
+    a.accumulate = 0;
+    // Out-of-core line lists (the reference walks any number of lines one after the other,
+    // _extcoeff.c:203-309): when the packed records of all groups exceed the record budget, the
+    // phase-sorted group list is cut into chunks of consecutive (isotope, phase) keys that fit.
+    size_t budget = p->record_budget;
+    if (const char *e = getenv("PB_RECORD_BUDGET"))
+        budget = (size_t)atoll(e);
+    struct Chunk {
+        int key_lo, key_hi;
+        int64_t g_lo, g_hi;
+    };
+    std::vector<Chunk> chunks;
+    size_t rec16_need = rec16_bytes;
+    if (staged && !scatter && rec16_bytes > budget) {
+        if (!packable || rounds || phase != 0 || getenv("PB_REC_SOA")) {
+            pb::set_error("pb_lbl_extinction: %zu B of line records exceed the record budget of "
+                          "%zu B and this call cannot be chunked (%s)", rec16_bytes, budget,
+                          phase != 0 ? "two-phase shard call"
+                                     : rounds ? "round gather" : "records are not packable");
+            return PB_ERR_NOMEM;
+        }
+        const int osamp = v->osamp;
+        const int64_t gmax = (int64_t)(budget / ((size_t)nlayers * sizeof(Rec16)));
+        Chunk c{0, 0, 0, 0};
+        int64_t biggest = 0;
+        for (int i = 0; i < a.niso; i++)
+            for (int ph = 0; ph < osamp; ph++) {
+                const int64_t g0 = p->h_ph_start[(size_t)i * (osamp + 1) + ph];
+                const int64_t g1 = p->h_ph_start[(size_t)i * (osamp + 1) + ph + 1];
+                if (g1 - g0 > gmax) {
+                    pb::set_error("pb_lbl_extinction: the %lld groups of one (isotope, phase) key "
+                                  "need more than the record budget of %zu B",
+                                  (long long)(g1 - g0), budget);
+                    return PB_ERR_NOMEM;
+                }
+                if (g1 - c.g_lo > gmax) {              // close the chunk before this key
+                    chunks.push_back(c);
+                    biggest = std::max(biggest, c.g_hi - c.g_lo);
+                    c.key_lo = i * osamp + ph;
+                    c.g_lo = g0;
+                }
+                c.key_hi = i * osamp + ph + 1;
+                c.g_hi = g1;
+            }
+        chunks.push_back(c);
+        biggest = std::max(biggest, c.g_hi - c.g_lo);
+        rec16_need = (size_t)std::max<int64_t>(1, biggest) * nlayers * sizeof(Rec16);
+    }
+    const bool chunked = !chunks.empty();
+    p->last_chunks = (int)chunks.size();
+    if (staged && !scatter && packable && (a.nch_max > 1 || chunked || !getenv("PB_REC_SOA"))) {
+        const size_t rec16_bytes = rec16_need;       // (shadows the whole-list size)
         if (rec16_bytes > p->rec16_alloc) {
             if (p->rec16) {
                 PB_HIP(hipStreamSynchronize(s));       // an earlier call may still read it
@@ -2767,7 +2858,11 @@ static int lbl_extinction(pb_lbl *p, double *ext_d, int64_t wbegin, int64_t wcou
         }
         a.rec32 = p->rec32;
     }
-    if (use_records && !p->rec_k) {
+    if (chunked)
+        a.res_cap = 0;                   // every layer through the staged gather
+    // the SoA records serve the global gather, the resident layers and PB_REC_SOA
+    const bool need_soa = use_records && !scatter && (a.rec16 == nullptr || a.res_cap > 0);
+    if (need_soa && !p->rec_k) {
         const size_t n = (size_t)p->max_layers * (size_t)l->ngroups;
         if (hipMalloc(&p->rec_k, n * 8) != hipSuccess ||
             hipMalloc(&p->rec_i32, n * 4 * 5) != hipSuccess) {
@@ -2803,6 +2898,67 @@ static int lbl_extinction(pb_lbl *p, double *ext_d, int64_t wbegin, int64_t wcou
     if (phase != 2) {
     k_layer_state<<<nlayers, 64, ((size_t)a.nlor + a.ndop) * 8 + (size_t)a.ndivs * 4, s>>>(a);
     PB_LAUNCH_CHECK();
+    }
+    if (chunked) {
+        // pass 1: the per-row maxima over ALL lines (the threshold of every chunk's gather);
+        // pass 2: per chunk, the records of its groups, then the gather, which continues the
+        // running sums of the earlier chunks.  One workgroup per tile (no phase split): the sums
+        // of a sample are then exactly those of a single launch over every key.
+        {
+            const int lines_per_block = 4096;
+            dim3 grid(pb::div_up(l->nlines, lines_per_block), nlayers);
+            k_kmax<<<grid, kBlock, (size_t)a.nrows * 8, s>>>(a, lines_per_block);
+            PB_LAUNCH_CHECK();
+        }
+        const bool timed = p->ev_used + 2 <= (int)p->ev.size();
+        if (timed)
+            PB_HIP(hipEventRecord(p->ev[p->ev_used], s));
+        const int per = kRecLayers;
+        const size_t rlds = (size_t)per * a.nrows * 8 + (size_t)a.ndop * 8 +
+                            (size_t)per * a.niso * (8 + 8 + 4) + (size_t)a.niso * (8 + 4) + 16 + 8;
+        PB_REQUIRE(rlds <= 64 * 1024, "pb_lbl_extinction: %zu B of LDS for the record kernel", rlds);
+        a.wm_lds = 0;
+        a.nsplit = 1;
+        a.part = nullptr;
+        a.ntiles = pb::div_up(wcount, S * sub);
+        const int unit_groups = (nlayers + 7) / 8;
+        dim3 ggrid((unsigned)(8 * a.ntiles * unit_groups), a.nrows);
+        void (*kern)(LblArgs) =
+            dma ? (S == 4   ? k_ext_staged<kStagedWaves, 4, true>
+                   : S == 2 ? k_ext_staged<kStagedWaves, 2, true>
+                            : k_ext_staged<kStagedWaves, 1, true>)
+                : (S == 4   ? k_ext_staged<kStagedWaves, 4, false>
+                   : S == 2 ? k_ext_staged<kStagedWaves, 2, false>
+                            : k_ext_staged<kStagedWaves, 1, false>);
+        if (lds > 64 * 1024)
+            PB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        for (size_t c = 0; c < chunks.size(); c++) {
+            a.grp_lo = chunks[c].g_lo;
+            a.grp_hi = chunks[c].g_hi;
+            a.rec_pitch = std::max<int64_t>(1, a.grp_hi - a.grp_lo);
+            a.key_lo = chunks[c].key_lo;
+            a.key_hi = chunks[c].key_hi;
+            a.accumulate = c > 0 ? 1 : 0;
+            if (a.grp_hi > a.grp_lo) {
+                dim3 rgrid(pb::div_up(a.grp_hi - a.grp_lo, kBlock), pb::div_up(nlayers, per));
+                if (a.nch_max > 1)
+                    k_records<2, kRecLayers><<<rgrid, kBlock, rlds, s>>>(a);
+                else
+                    k_records<1, kRecLayers><<<rgrid, kBlock, rlds, s>>>(a);
+                PB_LAUNCH_CHECK();
+            }
+            kern<<<ggrid, kStagedThreads, lds, s>>>(a);
+            PB_LAUNCH_CHECK();
+        }
+        p->last_gather = 2;
+        p->last_args = a;
+        p->last_packed = false;
+        if (timed) {
+            PB_HIP(hipEventRecord(p->ev[p->ev_used + 1], s));
+            p->ev_used += 2;
+        }
+        return PB_OK;
     }
     if (phase == 2) {
         // records and maxima are in place

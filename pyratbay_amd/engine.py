@@ -249,6 +249,17 @@ class LBL:
         """'auto' | 'global' | 'staged' | 'resident' (see pbhip.h: pb_lbl_set_gather_mode)."""
         call('pb_lbl_set_gather_mode', self._h, self.GATHER[mode])
 
+    def set_record_budget(self, nbytes):
+        """Largest buffer of per-(layer, group) line records a call may allocate; beyond it the
+        line list is walked in chunks (pb_lbl_set_record_budget)."""
+        call('pb_lbl_set_record_budget', self._h, int(nbytes))
+
+    @property
+    def last_chunks(self):
+        n = C.c_int(0)
+        call('pb_lbl_last_chunks', self._h, C.byref(n))
+        return n.value
+
     def set_concurrency(self, n):
         """The caller keeps n independent spectra in flight (pb_lbl_set_concurrency)."""
         call('pb_lbl_set_concurrency', self._h, int(n))

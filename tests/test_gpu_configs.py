@@ -137,6 +137,8 @@ def test_four_species_shards_and_rows(eng, orc):
 FULL = {
     # BASELINE.json configs[1]
     'c2': dict(args=(100001, 80, 100000), kw=dict(wnstep=0.05, niso=1), layers=(0, 41, 79)),
+    # north_star's speed-up configuration: the C2 grid with a 1e6-line list
+    'c2-1e6': dict(args=(100001, 80, 1000000), kw=dict(wnstep=0.05, niso=1), layers=(41,)),
     # configs[2]: 1e6 wavenumbers, 1e6-line 4-isotope list
     'c3': dict(args=(1000001, 80, 1000000), kw=dict(wnstep=0.005, niso=4), layers=(3, 76)),
     # configs[3]: 1e6 wavenumbers x 120 layers, 4 species x 1e6 lines (single-GPU form)
@@ -146,7 +148,7 @@ FULL = {
 }
 
 
-@pytest.mark.parametrize('name', ['c2', 'c3', 'c4'])
+@pytest.mark.parametrize('name', ['c2', 'c2-1e6', 'c3', 'c4'])
 def test_full_size_config(eng, orc, name, monkeypatch):
     import torch
     from pyratbay_amd import synth
@@ -181,6 +183,20 @@ def test_full_size_config(eng, orc, name, monkeypatch):
         part = lbl.extinction(t, d, z, add=True, wbegin=int(a), wcount=int(b - a))
         assert torch.equal(part, ref_staged[:, :, a:b]), f'shard [{a},{b}) differs'
         del part
+
+    # (2b) the line list walked in chunks under a record budget of 1/3.4 of the whole list's
+    # records (out-of-core line lists: pb_lbl_set_record_budget): bit for bit the one-call result
+    lbl.set_record_budget(int(ll.ngroups * nl * 16 / 3.4))
+    t1 = time.time()
+    cut = lbl.extinction(t, d, z, add=True)
+    torch.cuda.synchronize()
+    nchunks = lbl.last_chunks
+    assert nchunks >= 4, nchunks
+    assert torch.equal(cut, ref_staged), 'chunked line list differs from the one-call result'
+    del cut
+    lbl.set_record_budget(96 << 30)
+    print(f'{name}: {nchunks} chunks of the line list equal the one-call result '
+          f'({time.time() - t1:.2f} s)')
 
     monkeypatch.delenv('PB_STAGE_SPLIT')
     # (3) staged vs global gather: same terms, different association

@@ -768,3 +768,76 @@ def test_empty_shard_contributes_zero_maxima(eng):
                          out=torch.empty((3, 1, 0), dtype=torch.float64, device='cuda'))
     assert torch.count_nonzero(lbl.kmax_tensor()) == 0
     lbl.extinction_end()
+
+
+@pytest.mark.parametrize('long_rows', [False, True])
+@pytest.mark.parametrize('ethresh', [1e-30, 1e-3])
+def test_chunked_line_list_equals_one_call(eng, orc, monkeypatch, long_rows, ethresh):
+    """Out-of-core line lists (pb_lbl_set_record_budget): when the per-(layer, group) records
+    exceed the budget, the phase-sorted group list is walked in chunks -- one pass for the
+    per-row maxima of ALL lines, then per chunk its records and a gather that continues the
+    running sums.  Same terms, same order: bit-identical to the one-call form with one
+    workgroup per tile, for add = 1 and one row per species, with a threshold that drops most
+    lines (the maxima must be the global ones), on a wavenumber shard, with rows of several LDS
+    chunks; and equal to the oracle."""
+    import torch
+    from pyratbay_amd import synth
+    monkeypatch.setenv('PB_STAGE_SPLIT', '1')
+    if long_rows:
+        kw = dict(wnosamp=12, nlor=10, ndop=5, extent=4000.0, cutoff=80.0, niso=2)
+        nwave, nlines, nl = 4097, 3000, 3
+    else:
+        kw = dict(wnosamp=24, nlor=18, ndop=9, extent=80.0, cutoff=3.0, niso=3)
+        nwave, nlines, nl = 9001, 40000, 5
+    case = synth.lbl_case(nwave, nl, nlines, seed=31, **kw)
+    g, atm, ln, iso, vg = (case[k] for k in ('grid', 'atm', 'lines', 'iso', 'voigt'))
+    niso = len(iso['isomass'])
+    iso['isoiext'] = np.array([0, 1, 0][:niso], np.int32)
+    vt = eng.VoigtTable.build(vg['lorentz'], vg['doppler'], vg['size'], g['ownstep'], g['wnosamp'])
+    ll = eng.LineList(ln['lwn'], ln['elow'], ln['gf'], ln['lid'], niso, g['own'])
+
+    def plan():
+        lbl = eng.LBL(vt, ll, g['wn'], g['divisors'], atm['mol_radius'], atm['mol_mass'],
+                      iso['isoimol'], iso['isomass'], iso['isoratio'], iso['isoiext'],
+                      vg['cutoff'], ethresh, max_layers=nl)
+        lbl.set_gather_mode('staged')
+        return lbl
+    t, d, z = eng.dev(atm['temp']), eng.dev(atm['dens']), eng.dev(iso['isoz'])
+    whole, cut = plan(), plan()
+    total = ll.ngroups * nl * 16
+    for add in (True, False):
+        want = whole.extinction(t, d, z, add=add).clone()
+        assert whole.last_chunks == 0
+        for parts in (2.5, 7.3):
+            cut.set_record_budget(int(total / parts))
+            got = cut.extinction(t, d, z, add=add)
+            assert cut.last_chunks >= int(parts) + 1
+            assert torch.equal(got, want), (add, parts)
+        a, b = nwave // 3, nwave // 3 + 2500
+        part = cut.extinction(t, d, z, add=add, wbegin=a, wcount=b - a)
+        assert torch.equal(part, want[:, :, a:b])
+    if ethresh > 1e-10:
+        loose = plan()
+        loose.set_ethresh(1e-30)
+        assert not torch.equal(loose.extinction(t, d, z, add=True),
+                               whole.extinction(t, d, z, add=True))
+    # the chunked result against the oracle (one layer)
+    cut.set_record_budget(int(total / 4.1))
+    got = host(cut.extinction(t, d, z, add=True))[1]
+    profile = vt.flat()
+    want = np.zeros((1, g['nwave']))
+    orc.extinction(want, profile, vt.size, vt.index, vg['lorentz'], vg['doppler'], g['wn'],
+                   g['own'], g['divisors'], atm['dens'][1], atm['mol_radius'], atm['mol_mass'],
+                   iso['isoimol'], iso['isomass'], iso['isoratio'], iso['isoz'][:, 1].copy(),
+                   iso['isoiext'], ln['lwn'], ln['elow'], ln['gf'], ln['lid'], vg['cutoff'],
+                   ethresh, atm['temp'][1], 0, 1, 0)
+    assert np.array_equal(got == 0, want == 0)
+    np.testing.assert_allclose(got, want, rtol=RTOL)
+    # a budget below one (isotope, phase) key's records cannot be met; two-phase shard calls and
+    # the round gather are not chunked: loud errors, not silent over-allocation
+    cut.set_record_budget(16 * nl)
+    with pytest.raises(Exception, match='record budget'):
+        cut.extinction(t, d, z, add=True)
+    cut.set_record_budget(int(total / 3))
+    with pytest.raises(Exception, match='record budget'):
+        cut.extinction_begin(t, d, z, add=True, wbegin=0, wcount=2000)
