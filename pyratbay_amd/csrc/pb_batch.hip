@@ -15,6 +15,7 @@
 //                         reference's early exit and the transmission integral in one pass
 //   k_band_integrate_batch bandflux[w][nbands]
 #include <algorithm>
+#include <climits>
 #include <cstdlib>
 
 #include "pb_common.h"
@@ -501,6 +502,171 @@ __global__ __launch_bounds__(kBlock) void k_transit_pair(
 }
 
 // ---------------------------------------------------------------------------
+// The retrieval batch on the matrix cores.  Per walker the optical depths are ONE triangular
+// matrix product shared by all of its columns,
+//     tau[r][col] = sum_{j<=r} Q[r][j] * ec[itop + j][col],   Q[r][j] = P[r][j] + P[r][j-1]
+// (P = the ray paths of optic_depth.py:103-112: sum_i P[r][i] (ec[i+1] + ec[i]) regrouped by
+// layer), an 80 x 80 lower-triangular Q against an 80 x 1e5 block of ec at C5's shape.
+// v_mfma_f64_16x16x4_f64: A = a 16-row x 4-layer block of Q (one double per lane, from LDS, laid
+// out in lane order by k_path_qblocks), B = 4 layers x 16 columns of ec (one double per lane,
+// straight from global memory: lane = (layer l>>4, column l&15), 128-byte runs), C = 16 rows x 16
+// columns of tau (4 doubles per lane).  A wavefront owns NT column tiles and all MT row tiles:
+// NT x MT accumulators stay in registers while ec streams past ONCE (the vector form re-read
+// every column once per block of 16 rows: 3x at 80 layers), and of the MT x 4MT blocks of Q only
+// the 2MT^2 + 2MT on or below the diagonal are multiplied (60 of 100 at 80 layers).
+// The epilogue -- exp(-tau) r, first crossing of maxdepth, trapezoid over the rows
+// (radiative_transfer.py:57-71) -- runs on the accumulator layout: lane (q = l>>4, n = l&15) holds
+// the rows 16m + 4j + q of column n; the previous row's integrand comes from the lane 16 below
+// (one cross-lane move per row), the first crossing and the sums are combined over the four lanes
+// of a column.  Sums of a column are added in a different order than the reference's loop:
+// spectra agree to ~1e-15 relative with the vector form, not bit for bit.
+// ---------------------------------------------------------------------------
+__host__ __device__ inline int qblocks(int mt) { return 2 * mt * mt + 2 * mt; }
+
+__global__ __launch_bounds__(kBlock) void k_path_qblocks(double *out, const double *raypath,
+                                                         int64_t npath, int nblk, int nimpact)
+{
+    const int w = blockIdx.y;
+    const double *path = raypath + (int64_t)w * npath;
+    double *o = out + (int64_t)w * nblk * 64;
+    for (int e = blockIdx.x * kBlock + threadIdx.x; e < nblk * 64; e += gridDim.x * kBlock) {
+        const int blk = e >> 6, l = e & 63;
+        int m = 0;
+        while (qblocks(m + 1) <= blk)
+            m++;
+        const int ks = blk - qblocks(m);
+        const int r = 16 * m + (l & 15), j = 4 * ks + (l >> 4);
+        double v = 0.0;
+        if (r >= 1 && r < nimpact && j <= r) {
+            const int64_t base = ((int64_t)r * (r - 1)) / 2;
+            if (j < r)
+                v = path[base + j];
+            if (j >= 1)
+                v += path[base + j - 1];
+        }
+        o[e] = v;
+    }
+}
+
+typedef double v4d __attribute__((ext_vector_type(4)));
+typedef double d2u __attribute__((ext_vector_type(2), aligned(8)));
+
+// A wavefront owns 32 columns = two 16-column tiles (the even and the odd columns of its range:
+// one 16-byte load per lane fetches both) and all MT row tiles: 2 x MT accumulators stay in
+// registers while the layers stream past once, four K-steps (16 layers) in flight ahead of the
+// four being multiplied.  The loads carry no branch (rows beyond the last layer and columns beyond
+// the grid read a clamped address: their Q entries are zero, their results unused): behind a
+// divergent `if` the compiler drains every load (s_waitcnt vmcnt(0)) before it issues the next.
+template <int MT, int WPS>
+__global__ __launch_bounds__(kBlock, WPS) void k_transit_mfma(
+    double *spectrum, const double *ec, const double *qblk, const double *radius, int nblk,
+    double rstar, int itop, int ibottom, double maxdepth, int nlayers, int nwave)
+{
+    extern __shared__ __align__(16) double s_q[];         // [nblk][64] | rad[16 MT]
+    const int w = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nimpact = min(ibottom, nlayers) - itop;
+    double *s_rad = s_q + (size_t)nblk * 64;
+    {
+        const double *q = qblk + (int64_t)w * nblk * 64;
+        for (int e = tid; e < nblk * 64; e += kBlock)
+            s_q[e] = q[e];
+        for (int r = tid; r < 16 * MT; r += kBlock)
+            s_rad[r] = r < nimpact ? radius[(int64_t)w * nlayers + itop + r] : 0.0;
+    }
+    __syncthreads();
+    const int c0 = (blockIdx.x * (kBlock / 64) + wave) * 32;
+    if (c0 >= nwave)
+        return;                                           // (after the only barrier)
+    const int kq = lane >> 4, n = lane & 15;
+    const int col0 = c0 + 2 * n;                          // tile 0: even columns, tile 1: odd ones
+    const bool ok[2] = {col0 < nwave, col0 + 1 < nwave};
+    const int cpair = max(min(col0, nwave - 2), 0);       // first column of the pair I load
+    const bool second = col0 != cpair;                    // my column 0 is the pair's second one
+    const double *src = ec + ((int64_t)w * nlayers + itop) * nwave + cpair;
+    const int KS = (nimpact + 3) / 4;
+    v4d C[2][MT];
+#pragma unroll
+    for (int t = 0; t < 2; t++)
+#pragma unroll
+        for (int m = 0; m < MT; m++)
+            C[t][m] = v4d{0.0, 0.0, 0.0, 0.0};
+    double bcur[4][2], bnxt[4][2];
+    auto loadb = [&](int mb, double (&b)[4][2]) {         // (the launcher guarantees nwave >= 2)
+#pragma unroll
+        for (int kk = 0; kk < 4; kk++) {
+            const int j = min(4 * (4 * mb + kk) + kq, nimpact - 1);
+            const d2u v = *reinterpret_cast<const d2u *>(src + (int64_t)j * nwave);
+            b[kk][0] = second ? v.y : v.x;
+            b[kk][1] = v.y;
+        }
+    };
+    loadb(0, bcur);
+    const double *sq = s_q + lane;
+#pragma unroll
+    for (int mb = 0; mb < MT; mb++) {
+        if (4 * mb < KS) {                                // uniform
+            if (mb + 1 < MT)
+                loadb(mb + 1, bnxt);
+#pragma unroll
+            for (int kk = 0; kk < 4; kk++) {
+                const int ks = 4 * mb + kk;
+#pragma unroll
+                for (int m = mb; m < MT; m++) {
+                    const double a = sq[(qblocks(m) + ks) * 64];
+                    C[0][m] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bcur[kk][0], C[0][m], 0, 0, 0);
+                    C[1][m] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bcur[kk][1], C[1][m], 0, 0, 0);
+                }
+            }
+            if (mb + 1 < MT) {
+#pragma unroll
+                for (int kk = 0; kk < 4; kk++) {
+                    bcur[kk][0] = bnxt[kk][0];
+                    bcur[kk][1] = bnxt[kk][1];
+                }
+            }
+        }
+    }
+    // epilogue on the accumulator layout: rows 16m + 4j + kq of my two columns
+    const double rtop = s_rad[0];
+    const double *srad = s_rad + kq;
+    const int src_lane = (lane + 48) & 63;                // the lane one row above (16 below)
+#pragma unroll
+    for (int t = 0; t < 2; t++) {
+        int first = INT_MAX;
+#pragma unroll
+        for (int m = 0; m < MT; m++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int r = 16 * m + 4 * j + kq;
+                if (r < nimpact && C[t][m][j] > maxdepth)
+                    first = min(first, r);
+            }
+        first = min(first, __shfl_xor(first, 16));
+        first = min(first, __shfl_xor(first, 32));
+        double acc = 0.0, carry = 0.0;                    // carry: row 16m + 4j - 1 seen from q = 0
+#pragma unroll
+        for (int m = 0; m < MT; m++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int r = 16 * m + 4 * j + kq;
+                const bool in = r < nimpact && r <= first;
+                const double rr = srad[16 * m + 4 * j];
+                const double f = in ? pb::exp_s(-C[t][m][j]) * rr : 0.0;
+                const double up = __shfl(f, src_lane);    // q > 0: row r - 1; q = 0: row r + 3
+                const double fprev = kq > 0 ? up : carry;
+                carry = up;
+                if (in && r >= 1)
+                    acc += (rr - srad[16 * m + 4 * j - 1]) * (fprev + f);
+            }
+        acc += __shfl_xor(acc, 16);
+        acc += __shfl_xor(acc, 32);
+        if (kq == 0 && ok[t])
+            spectrum[(int64_t)w * nwave + col0 + t] = (rtop * rtop + 2 * (acc * 0.5)) / (rstar * rstar);
+    }
+}
+
+// ---------------------------------------------------------------------------
 // The same pass with the column tile in LDS: workgroup = 64 columns x NB wavefronts, wavefront b
 // owning the impact parameters 16b .. 16b+15.  The tile of s_i = ec[i+1] + ec[i] (64 columns x all
 // segments) is read from HBM ONCE, cooperatively and coalesced, and every wavefront then takes
@@ -746,6 +912,52 @@ int pb_transit_fused_launch(double *depth_d, int32_t *ideep_d, double *spectrum_
             return PB_OK;
         }
     }
+    // the retrieval batch (spectrum only, no deck) on the matrix cores: k_transit_mfma
+    {
+        // (read per call: the tests switch it inside one process)
+        const char *mode = getenv("PB_TRANSIT_MFMA");
+        const bool no_mfma = mode && atoi(mode) == 0, force_mfma = mode && atoi(mode) == 2;
+        const int mt = pb::div_up(std::max(nimpact, 1), 16);
+        if (!no_mfma && work_d && spectrum_d && !depth_d && !ideep_d && deck_row < 0 &&
+            nimpact > 1 && mt <= 8 && nwave >= 2 && (nwalkers > 1 || force_mfma)) {
+            const int nblk = qblocks(mt);
+            dim3 qgrid((unsigned)std::min(16, pb::div_up((int64_t)nblk * 64, kBlock)), nwalkers);
+            k_path_qblocks<<<qgrid, kBlock, 0, s>>>(work_d, raypath_d, npath, nblk, nimpact);
+            PB_LAUNCH_CHECK();
+            const size_t lds = ((size_t)nblk * 64 + (size_t)mt * 16) * 8;
+            const int nt = 2;
+            dim3 mgrid(pb::div_up(nwave, (kBlock / 64) * 16 * nt), nwalkers);
+#define PB_MFMA(M, W)                                                                            \
+    do {                                                                                         \
+        if (lds > 64 * 1024)                                                                     \
+            PB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_transit_mfma<M, W>),    \
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));   \
+        k_transit_mfma<M, W><<<mgrid, kBlock, lds, s>>>(spectrum_d, ec_d, work_d, radius_d, nblk, \
+                                                       rstar, itop, ibottom, maxdepth, nlayers,  \
+                                                       nwave);                                   \
+    } while (0)
+            switch (mt) {
+            case 1: PB_MFMA(1, 4); break;
+            case 2: PB_MFMA(2, 4); break;
+            case 3: PB_MFMA(3, 4); break;
+            case 4: PB_MFMA(4, 4); break;
+            case 5:
+                if (getenv("PB_MFMA_WPS") && atoi(getenv("PB_MFMA_WPS")) == 3)
+                    PB_MFMA(5, 3);
+                else if (getenv("PB_MFMA_WPS") && atoi(getenv("PB_MFMA_WPS")) == 2)
+                    PB_MFMA(5, 2);
+                else
+                    PB_MFMA(5, 4);
+                break;
+            case 6: PB_MFMA(6, 2); break;
+            case 7: PB_MFMA(7, 2); break;
+            default: PB_MFMA(8, 2); break;
+            }
+#undef PB_MFMA
+            PB_LAUNCH_CHECK();
+            return PB_OK;
+        }
+    }
     static const bool no_scalar = getenv("PB_TRANSIT_SCALAR") && atoi(getenv("PB_TRANSIT_SCALAR")) == 0;
     const bool scalar = work_d != nullptr && nimpact > 1 && !no_scalar;
     const int rows = fused_rows(nwave, nwalkers, nrow, scalar);
@@ -904,6 +1116,8 @@ int64_t pb_transit_work_doubles(int nlayers, int itop, int ibottom, int nwave, i
     int64_t n = 0;
     for (int rows : {8, 16, 40})
         n = std::max(n, blocked_len(rows, nimpact));
+    // ... and the 16 x 4 blocks of the matrix-core form (k_path_qblocks)
+    n = std::max<int64_t>(n, (int64_t)qblocks(pb::div_up(std::max(nimpact, 1), 16)) * 64);
     (void)nwave;
     return n * std::max(nwalkers, 0) + 8;
 }

@@ -86,14 +86,18 @@ def test_interp_ec_batch_vs_single_and_oracle(eng, orc, L, W):
         np.testing.assert_allclose(got6[w], want, rtol=RTOL)
 
 
-@pytest.mark.parametrize('rows', [None, 16])
+@pytest.mark.parametrize('rows', [None, 16, 'mfma'])
 @pytest.mark.parametrize('itop,ibottom,maxdepth', [(0, None, 10.0), (2, None, 10.0),
                                                    (0, 19, 10.0), (1, None, np.inf)])
 def test_transit_spectrum_batch_vs_oracle(eng, orc, itop, ibottom, maxdepth, rows, monkeypatch):
-    """rows=16 forces the block size of large launches at this small size: the spectrum-only
-    call then runs k_transit_pair (two columns per thread, fused multiply-adds), the call that
-    returns depth the one-column kernel with the reference's products and sums."""
-    if rows:
+    """The spectrum-only call of a batch runs on the matrix cores by default (k_transit_mfma:
+    rows='mfma'); with PB_TRANSIT_MFMA=0 it runs the vector kernels: rows=16 forces the block
+    size of large launches at this small size, which selects k_transit_pair (two columns per
+    thread, fused multiply-adds); rows=None the one-column kernel with the reference's products
+    and sums, which is also what the call that returns depth always runs."""
+    if rows != 'mfma':
+        monkeypatch.setenv('PB_TRANSIT_MFMA', '0')
+    if rows == 16:
         monkeypatch.setenv('PB_TRANSIT_ROWS', str(rows))
     rng = np.random.default_rng(7)
     c = cases.column_case(seed=9, nlayers=24, nwave=700)
@@ -263,3 +267,39 @@ def test_eval_bands_emission_batch(eng, orc):
         flux = np.sum(inten * weights[:, None], axis=0)
         want = [np.trapezoid(flux[s:s + len(r)] * r, wn[s:s + len(r)]) * h for s, r, h in bands]
         np.testing.assert_allclose(got[w], want, rtol=1e-11)
+
+
+@pytest.mark.parametrize('nlayers,nwave,itop,ibottom', [(80, 1000, 0, None), (17, 70, 1, None),
+                                                        (33, 257, 0, 30), (120, 300, 3, None),
+                                                        (128, 130, 0, None), (2, 64, 0, None),
+                                                        (16, 16, 0, None)])
+def test_transit_on_the_matrix_cores(eng, orc, monkeypatch, nlayers, nwave, itop, ibottom):
+    """k_transit_mfma (tau = Q . ec as 16x16x4 FP64 matrix products, the exit and the trapezoid
+    on the accumulator layout) against the oracle's loops and against the vector kernel, over the
+    shapes that select every instantiation: 1-8 row tiles, 4 or 2 column tiles per wavefront,
+    rows and columns that are no multiples of 16, itop > 0, ibottom < L, columns that cross
+    maxdepth in every row tile and columns that never do."""
+    rng = np.random.default_rng(11)
+    c = cases.column_case(seed=13, nlayers=nlayers, nwave=nwave)
+    L, W, nw = c['nlayers'], c['nwave'], 3
+    ibottom = L if ibottom is None else ibottom
+    # spread the crossing layer over the whole column: scale every column by its own factor
+    scale = 10.0**rng.uniform(-3, 3, W)
+    ecs = np.array([c['ec'] * scale * 10.0**rng.uniform(-0.3, 0.3) for _ in range(nw)])
+    radius = np.array([np.sort(c['radius'] * (1 + 0.01 * rng.uniform(-1, 1)))[::-1]
+                       for _ in range(nw)])
+    rad_d = eng.dev(radius)
+    path = eng.transit_path_device(rad_d, itop)
+    ec_d = eng.dev(ecs)
+    got = host(eng.transit_spectrum_batch(ec_d, path, rad_d, c['rstar'], itop, ibottom, 10.0))
+    monkeypatch.setenv('PB_TRANSIT_MFMA', '0')
+    vec = host(eng.transit_spectrum_batch(ec_d, path, rad_d, c['rstar'], itop, ibottom, 10.0))
+    np.testing.assert_allclose(got, vec, rtol=1e-13)
+    stops = set()
+    for w in range(nw):
+        wd, wi = orc.optical_depth_transit(ecs[w], radius[w], itop, ibottom, 10.0)
+        ws = orc.transmission(wd, radius[w], c['rstar'], wi, itop)
+        np.testing.assert_allclose(got[w], ws, rtol=RTOL)
+        stops |= set(np.unique(wi // 16))
+    if L >= 80:
+        assert len(stops) >= 2          # exits in several row tiles

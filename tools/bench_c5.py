@@ -28,6 +28,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 BATCH = 64
+# walkers per launch inside a batch (engine.TableSpectrum.eval_bands)
+CHUNK = int(os.environ.get('PB_C5_CHUNK', '64'))
 NSPEC, NTEMP, NLAYERS, NWAVE = 4, 10, 80, 100001
 HBM_PEAK_GBS = 8000.0
 
@@ -163,7 +165,7 @@ def main(args):
 
     def step(i):
         temps, dens, radius = batches[i % nbatch_distinct]
-        flux = model.eval_bands(temps, dens, pb, radius=radius, chunk=BATCH)
+        flux = model.eval_bands(temps, dens, pb, radius=radius, chunk=CHUNK)
         return gather_walkers(flux, BATCH, world, rank) if world > 1 else flux
 
     for i in range(args.warmup):
@@ -217,10 +219,17 @@ def main(args):
         nodes = sum(len(np.union1d(tlo[:, k], tlo[:, k] + 1)) for k in range(nlayers))
         interp_bytes = 8.0 * NSPEC * nwave * nodes + 8.0 * nlayers * nwave * nloc
         transit_bytes = (8.0 * nlayers * nwave + 8.0 * nwave) * nloc
+        mfma = os.environ.get('PB_TRANSIT_MFMA', '1') != '0'
+        # matrix-core form: per 32 columns 2 x 60 v_mfma_f64_16x16x4_f64 (the blocks of the
+        # 80 x 80 ray-path matrix on or below its diagonal) = 7680 flop per column
+        transit_flops = 2.0 * 60 * 2048 / 32 * nwave * nloc
         kernels = [
-            {'kernel': 'k_transit_pair<16>', 'kernel_ms': transit_ms,
-             'kernel_bytes': transit_bytes, 'bound_by': 'FP64 vector ALU (3160 fma + 80 exp per '
-             'column), not HBM'},
+            {'kernel': 'k_transit_mfma<5,4>' if mfma else 'k_transit_pair<16>',
+             'kernel_ms': transit_ms, 'kernel_bytes': transit_bytes,
+             'bound_by': ('FP64 matrix pipe (120 v_mfma_f64_16x16x4_f64 per 32 columns = '
+                          f'{transit_flops / (transit_ms * 1e-3) / 1e12:.1f} TFLOP/s) + 80 exp per '
+                          'column on the vector ALU; ec read once') if mfma else
+                         'FP64 vector ALU (3160 fma + 80 exp per column), not HBM'},
             {'kernel': 'k_interp_ec_batch2<4,true>' if os.environ.get('PB_INTERP_PAIRS', '1') != '0' else 'k_interp_ec_batch<4,true>', 'kernel_ms': interp_ms,
              'kernel_bytes': interp_bytes, 'bound_by': 'HBM (ec written per walker)'}]
         for k in kernels:

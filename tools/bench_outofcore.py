@@ -1,8 +1,8 @@
 """Out-of-core line lists: a synthetic list of N lines (default 1e8) on C2's grid (1e5 wavenumbers
 x 80 layers) under a fixed record budget (default 16 GiB), walked in chunks
-(pb_lbl_set_record_budget).  Reports set-up and per-call times and, with --check,
-property: the extinction of the whole list equals the sum over K interleaved sub-lists, each
-computed in one un-chunked call (co-adding differs between the two, the sums do not, 1e-9).
+(pb_lbl_set_record_budget).  Reports set-up and per-call times and, with --check, compares with
+the same list in ONE un-chunked call, bit for bit (the records of 1e8 lines still fit in 288 GB;
+the budget is for smaller cards and longer lists).
 usage: python tools/bench_outofcore.py [--lines 1e8] [--budget-gib 16] [--check] [--out file.json]"""
 import argparse
 import json
