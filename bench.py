@@ -40,6 +40,12 @@ WORKLOADS = {
                label='1e5 wavenumbers x 80 layers, 1e5 synthetic lines, transit'),
     'c2-1e6': dict(nwave=100001, nlayers=80, nlines=1000000, wnstep=0.05, niso=1,
                    label='1e5 wavenumbers x 80 layers, 1e6 synthetic lines, transit'),
+    # the C2 problem on a constant-resolving-power grid (the reference's `resolution` mode,
+    # _extcoeff.c:320-326): R = 123 300 puts ~1e5 samples between 4000 and 9000 cm-1; the fine
+    # grid is the reference's default for that mode (wnstep 1.0 -> wnosamp 2520)
+    'c2-res': dict(nwave=100001, nlayers=80, nlines=100000, wnstep=0.05, niso=1,
+                   resolution=123300.0,
+                   label='~1e5 wavenumbers at R = 123 300 x 80 layers, 1e5 synthetic lines, transit'),
     'small': dict(nwave=10001, nlayers=20, nlines=10000, wnstep=0.05, niso=1,
                   label='1e4 wavenumbers x 20 layers, 1e4 synthetic lines, transit'),
     'c3': dict(nwave=1000001, nlayers=80, nlines=1000000, wnstep=0.005, niso=4,
@@ -58,7 +64,7 @@ NORTH_STAR = 'c2-1e6'     # north_star's >= 50x target configuration
 
 def make_case(w):
     from pyratbay_amd import synth
-    kw = {k: w[k] for k in ('species', 'vmr', 'line_species') if k in w}
+    kw = {k: w[k] for k in ('species', 'vmr', 'line_species', 'resolution') if k in w}
     return synth.lbl_case(w['nwave'], w['nlayers'], w['nlines'], wnstep=w['wnstep'],
                           niso=w['niso'], seed=42, **kw)
 
@@ -80,7 +86,7 @@ def _ext_module():
     return 'port', orc.extinction, np.int32
 
 
-def _run_layers(arr, layers, ec_out, scal):
+def _run_layers(arr, layers, ec_out, scal, resolution=0):
     """_extcoeff.extinction for the given layers, one call per layer like
     pyrat/extinction.py:170-213; returns seconds per layer."""
     kind, ext_fn, int_t = _ext_module()
@@ -95,7 +101,7 @@ def _run_layers(arr, layers, ec_out, scal):
                arr['mol_radius'], arr['mol_mass'], ints['isoimol'], arr['isomass'],
                arr['isoratio'], np.ascontiguousarray(arr['isoz'][:, layer]), ints['isoiext'],
                arr['lwn'], arr['elow'], arr['gf'], ints['lid'], scal['cutoff'],
-               scal['ethresh'], float(arr['temp'][layer]), 0, 1, 0)
+               scal['ethresh'], float(arr['temp'][layer]), 0, 1, int(resolution))
         times.append(time.perf_counter() - t0)
         ec_out[layer] = row[0]
     return kind, times
@@ -112,7 +118,8 @@ def cpu_worker():
         arr = {k: np.load(os.path.join(d, k + '.npy'), mmap_mode='r') for k in EXT_KEYS}
         ec = np.load(os.path.join(d, 'ec.npy'), mmap_mode='r+')
         t0 = time.perf_counter()
-        kind, times = _run_layers(arr, job['layers'], ec, job['scal'])
+        kind, times = _run_layers(arr, job['layers'], ec, job['scal'],
+                                  job['scal'].get('resolution', 0))
         ec.flush()
         print(json.dumps({'kind': kind, 'times': times,
                           'wall': time.perf_counter() - t0}), flush=True)
@@ -210,11 +217,12 @@ def cpu_legs(case, voigt, pool, budget_layers, gpu_ec, gpu_spectrum, rt_path):
                mol_mass=atm['mol_mass'], isoimol=iso['isoimol'], isomass=iso['isomass'],
                isoratio=iso['isoratio'], isoz=iso['isoz'], isoiext=iso['isoiext'],
                lwn=ln['lwn'], elow=ln['elow'], gf=ln['gf'], lid=ln['lid'], temp=atm['temp'])
-    scal = dict(cutoff=float(vg['cutoff']), ethresh=float(case['ethresh']))
+    scal = dict(cutoff=float(vg['cutoff']), ethresh=float(case['ethresh']),
+                resolution=int(g.get('resolution') is not None))
     # (a) one core, in this process
     layers = np.unique(np.linspace(0, nlayers - 1, budget_layers).round().astype(int))
     ec1 = np.zeros((nlayers, nwave))
-    kind, times = _run_layers(arr, [int(x) for x in layers], ec1, scal)
+    kind, times = _run_layers(arr, [int(x) for x in layers], ec1, scal, scal['resolution'])
     t_ext1 = float(np.sum(times)) * nlayers / len(layers)
     # (b) all cores: arrays shared through files the workers map
     allcores = None

@@ -72,7 +72,10 @@ typedef struct pb_voigt pb_voigt;
  * (psize_h[nlor*ndop]; 0 = alias the previous Doppler column, vprofile.c:100-104).
  * `dwn` is the fine-grid step (spec.ownstep), `osamp` the oversampling factor
  * (spec.wnosamp) that fixes the phase-major device layout used by the extinction
- * kernel.  Synchronous. */
+ * kernel.  keep_flat: 0 = phase-major layout only (constant-step plans), 1 = also the
+ * reference layout (vprofile.grid's `profile`), 2 = the reference layout ONLY: what a plan of
+ * the `resolution` / `wlstep` mode reads (utils.h:139-163) -- no second copy of the table.
+ * Synchronous. */
 int pb_voigt_create(pb_voigt **out, const double *lorentz_h, int nlor,
                     const double *doppler_h, int ndop, const int32_t *psize_h,
                     double dwn, int osamp, int keep_flat, void *stream);

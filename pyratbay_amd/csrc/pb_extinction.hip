@@ -732,7 +732,13 @@ __global__ __launch_bounds__(kBlock) void k_records(LblArgs a)
 
 // NW wavefronts per workgroup, S sub-tiles of NW*256 samples each (tile = S*NW*256); one
 // record per thread per batch.
-template <int NW, int S, bool kDma>
+// kProbe (timing experiments, results INVALID, never selected unless PB_STAGE_PROBE is set):
+// 1 = "contiguous ownership": a lane owns 4 consecutive samples of a span and a visit is two
+//     16-byte LDS reads at the 16-byte-aligned address at or below the one it needs (what a
+//     second, 8-byte-shifted image of the row would make legal) instead of four 8-byte reads;
+// 2 = the same with 2 consecutive samples per lane in each half of the span;
+// 3 = (valid results) the remainder records of a visit loop software-pipelined.
+template <int NW, int S, bool kDma, int kProbe = 0>
 __global__ __launch_bounds__(NW * 64, 8) void k_ext_staged(LblArgs a)
 {
     constexpr int kThreads = NW * 64;
@@ -1197,6 +1203,23 @@ __global__ __launch_bounds__(NW * 64, 8) void k_ext_staged(LblArgs a)
                     auto visit = [&](const double2 raw) {
                         const double k = raw.x;
                         const int qoff = __double2loint(raw.y);
+                        if constexpr (kProbe == 1 || kProbe == 2) {
+                            // 1: 4 consecutive samples per lane (lane pitch 32 B: two-way bank
+                            // conflicts); 2: 2 consecutive samples in each half of the span (lane
+                            // pitch 16 B, conflict-free)
+                            // (offsets from the LDS base: a pointer rebuilt from an integer
+                            // would be a flat pointer and the reads flat loads)
+                            const char *base = reinterpret_cast<const char *>(s_row);
+                            const int off = ((int)(rs - base) + (kProbe == 1 ? 3 : 1) * 8 * lane + qoff) & ~15;
+                            const double2 v0 = *reinterpret_cast<const double2 *>(base + off);
+                            const double2 v1 = *reinterpret_cast<const double2 *>(
+                                base + off + (kProbe == 1 ? 16 : 1024));
+                            acc[u][0] = fma(k, v0.x, acc[u][0]);
+                            acc[u][1] = fma(k, v0.y, acc[u][1]);
+                            acc[u][2] = fma(k, v1.x, acc[u][2]);
+                            acc[u][3] = fma(k, v1.y, acc[u][3]);
+                            return;
+                        }
                         const double *p0 = reinterpret_cast<const double *>(rs + qoff);
                         const double a0 = p0[0], a1 = p0[64], a2 = p0[128], a3 = p0[192];
                         acc[u][0] = fma(k, a0, acc[u][0]);
@@ -1213,8 +1236,22 @@ __global__ __launch_bounds__(NW * 64, 8) void k_ext_staged(LblArgs a)
                         visit(w2);
                         visit(w3);
                     }
-                    for (; r < last; r++)
-                        visit(recs[r]);
+                    if constexpr (kProbe == 3) {
+                        // remainder records software-pipelined: the next record's {k, offset} is
+                        // requested before the current record's row reads are consumed
+                        if (r < last) {
+                            double2 cur = recs[r];
+                            for (; r + 1 < last; r++) {
+                                const double2 nxt = recs[r + 1];
+                                visit(cur);
+                                cur = nxt;
+                            }
+                            visit(cur);
+                        }
+                    } else {
+                        for (; r < last; r++)
+                            visit(recs[r]);
+                    }
                 }
             };
             // Software pipeline over the segments.  Segment j lives in register set j % D;
@@ -1787,10 +1824,16 @@ __global__ __launch_bounds__(kBlock) void k_combine_parts(double *ext, const dou
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(kBlock) void k_ext_linterp(LblArgs a)
 {
-    __shared__ double s_k[kBlock];
-    __shared__ int64_t s_start[kBlock];                 // start of the profile in flat[]
-    __shared__ int s_inoff[kBlock];                     // half - iown
-    __shared__ int s_min[kBlock], s_max[kBlock], s_half2[kBlock];
+    // one record of the batch: two 16-byte LDS broadcast reads per (record, wavefront)
+    struct __align__(16) RecA {
+        double k;
+        int64_t start;                                  // start of the profile in flat[]
+    };
+    struct __align__(16) RecB {
+        int inoff, half2, mn, mx;                       // half - iown, 2*half, window [mn, mx)
+    };
+    __shared__ RecA s_ra[kBlock + 4];
+    __shared__ RecB s_rb[kBlock + 4];
 
     int tile, layer;
     decode_block(a, tile, layer);
@@ -1862,34 +1905,45 @@ __global__ __launch_bounds__(kBlock) void k_ext_linterp(LblArgs a)
                         start = a.pindex[w.cell];
                     }
                 }
-                s_k[threadIdx.x] = k;
-                s_start[threadIdx.x] = start;
-                s_inoff[threadIdx.x] = inoff;
-                s_min[threadIdx.x] = mn;
-                s_max[threadIdx.x] = mx;
-                s_half2[threadIdx.x] = half2;
+                // (a dead record keeps an empty window, k = 0 and the start of the table)
+                s_ra[threadIdx.x] = RecA{k, start};
+                s_rb[threadIdx.x] = RecB{inoff, half2, mn, mx};
+                if (threadIdx.x < 4) {                  // the padding of the last trip of four
+                    s_ra[kBlock + threadIdx.x] = RecA{0.0, 0};
+                    s_rb[kBlock + threadIdx.x] = RecB{0, 0, 0, 0};
+                }
             }
             __syncthreads();
             const int nrec = (int)min((int64_t)kBlock, g1 - gb);
-            for (int e = 0; e < nrec; e++) {
-                const int mn = s_min[e], mx = s_max[e];
-                if (mn >= mx || mx <= tile_jmin || mn > tile_jmax)
-                    continue;
-                if (!live)
-                    continue;
-                const double k = s_k[e];
-                const double *tab = a.flat + s_start[e];
-                const int64_t inoff = s_inoff[e];
-                const int half2 = s_half2[e];
-                if (ilo >= mn && ilo < mx) {
-                    const int64_t f = inoff + (int64_t)ofactor * ilo;
-                    if (f >= 0 && f <= half2)
-                        acc0 = fma(k, tab[f], acc0);
+            // Four records per trip and NO branch around the table reads: a lane outside a
+            // record's window reads element 0 of that profile with a zero strength instead.
+            // Behind per-record branches every pair of reads was drained (s_waitcnt vmcnt(0))
+            // before the next record's were issued; now eight gathers are in flight per lane.
+            // The sums see the same terms in the same order (+ k * 0-weight terms that are
+            // exactly zero: profile samples are finite).
+            for (int e = 0; e < nrec; e += 4) {
+                double k0[4], k1[4], v0[4], v1[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const RecA ra = s_ra[e + u];        // (entries beyond nrec: k = 0 records of
+                    const RecB rb = s_rb[e + u];        // this or an earlier batch, or the padding)
+                    const bool have = e + u < nrec;
+                    const int64_t f0 = rb.inoff + (int64_t)ofactor * ilo;
+                    const int64_t f1 = f0 + ofactor;
+                    const bool in0 = have && live && ilo >= rb.mn && ilo < rb.mx && f0 >= 0 &&
+                                     f0 <= rb.half2;
+                    const bool in1 = have && live && ilo + 1 >= rb.mn && ilo + 1 < rb.mx && f1 >= 0 &&
+                                     f1 <= rb.half2;
+                    const double *tab = a.flat + ra.start;
+                    v0[u] = tab[in0 ? f0 : 0];
+                    v1[u] = tab[in1 ? f1 : 0];
+                    k0[u] = in0 ? ra.k : 0.0;
+                    k1[u] = in1 ? ra.k : 0.0;
                 }
-                if (ilo + 1 >= mn && ilo + 1 < mx) {
-                    const int64_t f = inoff + (int64_t)ofactor * (ilo + 1);
-                    if (f >= 0 && f <= half2)
-                        acc1 = fma(k, tab[f], acc1);
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    acc0 = fma(k0[u], v0[u], acc0);
+                    acc1 = fma(k1[u], v1[u], acc1);
                 }
             }
         }
@@ -2246,6 +2300,9 @@ int pb_lbl_create(pb_lbl **out, pb_voigt *voigt, pb_lines *lines, const double *
         PB_REQUIRE(isoimol_h[i] >= 0 && isoimol_h[i] < nmol,
                    "pb_lbl_create: isoimol[%d] out of range", i);
     PB_REQUIRE(divisors_h[0] >= 1, "pb_lbl_create: divisors must start at >= 1");
+    PB_REQUIRE(resolution || voigt->d_pm,
+               "pb_lbl_create: this Voigt table keeps the reference layout only (keep_flat = 2); "
+               "constant-step plans need the phase-major layout");
     const double wnstep = wn_h[1] - wn_h[0];
     if (!resolution) {
         // the kept samples of every admissible dynamic grid must be osamp apart
@@ -3237,6 +3294,11 @@ static int lbl_extinction(pb_lbl *p, double *ext_d, int64_t wbegin, int64_t wcou
                 : (S == 4   ? k_ext_staged<kStagedWaves, 4, false>
                    : S == 2 ? k_ext_staged<kStagedWaves, 2, false>
                             : k_ext_staged<kStagedWaves, 1, false>);
+        if (const char *e = getenv("PB_STAGE_PROBE"))
+            if (atoi(e) >= 1 && atoi(e) <= 3 && S == 2 && dma)    // 1, 2: timing probes, wrong sums
+                kern = atoi(e) == 1   ? k_ext_staged<kStagedWaves, 2, true, 1>
+                       : atoi(e) == 2 ? k_ext_staged<kStagedWaves, 2, true, 2>
+                                      : k_ext_staged<kStagedWaves, 2, true, 3>;
         if (lds > 64 * 1024)
             PB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

@@ -369,6 +369,17 @@ int pb_voigt_ensure_flat(pb_voigt *v, hipStream_t stream)
     return PB_OK;
 }
 
+// keep_flat == 2: only the reference layout stays on the device (plans of the `resolution` /
+// `wlstep` mode read nothing else); the phase-major table is released once the flat one exists
+static int release_phase_major(pb_voigt *v, hipStream_t s)
+{
+    PB_HIP(hipStreamSynchronize(s));
+    (void)hipFree(v->d_pm_alloc);
+    v->d_pm_alloc = nullptr;
+    v->d_pm = nullptr;
+    return PB_OK;
+}
+
 extern "C" {
 
 int pb_voigt_create(pb_voigt **out, const double *lorentz_h, int nlor,
@@ -404,6 +415,8 @@ int pb_voigt_create(pb_voigt **out, const double *lorentz_h, int nlor,
     }
     if (rc == PB_OK && keep_flat)
         rc = pb_voigt_ensure_flat(v, s);
+    if (rc == PB_OK && keep_flat == 2)
+        rc = release_phase_major(v, s);
     if (rc == PB_OK && hipStreamSynchronize(s) != hipSuccess) {
         pb::set_error("pb_voigt_create: kernel failed: %s",
                       hipGetErrorString(hipGetLastError()));
@@ -511,7 +524,7 @@ int64_t pb_voigt_device_bytes(const pb_voigt *v)
 {
     if (!v)
         return 0;
-    return (v->npm + 2 * kPmPad + (v->d_flat ? v->nflat : 0)) * 8;
+    return ((v->d_pm_alloc ? v->npm + 2 * kPmPad : 0) + (v->d_flat ? v->nflat : 0)) * 8;
 }
 
 void pb_voigt_destroy(pb_voigt *v)

@@ -700,14 +700,20 @@ class LBLSpectrum:
         self.wcount = self.nwave - wbegin if wcount is None else wcount
         self.itop = itop
         self.maxdepth = case['maxdepth']
+        # (resolution mode reads the reference layout only: keep_flat = 2 keeps no second copy)
+        if g.get('resolution') is not None and not keep_flat:
+            keep_flat = 2
         self.voigt = voigt or VoigtTable.build(vg['lorentz'], vg['doppler'], vg['size'],
                                                g['ownstep'], g['wnosamp'], keep_flat)
         self.lines = lines or LineList(ln['lwn'], ln['elow'], ln['gf'], ln['lid'],
                                        len(iso['isomass']), g['own'])
+        # a constant-resolving-power (or constant-wavelength-step) output grid: the kept samples
+        # are interpolated from the dynamic grid (_extcoeff.c:320-326) and ACCUMULATED into ec
+        self.resolution = g.get('resolution') is not None
         self.lbl = LBL(self.voigt, self.lines, g['wn'], g['divisors'], atm['mol_radius'],
                        atm['mol_mass'], iso['isoimol'], iso['isomass'], iso['isoratio'],
                        iso['isoiext'], vg['cutoff'], case['ethresh'],
-                       max_layers=self.nlayers)
+                       resolution=self.resolution, max_layers=self.nlayers)
         # atmosphere state, resident (+ the host copy of the temperatures that the continuum
         # terms take their per-layer factors from)
         self.temp_host = np.array(atm['temp'], float)
@@ -763,6 +769,8 @@ class LBLSpectrum:
                 self.intervals.copy_(dev(-np.diff(radius)))
 
     def extinction(self):
+        if self.resolution:
+            self.ec.zero_()              # the interpolating kernel adds to what it finds
         if self.kmax_exchange is not None:
             # wavenumber shard of a multi-GPU run: every rank derives the records (and the
             # strengths, the exp() work) of its own groups only; the per-row maxima that set

@@ -60,6 +60,23 @@ def spectral_grid(wnlow, wnhigh, wnstep, wnosamp=None):
                 onwave=onwave, wnosamp=int(wnosamp), divisors=divisors(wnosamp))
 
 
+def resolution_grid(wnlow, wnhigh, resolution, wnstep=1.0, wnosamp=None):
+    """Constant-resolving-power output grid (spec_tools.py:499-504) over the constant-step fine
+    grid the reference keeps in that mode: wnstep stays the config's wnstep (default 1.0 cm-1)
+    and only sets ownstep = wnstep / wnosamp (spectrum.py:184-222)."""
+    if wnosamp is None:
+        wnosamp = int(HCN[wnstep / HCN <= 0.0004][0])
+    f = 0.5 / resolution
+    g = (1.0 + f) / (1.0 - f)
+    nwave = int(np.ceil(-np.log(wnlow / wnhigh) / np.log(g)))
+    wn = wnlow * g**np.arange(nwave)
+    ownstep = wnstep / wnosamp
+    onwave = int(np.ceil((wn[-1] - wnlow) / ownstep)) + 1
+    own = wnlow + np.arange(onwave) * ownstep
+    return dict(wn=wn, own=own, wnstep=wnstep, ownstep=ownstep, nwave=nwave, onwave=onwave,
+                wnosamp=int(wnosamp), divisors=divisors(wnosamp), resolution=float(resolution))
+
+
 def voigt_widths(wn, press_bar, masses, radii_cm, nlor, ndop, tmin=100.0, tmax=3000.0):
     """log-spaced Lorentz/Doppler HWHM samples (voigt.py:27-105 with the
     H2-dominated estimates of broadening.py:411-497)."""
@@ -154,7 +171,7 @@ def lbl_case(nwave_target, nlayers, nlines, *, wnlow=4000.0, wnstep=0.05, wnosam
              niso=1, nlor=100, ndop=50, extent=300.0, cutoff=25.0, dlratio=0.1,
              seed=42, species=('H2', 'He', 'H2O'), vmr=(0.85, 0.149, 4e-4),
              line_species_index=2, iso_masses=None, ptop=1e-6, pbottom=1e2,
-             line_species=None):
+             line_species=None, resolution=None):
     """Everything the LBL hot path needs for one synthetic spectrum.
 
     The line-carrying species is species[line_species_index]; its `niso` isotopes
@@ -168,7 +185,12 @@ def lbl_case(nwave_target, nlayers, nlines, *, wnlow=4000.0, wnstep=0.05, wnosam
     isoiext[i] = position of the isotope's species, so that add=0 gives one extinction
     row per species (pyrat/extinction.py:170-213, _extcoeff.c:203-226,265-272)."""
     wnhigh = wnlow + (nwave_target - 1) * wnstep
-    grid = spectral_grid(wnlow, wnhigh + 0.5 * wnstep, wnstep, wnosamp)
+    if resolution is not None:
+        # `resolution` mode: nwave_target and wnstep only fix the upper boundary; the fine grid
+        # follows the reference's default rule (wnstep 1.0 -> wnosamp 2520) unless wnosamp is given
+        grid = resolution_grid(wnlow, wnhigh, resolution, 1.0, wnosamp)
+    else:
+        grid = spectral_grid(wnlow, wnhigh + 0.5 * wnstep, wnstep, wnosamp)
     atm = synthetic_atmosphere(nlayers, species, vmr, ptop=ptop, pbottom=pbottom)
     if line_species is None:
         carriers = [line_species_index]

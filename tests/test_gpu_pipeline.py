@@ -416,3 +416,40 @@ def test_shard_pipeline_single_process(eng, case):
     np.testing.assert_allclose(hinted.ec.cpu().numpy(), serial.ec.cpu().numpy(), rtol=1e-12)
     with pytest.raises(Exception):
         hinted.lbl.set_concurrency(0)
+
+
+def test_resolution_mode_spectrum(eng, orc):
+    """A constant-resolving-power output grid through LBLSpectrum (the reference's `resolution`
+    mode: the kept samples are interpolated from the dynamic grid, _extcoeff.c:320-326 /
+    utils.h:139-163, and ACCUMULATED): every layer of ec against the oracle, two runs equal (the
+    model zeroes ec itself), the table kept in the reference layout only (keep_flat = 2), and a
+    constant-step plan on such a table refused."""
+    import torch
+    from pyratbay_amd import synth
+    case = synth.lbl_case(2001, 6, 5000, wnosamp=24, nlor=14, ndop=7, extent=60.0, cutoff=3.0,
+                          niso=2, seed=17, resolution=60000.0)
+    g, atm, ln, iso, vg = (case[k] for k in ('grid', 'atm', 'lines', 'iso', 'voigt'))
+    assert g['resolution'] == 60000.0 and abs(g['wn'][1] / g['wn'][0] - 1 - 1 / 60000.0) < 1e-9
+    model = eng.LBLSpectrum(case, rt_path='transit')
+    first = model.run().clone()
+    assert model.lbl.last_gather_kernel == 'k_ext_linterp'
+    assert torch.equal(model.run(), first)                 # ec is zeroed per run, not summed up
+    vt = model.voigt
+    assert vt.device_bytes < 1.2 * 8 * vt.nprofile         # one layout on the device, not two
+    profile = vt.flat()
+    ec = model.ec.cpu().numpy()[:, 0]
+    for layer in range(atm['nlayers']):
+        want = np.zeros((1, g['nwave']))
+        orc.extinction(want, profile, vt.size, vt.index, vg['lorentz'], vg['doppler'], g['wn'],
+                       g['own'], g['divisors'], atm['dens'][layer], atm['mol_radius'],
+                       atm['mol_mass'], iso['isoimol'], iso['isomass'], iso['isoratio'],
+                       iso['isoz'][:, layer].copy(), iso['isoiext'], ln['lwn'], ln['elow'],
+                       ln['gf'], ln['lid'], vg['cutoff'], case['ethresh'], atm['temp'][layer],
+                       0, 1, 1)
+        assert np.array_equal(ec[layer] == 0, want[0] == 0)
+        np.testing.assert_allclose(ec[layer], want[0], rtol=RTOL)
+    assert np.count_nonzero(ec) > 0.5 * ec.size
+    with pytest.raises(Exception, match='reference layout only'):
+        eng.LBL(vt, model.lines, g['wn'][:10] * 0 + g['wn'][0] + 0.05 * np.arange(10),
+                g['divisors'], atm['mol_radius'], atm['mol_mass'], iso['isoimol'],
+                iso['isomass'], iso['isoratio'], iso['isoiext'], vg['cutoff'], 1e-30)

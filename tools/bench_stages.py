@@ -10,8 +10,7 @@ from pyratbay_amd import engine, synth
 name = sys.argv[1] if len(sys.argv) > 1 else 'c2'
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 10
 w = bench.WORKLOADS[name]
-case = synth.lbl_case(w['nwave'], w['nlayers'], w['nlines'], wnstep=w['wnstep'],
-                      niso=w['niso'], seed=42)
+case = bench.make_case(w)
 nshard = int(sys.argv[3]) if len(sys.argv) > 3 else 1
 from pyratbay_amd.dist import shard_bounds
 b = shard_bounds(case['grid']['nwave'], nshard)
