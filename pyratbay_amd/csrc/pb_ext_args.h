@@ -113,6 +113,12 @@ struct LblArgs {
     // (see the kernel's block decoding); split 0 writes ext, the others part[split-1][layer][row][sample]
     int nsplit;
     double *part;
+    // per-layer phase split of the staged kernel (null: every layer is split nsplit ways): the
+    // (layer, split) units of the launch in dispatch order, unit_tab[u] = layer << 8 | split, and
+    // the number of pieces of every layer; nsplit is then the largest of them (plane count)
+    const int32_t *unit_tab;
+    const int32_t *lsplit;
+    int nunits;
     // per (layer, phase-sorted group) records written by k_records [nlayers][ngroups]
     double *rec_k;                    // co-added strength (before threshold / density)
     int32_t *rec_ulo, *rec_uhi;       // window on the global output grid

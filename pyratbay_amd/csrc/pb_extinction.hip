@@ -786,11 +786,19 @@ __global__ __launch_bounds__(NW * 64, 8) void k_ext_staged(LblArgs a)
         tile = k % a.ntiles;
         const int grp = k / a.ntiles;                  // snake order over the XCDs: decode_block
         const int unit = grp * 8 + ((grp & 1) ? 7 - (id & 7) : (id & 7));
-        layer = a.nlayers - 1 - unit / a.nsplit;       // < 0 for the padding blocks
-        zsplit = unit % a.nsplit;
+        if (a.unit_tab) {
+            // per-layer split: the unit table lists the (layer, piece) pairs, deepest layer first
+            const int e = unit < a.nunits ? a.unit_tab[unit] : -1;
+            layer = e < 0 ? -1 : e >> 8;
+            zsplit = e & 0xff;
+        } else {
+            layer = a.nlayers - 1 - unit / a.nsplit;   // < 0 for the padding blocks
+            zsplit = unit % a.nsplit;
+        }
     }
     if (layer < 0 || (a.res_cap > 0 && a.ls_resident[layer]))
         return;
+    const int nsp = a.lsplit ? a.lsplit[layer] : a.nsplit;    // pieces of this layer's tiles
     const int row = blockIdx.y;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -958,7 +966,7 @@ __global__ __launch_bounds__(NW * 64, 8) void k_ext_staged(LblArgs a)
         for (int r = 0; r < per; r++) {
             const int pv = tid * per + r;
             const int p = pv / nch, c = pv - p * nch;
-            if (pv < nvirt && ((a.nsplit > 1 && p * a.nsplit / osamp != zsplit) ||
+            if (pv < nvirt && ((nsp > 1 && p * nsp / osamp != zsplit) ||
                                iso * osamp + p < a.key_lo || iso * osamp + p >= a.key_hi)) {
                 s_phs[pv] = 0;                     // another workgroup's, or another chunk's, phase
                 s_cum[pv] = 0;
@@ -1816,6 +1824,25 @@ __global__ __launch_bounds__(kBlock) void k_combine_parts(double *ext, const dou
     ext[i] = v;
 }
 
+// the same with a per-layer number of pieces: grid.y = layer, layers in one piece are skipped
+__global__ __launch_bounds__(kBlock) void k_combine_layer_parts(double *ext, const double *part,
+                                                               const int32_t *lsplit,
+                                                               int64_t per_layer, int64_t n)
+{
+    const int layer = blockIdx.y;
+    const int nparts = lsplit[layer] - 1;
+    if (nparts <= 0)
+        return;
+    const int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (j >= per_layer)
+        return;
+    const int64_t i = (int64_t)layer * per_layer + j;
+    double v = ext[i];
+    for (int p = 0; p < nparts; p++)
+        v += part[(int64_t)p * n + i];
+    ext[i] = v;
+}
+
 // ---------------------------------------------------------------------------
 // 3b. gather, arbitrary output grid (resolution / wlstep mode): every output needs the
 // two dynamic-grid samples that bracket it (linterp, utils.h:139-163).  Uses the
@@ -2070,6 +2097,10 @@ struct pb_lbl {
     // the line list (pb_lbl_set_record_budget; PB_RECORD_BUDGET overrides)
     size_t record_budget = (size_t)96 << 30;
     int last_chunks = 0;     // chunks of the last call (0 = records of every group at once)
+    // per-layer phase split of the staged kernel: device tables and the configuration they hold
+    int32_t *d_unit_tab = nullptr, *d_lsplit = nullptr;
+    int ut_key[4] = {-1, -1, -1, -1};                 // nlayers, base split, deep layers, deep split
+    int ut_units = 0;
     int concurrency = 1;     // independent calls the caller keeps in flight beside this plan's
     int gather_mode = 0;     // 0 = choose, 1 = global gather, 2 = LDS-staged, 3 = resident+global
     int last_gather = 0;     // last call: 1 global, 2 staged, 3 linterp; +8 = resident kernel too
@@ -3269,9 +3300,70 @@ static int lbl_extinction(pb_lbl *p, double *ext_d, int64_t wbegin, int64_t wcou
                                                                              rsplit - 1, n);
         }
     } else if (staged) {
+        // Per-layer split.  A launch ends when its slowest workgroup does, and the slowest are the
+        // tiles of the deepest layers (cutoff-limited windows of ~1000 samples against 200-300
+        // higher up: 0.7-0.9 ms of a 0.88-ms C2 launch, profiles/r02_gather_ab.md), which the
+        // dispatch order puts first.  The deepest `deep` layers are cut into more pieces than the
+        // others, so that no single workgroup spans the launch.  Pieces of a tile add their sums in
+        // a fixed order (k_combine_layer_parts): bitwise reproducible; against an unsplit launch
+        // the association of a sample's terms differs (~1e-16).  PB_STAGE_SPLIT pins one split for
+        // every layer (the exactness tests), PB_STAGE_DEEP=frac[,factor] tunes the rule.
+        // Measured (profiles/r03_gather_ab.md): C3 44.1 -> 42.3 ms (-4 %), the 1e6-line list -1 %,
+        // C2 +4 % (one spectrum at a time) / +3 % (pipelined): the second prologue and the combine
+        // pass cost a light launch more than its tail does.  On by default only for long rows.
+        int deep = 0, deep_split = nsplit;
+        if (!getenv("PB_STAGE_SPLIT") && nsplit < 8 && nlayers >= 8) {
+            double frac = a.nch_max > 1 ? 0.3 : 0.0;
+            int factor = 2;
+            if (const char *e = getenv("PB_STAGE_DEEP")) {
+                frac = atof(e);
+                if (const char *c = strchr(e, ','))
+                    factor = std::max(1, atoi(c + 1));
+            }
+            deep = (int)(frac * nlayers + 0.5);
+            deep_split = std::min(8, nsplit * factor);
+            const int64_t plane = (int64_t)nlayers * a.nrows * wcount * 8;
+            while (deep_split > nsplit && (deep_split - 1) * plane > ((int64_t)1 << 30))
+                deep_split--;
+            if (deep <= 0 || deep_split <= nsplit)
+                deep = 0, deep_split = nsplit;
+        }
+        a.unit_tab = nullptr;
+        a.lsplit = nullptr;
+        a.nunits = 0;
+        if (deep > 0) {
+            if (p->ut_key[0] != nlayers || p->ut_key[1] != nsplit || p->ut_key[2] != deep ||
+                p->ut_key[3] != deep_split) {
+                std::vector<int32_t> tab, ls((size_t)nlayers);
+                for (int layer = nlayers - 1; layer >= 0; layer--) {
+                    const int n = layer >= nlayers - deep ? deep_split : nsplit;
+                    ls[(size_t)layer] = n;
+                    for (int z = 0; z < n; z++)
+                        tab.push_back((layer << 8) | z);
+                }
+                PB_HIP(hipStreamSynchronize(s));       // an earlier call may still read the tables
+                (void)hipFree(p->d_unit_tab);
+                (void)hipFree(p->d_lsplit);
+                p->d_unit_tab = p->d_lsplit = nullptr;
+                PB_HIP(hipMalloc(&p->d_unit_tab, tab.size() * 4));
+                PB_HIP(hipMalloc(&p->d_lsplit, ls.size() * 4));
+                PB_HIP(hipMemcpy(p->d_unit_tab, tab.data(), tab.size() * 4, hipMemcpyHostToDevice));
+                PB_HIP(hipMemcpy(p->d_lsplit, ls.data(), ls.size() * 4, hipMemcpyHostToDevice));
+                p->ut_key[0] = nlayers;
+                p->ut_key[1] = nsplit;
+                p->ut_key[2] = deep;
+                p->ut_key[3] = deep_split;
+                p->ut_units = (int)tab.size();
+            }
+            a.unit_tab = p->d_unit_tab;
+            a.lsplit = p->d_lsplit;
+            a.nunits = p->ut_units;
+        }
+        const int nunits = deep > 0 ? p->ut_units : nlayers * nsplit;
+        const int nplanes = deep > 0 ? deep_split : nsplit;
         a.nsplit = nsplit;
-        if (nsplit > 1) {
-            const size_t need = (size_t)(nsplit - 1) * nlayers * a.nrows * wcount * 8;
+        if (nplanes > 1) {
+            const size_t need = (size_t)(nplanes - 1) * nlayers * a.nrows * wcount * 8;
             if (need > p->part_bytes) {
                 (void)hipFree(p->part);
                 p->part = nullptr;
@@ -3285,7 +3377,7 @@ static int lbl_extinction(pb_lbl *p, double *ext_d, int64_t wbegin, int64_t wcou
             a.part = p->part;
         }
         a.ntiles = pb::div_up(wcount, S * sub);
-        const int unit_groups = (nlayers * nsplit + 7) / 8;     // (layer, split) units per XCD
+        const int unit_groups = (nunits + 7) / 8;               // (layer, split) units per XCD
         dim3 grid((unsigned)(8 * a.ntiles * unit_groups), a.nrows);
         void (*kern)(LblArgs) =
             dma ? (S == 4   ? k_ext_staged<kStagedWaves, 4, true>
@@ -3303,7 +3395,13 @@ static int lbl_extinction(pb_lbl *p, double *ext_d, int64_t wbegin, int64_t wcou
             PB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         kern<<<grid, kStagedThreads, lds, s>>>(a);
-        if (nsplit > 1) {
+        if (deep > 0) {
+            PB_LAUNCH_CHECK();
+            const int64_t per_layer = (int64_t)a.nrows * wcount;
+            dim3 cgrid((unsigned)pb::div_up(per_layer, kBlock), nlayers);
+            k_combine_layer_parts<<<cgrid, kBlock, 0, s>>>(ext_d, p->part, p->d_lsplit, per_layer,
+                                                          (int64_t)nlayers * per_layer);
+        } else if (nsplit > 1) {
             PB_LAUNCH_CHECK();
             const int64_t n = (int64_t)nlayers * a.nrows * wcount;
             k_combine_parts<<<(unsigned)pb::div_up(n, kBlock), kBlock, 0, s>>>(ext_d, p->part,
@@ -3528,6 +3626,8 @@ void pb_lbl_destroy(pb_lbl *p)
     (void)hipFree(p->rec16);
     (void)hipFree(p->part);
     (void)hipFree(p->d_wm);
+    (void)hipFree(p->d_unit_tab);
+    (void)hipFree(p->d_lsplit);
     (void)hipFree(p->gs_start);
     (void)hipFree(p->ls_dnwn);
     (void)hipFree(p->ls_dwnstep);

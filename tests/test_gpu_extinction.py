@@ -841,3 +841,45 @@ def test_chunked_line_list_equals_one_call(eng, orc, monkeypatch, long_rows, eth
     cut.set_record_budget(int(total / 3))
     with pytest.raises(Exception, match='record budget'):
         cut.extinction_begin(t, d, z, add=True, wbegin=0, wcount=2000)
+
+
+@pytest.mark.parametrize('deep', ['0.5,3', '0.3,2', '1.0,8'])
+def test_per_layer_phase_split(eng, orc, monkeypatch, deep):
+    """The deepest layers of a staged launch can be cut into more pieces than the others (a unit
+    table instead of one split for every layer; their partial sums are added in a fixed order by
+    k_combine_layer_parts).  Same terms: equal to the unsplit launch to 1e-13 and to the oracle,
+    identical zero pattern, two runs bitwise equal -- also with every layer deep and with the
+    base launch already split."""
+    import torch
+    from pyratbay_amd import synth
+    case = synth.lbl_case(9001, 11, 40000, wnosamp=24, nlor=18, ndop=9, extent=80.0,
+                          cutoff=3.0, niso=3, seed=41)
+    g, atm, ln, iso, vg = (case[k] for k in ('grid', 'atm', 'lines', 'iso', 'voigt'))
+    vt = eng.VoigtTable.build(vg['lorentz'], vg['doppler'], vg['size'], g['ownstep'], 24)
+    ll = eng.LineList(ln['lwn'], ln['elow'], ln['gf'], ln['lid'], 3, g['own'])
+    lbl = eng.LBL(vt, ll, g['wn'], g['divisors'], atm['mol_radius'], atm['mol_mass'],
+                  iso['isoimol'], iso['isomass'], iso['isoratio'], iso['isoiext'],
+                  vg['cutoff'], 1e-30, max_layers=11)
+    lbl.set_gather_mode('staged')
+    t, d, z = eng.dev(atm['temp']), eng.dev(atm['dens']), eng.dev(iso['isoz'])
+    monkeypatch.setenv('PB_STAGE_DEEP', '0')
+    plain = lbl.extinction(t, d, z, add=True).clone()
+    monkeypatch.setenv('PB_STAGE_DEEP', deep)
+    got = lbl.extinction(t, d, z, add=True).clone()
+    assert torch.equal(lbl.extinction(t, d, z, add=True), got)
+    assert torch.equal(got == 0, plain == 0)
+    rel = ((got - plain).abs() / plain.abs().clamp_min(1e-300)).max().item()
+    assert rel <= 1e-13, rel
+    rows = lbl.extinction(t, d, z, add=False)                    # two output rows, same split
+    monkeypatch.setenv('PB_STAGE_DEEP', '0')
+    rows0 = lbl.extinction(t, d, z, add=False)
+    assert ((rows - rows0).abs() / rows0.abs().clamp_min(1e-300)).max().item() <= 1e-13
+    profile = vt.flat()
+    for layer in (0, 5, 10):
+        want = np.zeros((1, g['nwave']))
+        orc.extinction(want, profile, vt.size, vt.index, vg['lorentz'], vg['doppler'], g['wn'],
+                       g['own'], g['divisors'], atm['dens'][layer], atm['mol_radius'],
+                       atm['mol_mass'], iso['isoimol'], iso['isomass'], iso['isoratio'],
+                       iso['isoz'][:, layer].copy(), iso['isoiext'], ln['lwn'], ln['elow'],
+                       ln['gf'], ln['lid'], vg['cutoff'], 1e-30, atm['temp'][layer], 0, 1, 0)
+        np.testing.assert_allclose(host(got)[layer], want, rtol=RTOL)
