@@ -2809,8 +2809,9 @@ static int lbl_extinction(pb_lbl *p, double *ext_d, int64_t wbegin, int64_t wcou
     int S = 2;
     int nsplit = (int)std::min<int64_t>(
         8, pb::div_up((int64_t)(per_phase >= 64.0 ? 8000 : 2000), std::max<int64_t>(1, blocks2)));
-    if (shared_chip)           // at most one round of workgroups on the chip's 1024 slots
-        nsplit = (int)std::max<int64_t>(1, std::min<int64_t>(8, 1024 / std::max<int64_t>(1, blocks2)));
+    if (shared_chip)           // about one round of workgroups on the chip's 1024 slots
+        nsplit = (int)std::max<int64_t>(
+            1, std::min<int64_t>(8, (1024 + blocks2 / 2) / std::max<int64_t>(1, blocks2)));
     {
         const int64_t plane = (int64_t)nlayers * a.nrows * wcount * 8;
         while (nsplit > 1 && (nsplit - 1) * plane > ((int64_t)1 << 30))
@@ -2831,7 +2832,9 @@ static int lbl_extinction(pb_lbl *p, double *ext_d, int64_t wbegin, int64_t wcou
         S = atoi(e) >= 4 ? 4 : atoi(e) >= 2 ? 2 : 1;
     if (const char *e = getenv("PB_STAGE_SPLIT"))
         nsplit = std::max(1, std::min(8, atoi(e)));
-    const bool enough_blocks = pb::div_up(wcount, S * sub) * (int64_t)nlayers * nsplit >= 750;
+    // (with other spectra in flight the launches of all of them count towards filling the chip)
+    const bool enough_blocks = pb::div_up(wcount, S * sub) * (int64_t)nlayers * nsplit *
+                                   (shared_chip ? p->concurrency : 1) >= 750;
     // round-staged kernel (pb_rounds.hip): rows of one piece (<= 1024 samples), packed records
     const bool rounds = can_stage && a.nch_max == 1 && packable && p->gather_mode == 5;
     const bool staged = can_stage && (p->gather_mode == 2 || rounds ||

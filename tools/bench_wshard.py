@@ -47,4 +47,5 @@ if streams > 1:
     pipe.flush()
     torch.cuda.synchronize()
     print(f'{name} shard {r}/{world} (two-phase, {streams} in flight): '
-          f'{(time.perf_counter() - t0) / steps * 1e3:.3f} ms/spectrum', flush=True)
+          f'{(time.perf_counter() - t0) / steps * 1e3:.3f} ms/spectrum '
+          f'[{pipe.models[0].lbl.last_gather_kernel}]', flush=True)
