@@ -557,8 +557,8 @@ typedef double d2u __attribute__((ext_vector_type(2), aligned(8)));
 // four being multiplied.  The loads carry no branch (rows beyond the last layer and columns beyond
 // the grid read a clamped address: their Q entries are zero, their results unused): behind a
 // divergent `if` the compiler drains every load (s_waitcnt vmcnt(0)) before it issues the next.
-template <int MT, int WPS>
-__global__ __launch_bounds__(kBlock, WPS) void k_transit_mfma(
+template <int MT, int WPS, int TB>
+__global__ __launch_bounds__(TB, WPS) void k_transit_mfma(
     double *spectrum, const double *ec, const double *qblk, const double *radius, int nblk,
     double rstar, int itop, int ibottom, double maxdepth, int nlayers, int nwave)
 {
@@ -569,13 +569,13 @@ __global__ __launch_bounds__(kBlock, WPS) void k_transit_mfma(
     double *s_rad = s_q + (size_t)nblk * 64;
     {
         const double *q = qblk + (int64_t)w * nblk * 64;
-        for (int e = tid; e < nblk * 64; e += kBlock)
+        for (int e = tid; e < nblk * 64; e += TB)
             s_q[e] = q[e];
-        for (int r = tid; r < 16 * MT; r += kBlock)
+        for (int r = tid; r < 16 * MT; r += TB)
             s_rad[r] = r < nimpact ? radius[(int64_t)w * nlayers + itop + r] : 0.0;
     }
     __syncthreads();
-    const int c0 = (blockIdx.x * (kBlock / 64) + wave) * 32;
+    const int c0 = (blockIdx.x * (TB / 64) + wave) * 32;
     if (c0 >= nwave)
         return;                                           // (after the only barrier)
     const int kq = lane >> 4, n = lane & 15;
@@ -925,33 +925,35 @@ int pb_transit_fused_launch(double *depth_d, int32_t *ideep_d, double *spectrum_
             k_path_qblocks<<<qgrid, kBlock, 0, s>>>(work_d, raypath_d, npath, nblk, nimpact);
             PB_LAUNCH_CHECK();
             const size_t lds = ((size_t)nblk * 64 + (size_t)mt * 16) * 8;
-            const int nt = 2;
-            dim3 mgrid(pb::div_up(nwave, (kBlock / 64) * 16 * nt), nwalkers);
-#define PB_MFMA(M, W)                                                                            \
+#define PB_MFMA(M, W, T)                                                                         \
     do {                                                                                         \
         if (lds > 64 * 1024)                                                                     \
-            PB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_transit_mfma<M, W>),    \
+            PB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_transit_mfma<M, W, T>), \
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));   \
-        k_transit_mfma<M, W><<<mgrid, kBlock, lds, s>>>(spectrum_d, ec_d, work_d, radius_d, nblk, \
-                                                       rstar, itop, ibottom, maxdepth, nlayers,  \
-                                                       nwave);                                   \
+        dim3 mgrid(pb::div_up(nwave, (T / 64) * 32), nwalkers);                                  \
+        k_transit_mfma<M, W, T><<<mgrid, T, lds, s>>>(spectrum_d, ec_d, work_d, radius_d, nblk,  \
+                                                     rstar, itop, ibottom, maxdepth, nlayers,    \
+                                                     nwave);                                     \
     } while (0)
+            // threads per workgroup: a workgroup stages its walker's Q blocks (30 KB at 80
+            // layers) once for TB / 64 x 32 columns
+            const int tb = getenv("PB_MFMA_TB") ? atoi(getenv("PB_MFMA_TB")) : 512;
             switch (mt) {
-            case 1: PB_MFMA(1, 4); break;
-            case 2: PB_MFMA(2, 4); break;
-            case 3: PB_MFMA(3, 4); break;
-            case 4: PB_MFMA(4, 4); break;
+            case 1: PB_MFMA(1, 4, 256); break;
+            case 2: PB_MFMA(2, 4, 256); break;
+            case 3: PB_MFMA(3, 4, 256); break;
+            case 4: PB_MFMA(4, 4, 256); break;
             case 5:
-                if (getenv("PB_MFMA_WPS") && atoi(getenv("PB_MFMA_WPS")) == 3)
-                    PB_MFMA(5, 3);
-                else if (getenv("PB_MFMA_WPS") && atoi(getenv("PB_MFMA_WPS")) == 2)
-                    PB_MFMA(5, 2);
+                if (tb >= 1024)
+                    PB_MFMA(5, 4, 1024);
+                else if (tb >= 512)
+                    PB_MFMA(5, 4, 512);
                 else
-                    PB_MFMA(5, 4);
+                    PB_MFMA(5, 4, 256);
                 break;
-            case 6: PB_MFMA(6, 2); break;
-            case 7: PB_MFMA(7, 2); break;
-            default: PB_MFMA(8, 2); break;
+            case 6: PB_MFMA(6, 2, 256); break;
+            case 7: PB_MFMA(7, 2, 256); break;
+            default: PB_MFMA(8, 2, 256); break;
             }
 #undef PB_MFMA
             PB_LAUNCH_CHECK();
