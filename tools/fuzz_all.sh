@@ -13,3 +13,4 @@ run tools/fuzz_rt.py $((2000 * s))
 run tools/fuzz_continuum.py $((3000 * s))
 run tools/fuzz_dropin.py $((8000 * s))
 run tools/fuzz_opacity.py $((2000 * s))
+run tools/fuzz_r3.py $((3000 * s))
