@@ -22,6 +22,9 @@ PB_STREAMS=1 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/
 cp $(find gpurun_out/prof_c2res -name '*kernel_stats.csv' | head -1) gpurun_out/${tag}_kernel_stats_c2res.csv
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_c5 -- python bench.py --workload c5 --steps 20 --no-cpu-baseline > gpurun_out/prof_c5.log 2>&1 || exit 1
 cp $(find gpurun_out/prof_c5 -name '*kernel_stats.csv' | head -1) gpurun_out/${tag}_kernel_stats_c5.csv
+rm -rf gpurun_out/prof_marker
+rocprofv3 --marker-trace --kernel-trace --stats --output-format csv -d gpurun_out/prof_marker -- python tools/show_timestamps.py c2 > gpurun_out/${tag}_timestamps.log 2>&1 || exit 1
+cp $(find gpurun_out/prof_marker -name '*marker_api_stats.csv' | head -1) gpurun_out/${tag}_marker_api_stats.csv
 echo "kernel stats done"
 python bench.py --workload c5 > gpurun_out/${tag}_bench_c5.json 2> gpurun_out/${tag}_bench_c5.err || exit 1
 PB_TRANSIT_MFMA=0 python bench.py --workload c5 --no-cpu-baseline > gpurun_out/${tag}_bench_c5_vector.json 2> gpurun_out/${tag}_bench_c5_vector.err || exit 1
@@ -31,6 +34,7 @@ python bench.py --workload c4 --steps 3 --warmup 1 --cpu-layers 2 > gpurun_out/$
 echo "other workloads done"
 { for n in 2 4 8; do python tools/bench_wshard.py $n c2 3; done; python tools/bench_wshard.py 8 c2-1e6 3; python tools/bench_wshard.py 8 c2 2; python tools/bench_wshard.py 8 c2-1e6 2; } 2>&1 | grep shard > gpurun_out/${tag}_wshard.log
 python tools/bench_dropin.py 2>&1 | grep drop-in > gpurun_out/${tag}_dropin.log
+python tools/bench_outofcore.py --lines 1e8 --budget-gib 16 --check --out gpurun_out/${tag}_outofcore_1e8.json > gpurun_out/${tag}_outofcore.log 2>&1 || { tail -3 gpurun_out/${tag}_outofcore.log; exit 1; }
 echo "rank shards done"
 python tools/pmc_traffic.py c2 > gpurun_out/pmc_traffic.log 2>&1 || { tail -5 gpurun_out/pmc_traffic.log; exit 1; }
 tail -2 gpurun_out/pmc_traffic.log
