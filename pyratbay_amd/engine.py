@@ -1065,24 +1065,22 @@ class TableSpectrum:
         return out
 
     def _eval_chunk(self, temps, dens, bands, radius, shared_radius, path1, out, w0, w1):
-        transit = self.rt_path == 'transit'
-        if True:
-            n = w1 - w0
-            ec = interp_ec_batch(self.etable, self.ttable, temps[w0:w1], dens[w0:w1])
-            if not transit:
-                rad = radius.expand(n, -1) if shared_radius else radius[w0:w1]
-                intervals = (rad[:, :-1] - rad[:, 1:]).contiguous()        # -diff(radius)
-                spectra = emission_flux_batch(ec, intervals, self.wn, temps[w0:w1], self.mu,
-                                              self.weights, self.itop, self.nlayers,
-                                              self.maxdepth)
-                bands.integrate_batch(spectra, out[w0:w1])
-                return
-            if shared_radius:
-                rad = radius.expand(n, -1).contiguous()
-                path = path1.expand(n, -1).contiguous()
-            else:
-                rad = radius[w0:w1].contiguous()
-                path = transit_path_device(rad, self.itop)
-            spectra = transit_spectrum_batch(ec, path, rad, self.rstar, self.itop, self.nlayers,
-                                             self.maxdepth)
+        """One chunk of eval_bands: walkers [w0, w1) through every stage, one launch each."""
+        n = w1 - w0
+        ec = interp_ec_batch(self.etable, self.ttable, temps[w0:w1], dens[w0:w1])
+        if self.rt_path != 'transit':
+            rad = radius.expand(n, -1) if shared_radius else radius[w0:w1]
+            intervals = (rad[:, :-1] - rad[:, 1:]).contiguous()            # -diff(radius)
+            spectra = emission_flux_batch(ec, intervals, self.wn, temps[w0:w1], self.mu,
+                                          self.weights, self.itop, self.nlayers, self.maxdepth)
             bands.integrate_batch(spectra, out[w0:w1])
+            return
+        if shared_radius:
+            rad = radius.expand(n, -1).contiguous()
+            path = path1.expand(n, -1).contiguous()
+        else:
+            rad = radius[w0:w1].contiguous()
+            path = transit_path_device(rad, self.itop)
+        spectra = transit_spectrum_batch(ec, path, rad, self.rstar, self.itop, self.nlayers,
+                                         self.maxdepth)
+        bands.integrate_batch(spectra, out[w0:w1])
