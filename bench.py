@@ -32,6 +32,9 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# HIP maps streams onto this many hardware queues (default 4); the pipelines, the default stream
+# and RCCL's own streams are more than four at N > 1, and two streams on one queue do not overlap
+os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
 
 C4_SPECIES = ('H2', 'He', 'H2O', 'CO', 'CO2', 'CH4')
 C4_VMR = (0.85, 0.149, 4e-4, 5e-4, 1e-7, 1e-4)

@@ -916,10 +916,10 @@ int pb_transit_fused_launch(double *depth_d, int32_t *ideep_d, double *spectrum_
     {
         // (read per call: the tests switch it inside one process)
         const char *mode = getenv("PB_TRANSIT_MFMA");
-        const bool no_mfma = mode && atoi(mode) == 0, force_mfma = mode && atoi(mode) == 2;
+        const bool no_mfma = mode && atoi(mode) == 0;
         const int mt = pb::div_up(std::max(nimpact, 1), 16);
         if (!no_mfma && work_d && spectrum_d && !depth_d && !ideep_d && deck_row < 0 &&
-            nimpact > 1 && mt <= 8 && nwave >= 2 && (nwalkers > 1 || force_mfma)) {
+            nimpact > 1 && mt <= 8 && nwave >= 2 && nwalkers >= 1) {
             const int nblk = qblocks(mt);
             dim3 qgrid((unsigned)std::min(16, pb::div_up((int64_t)nblk * 64, kBlock)), nwalkers);
             k_path_qblocks<<<qgrid, kBlock, 0, s>>>(work_d, raypath_d, npath, nblk, nimpact);

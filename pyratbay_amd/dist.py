@@ -391,13 +391,13 @@ class ShardPipeline:
     submit() -> (full spectrum on every rank, event); flush() joins the caller's stream."""
 
     def __init__(self, case, world, rank, depth=2, group=None, kmax_exchange=True,
-                 voigt=None, lines=None, rt_path='transit'):
+                 voigt=None, lines=None, rt_path='transit', **model_kw):
         from . import engine
         nwave = case['grid']['nwave']
         self.world, self.rank, self.group = world, rank, group
         self.gathers = [SpectrumGather(nwave, world, rank, 'cuda', group) for _ in range(depth)]
         g0 = self.gathers[0]
-        kw = dict(rt_path=rt_path, wbegin=g0.wbegin, wcount=g0.wcount)
+        kw = dict(rt_path=rt_path, wbegin=g0.wbegin, wcount=g0.wcount, **model_kw)
         first = engine.LBLSpectrum(case, voigt=voigt, lines=lines, **kw)
         self.models = [first] + [engine.LBLSpectrum(case, voigt=first.voigt, lines=first.lines,
                                                     **kw) for _ in range(depth - 1)]
@@ -405,7 +405,7 @@ class ShardPipeline:
             m.lbl.set_concurrency(depth)
             if kmax_exchange and world > 1:
                 m.kmax_exchange = kmax_allreduce(group)
-        self.streams = [torch.cuda.Stream() for _ in range(depth)]
+        self.streams = engine.side_streams(depth)
         self.done = [None] * depth
         self.count = 0
 

@@ -26,6 +26,22 @@ def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+_SIDE_STREAMS = []
+
+
+def side_streams(n):
+    """The process-wide side streams 0 .. n-1 (created once, shared by every pipeline object).
+    HIP maps streams onto a handful of hardware queues (GPU_MAX_HW_QUEUES, default 4) in the order
+    they are created; two streams on one queue run their kernels strictly one after the other.
+    A process that makes fresh streams for every SpectrumPipeline / ShardPipeline soon has two
+    "concurrent" contexts on the same queue (seen in a kernel trace: the second of two pipelines
+    of one process ran fully serialised).  Re-using the same few streams keeps the mapping the
+    one the first pipeline got."""
+    while len(_SIDE_STREAMS) < n:
+        _SIDE_STREAMS.append(torch.cuda.Stream())
+    return _SIDE_STREAMS[:n]
+
+
 def _ptr(t):
     if t is None:
         return None
@@ -682,11 +698,17 @@ class LBLSpectrum:
     def __init__(self, case, rt_path='transit', wbegin=0, wcount=None, itop=0,
                  quadrature_mu=None, quadrature_weights=None, keep_flat=False,
                  voigt=None, lines=None, tint=0.0, flux_top=None, continuum=None,
-                 continuum_density=None, timestamps=True):
+                 continuum_density=None, timestamps=True, materialize_depth=True):
         require_gpu()
         # per-stage HIP-event timers behind the `timestamps` property (the reference's
         # pyrat.timestamps keys); timestamps=False: run() records no events
         self._timer = StageTimer() if timestamps else None
+        # materialize_depth=False (transit geometry): run() computes the optical depths, applies
+        # the reference's exit rule and integrates the spectrum in ONE pass on the matrix cores
+        # (pb_transit_spectrum_batch with one "walker": tau = Q . ec) without
+        # writing depth[L, W] / ideep[W] -- `self.depth` and `self.ideep` then stay None.  The
+        # default keeps the reference's outputs (pyrat.od.depth, pyrat.od.ideep).
+        self.materialize_depth = bool(materialize_depth)
         g, atm, ln, iso, vg = (case['grid'], case['atm'], case['lines'], case['iso'],
                                case['voigt'])
         self.case = case
@@ -843,6 +865,16 @@ class LBLSpectrum:
         self.extinction()
         if t is not None:
             t.mark('extinction', 'odepth')
+        if self.rt_path == 'transit' and not self.materialize_depth:
+            if t is not None:
+                t.mark('odepth', 'spectrum')        # (no separate stage: counted under 'spectrum')
+            self.depth = self.ideep = None
+            self.spectrum = transit_spectrum_batch(
+                self.ec.view(1, self.nlayers, self.wcount), self.raypath.view(1, -1),
+                self.radius.view(1, -1), self.rstar, self.itop, self.nlayers, self.maxdepth)[0]
+            if t is not None:
+                t.mark('spectrum')
+            return self.spectrum
         if self.rt_path == 'transit':
             self.spectrum, self.depth, self.ideep = transit_spectrum(
                 self.ec.view(self.nlayers, self.wcount), self.raypath, self.radius,
@@ -892,7 +924,7 @@ class SpectrumPipeline:
         self.models = [first] + [LBLSpectrum(case, **kw) for _ in range(depth - 1)]
         for m in self.models:
             m.lbl.set_concurrency(depth)
-        self.streams = [torch.cuda.Stream() for _ in range(depth)]
+        self.streams = side_streams(depth)
         self.done = [None] * depth          # completion event of each context's last spectrum
         self.count = 0
 
@@ -1045,8 +1077,7 @@ class TableSpectrum:
         streams = max(1, min(streams, nchunks))
         caller = torch.cuda.current_stream()
         if streams > 1:
-            if len(getattr(self, '_eval_streams', [])) < streams:
-                self._eval_streams = [torch.cuda.Stream() for _ in range(streams)]
+            self._eval_streams = side_streams(streams)
             for st in self._eval_streams[:streams]:
                 st.wait_stream(caller)
         for ci, w0 in enumerate(range(0, nw, chunk)):

@@ -453,3 +453,31 @@ def test_resolution_mode_spectrum(eng, orc):
         eng.LBL(vt, model.lines, g['wn'][:10] * 0 + g['wn'][0] + 0.05 * np.arange(10),
                 g['divisors'], atm['mol_radius'], atm['mol_mass'], iso['isoimol'],
                 iso['isomass'], iso['isoratio'], iso['isoiext'], vg['cutoff'], 1e-30)
+
+
+def test_spectrum_without_materialised_depth(eng, case, orc, oracle_ec):
+    """LBLSpectrum(materialize_depth=False): optical depths, the reference's exit rule and the
+    transmission integral in one pass on the matrix cores, depth[L, W] / ideep[W] never written.
+    The spectrum equals the default path's to 1e-13 and the oracle's to 1e-10; the timestamps keep
+    the reference's three keys; two pipelines of one process share their side streams."""
+    import torch
+    atm = case['atm']
+    full = eng.LBLSpectrum(case, rt_path='transit')
+    want = full.run().clone()
+    lean = eng.LBLSpectrum(case, rt_path='transit', voigt=full.voigt, lines=full.lines,
+                           materialize_depth=False)
+    got = lean.run()
+    assert lean.depth is None and lean.ideep is None
+    np.testing.assert_allclose(got.cpu().numpy(), want.cpu().numpy(), rtol=1e-13)
+    depth, ideep = orc.optical_depth_transit(oracle_ec, atm['radius'], 0, atm['nlayers'],
+                                             case['maxdepth'])
+    ref = orc.transmission(depth, atm['radius'], atm['rstar'], ideep, 0)
+    np.testing.assert_allclose(got.cpu().numpy(), ref, rtol=RTOL)
+    assert list(lean.timestamps) == ['extinction', 'odepth', 'spectrum']
+    p1 = eng.SpectrumPipeline(case, depth=2, voigt=full.voigt, lines=full.lines)
+    p2 = eng.SpectrumPipeline(case, depth=2, voigt=full.voigt, lines=full.lines,
+                              materialize_depth=False)
+    assert all(a is b for a, b in zip(p1.streams, p2.streams))
+    out, ev = p2.submit()
+    ev.synchronize()
+    np.testing.assert_allclose(out.cpu().numpy(), want.cpu().numpy(), rtol=1e-13)

@@ -20,7 +20,8 @@ steps = int(os.environ.get('PB_WSHARD_STEPS', '50'))
 case = bench.make_case(bench.WORKLOADS[name])
 b = shard_bounds(case['grid']['nwave'], world)
 r = world // 2
-kw = dict(rt_path='transit', wbegin=int(b[r]), wcount=int(b[r + 1] - b[r]))
+kw = dict(rt_path='transit', wbegin=int(b[r]), wcount=int(b[r + 1] - b[r]),
+          materialize_depth=os.environ.get('PB_NO_DEPTH') != '1')
 m = engine.LBLSpectrum(case, **kw)
 for label, exch in (('one call', None), ('two-phase', lambda t: None)):
     m.kmax_exchange = exch
