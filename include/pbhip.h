@@ -398,6 +398,21 @@ int pb_band_integrate(double *bandflux_d, const double *spectrum_d, const double
  * lower triangle pb_optical_depth_transit takes. */
 int pb_transit_path(double *raypath_d, const double *radius_d, int itop, int nlayers,
                     int nwalkers, void *stream);
+/* Loader of sampled cross sections: one species' table of one opacity file
+ * (in_d[ntemp_in, nlay_in, nwave_in], cm2 molecule-1) brought onto the run's grid
+ * (out_d[ntemp_out, nlay_out, nwave_out]) -- tools.interpolate_opacity
+ * (pyratbay/tools/tools.py:1026-1107) as Line_Sample.__init__ calls it
+ * (pyratbay/opacity/line_sampling.py:245-275).  wsel_d[nwave_out]: the kept wavenumber samples
+ * of the file (window + thinning).  Per output temperature / pressure the lower bracket node
+ * (tlo_d, plo_d) and the weight of the upper one (tweight_d, pweight_d; 0 = on or beyond a
+ * node: constant extrapolation), prepared on the host.  resample = 0: the file's own grid,
+ * values pass untouched (brackets = the nodes, weights ignored); else linear in log(cs), zeros
+ * entering as exp(-230).  accumulate != 0 adds to out_d (a species spread over several files). */
+int pb_resample_cross_section(double *out_d, const double *in_d, const int32_t *wsel_d,
+                              const int32_t *tlo_d, const double *tweight_d,
+                              const int32_t *plo_d, const double *pweight_d, int ntemp_in,
+                              int nlay_in, int nwave_in, int ntemp_out, int nlay_out,
+                              int nwave_out, int resample, int accumulate, void *stream);
 /* interp_ec (src_c/_extcoeff.c:367-418), assigning form, for a batch: temps_d[nwalkers,nlayers],
  * density_d[nwalkers,nlayers,nmol] -> ec_d[nwalkers,nlayers,nwave].  The table is read once per
  * chunk of walkers.  work_d: nwalkers*nlayers*136 bytes of device scratch.  nmol <= 8. */

@@ -432,3 +432,80 @@ def emission_deck(depth, ideep, wn, temp, mu, weights, rtop, cloud_tsurf=None, c
         ideep = np.clip(ideep, 0, cloud_itop)
     inten = intensity(depth, ideep.astype(np.int32), B, mu, rtop)
     return np.sum(inten * np.asarray(weights)[:, None], axis=0)
+
+
+# ---------------------------------------------------------------------------------------------
+# Loader of sampled cross sections (numpy restatement; test infrastructure)
+# ---------------------------------------------------------------------------------------------
+def wn_mask(wn, wn_min, wn_max, tol=1.0e-8):
+    """pyratbay/spectrum/spec_tools.py:778-814: samples within [wn_min, wn_max] with a tolerance
+    of tol x the sampling step at the edges."""
+    wn = np.asarray(wn, float)
+    mask = (wn >= wn_min) & (wn <= wn_max)
+    if np.sum(mask) < 2:
+        min_dwn = max_dwn = 0
+    else:
+        min_dwn = np.abs(np.ediff1d(wn[mask][0:2]))
+        max_dwn = np.abs(np.ediff1d(wn[mask][-2:]))
+    return (wn >= wn_min - min_dwn * tol) & (wn <= wn_max + max_dwn * tol)
+
+
+def interpolate_opacity(cs, temp, press, temperature=None, pressure=None):
+    """pyratbay/tools/tools.py:1026-1107 on arrays: cs[ntemp, nlayers, nwave] tabulated at
+    (temp, press) -> the same on (temperature, pressure): linear in log(cs) over log(p), then over
+    T, constant beyond the table; untouched when both grids agree with the table's to 1 %."""
+    cs = np.asarray(cs, float)
+    resample_p = pressure is not None and (
+        len(press) != len(pressure) or np.any(np.abs(1.0 - press / pressure) > 0.01))
+    resample_t = temperature is not None and (
+        len(temp) != len(temperature) or np.any(np.abs(1.0 - temp / temperature) > 0.01))
+    if not resample_p and not resample_t:
+        return cs
+    with np.errstate(divide='ignore'):
+        log_cs = np.log(cs)
+    log_cs[~np.isfinite(log_cs)] = -230.0
+    if resample_p:
+        x, xt = np.log(pressure), np.log(press)
+        out = np.empty((log_cs.shape[0], len(x), log_cs.shape[2]))
+        for t in range(log_cs.shape[0]):
+            for w in range(log_cs.shape[2]):
+                out[t, :, w] = np.interp(x, xt, log_cs[t, :, w])
+        log_cs = out
+    if resample_t:
+        out = np.empty((len(temperature), log_cs.shape[1], log_cs.shape[2]))
+        for p in range(log_cs.shape[1]):
+            for w in range(log_cs.shape[2]):
+                out[:, p, w] = np.interp(temperature, temp, log_cs[:, p, w])
+        log_cs = out
+    return np.exp(log_cs)
+
+
+def line_sample_table(tables, temperature=None, pressure=None, min_wn=0.0, max_wn=np.inf,
+                      wl_thinning=1):
+    """Line_Sample.__init__ (opacity/line_sampling.py:104-275) on in-memory tables: `tables` is
+    a list of (species, temp, press, wn, cs[ntemp, nlayers, nwave]) in file order.  Returns
+    (species[nspec], temp, press, wn, cs_table[nspec, ntemp, nlayers, nwave]); a species that
+    appears in several files is the SUM of its files."""
+    _, temp0, press0, wn0, _ = tables[0]
+    temp = np.asarray(temp0 if temperature is None else temperature, float)
+    press = np.asarray(press0 if pressure is None else pressure, float)
+    mask0 = wn_mask(wn0, min_wn, max_wn)
+    wn = np.asarray(wn0)[mask0][::wl_thinning]
+    species, index = [], []
+    for sp, _, ptab, wtab, _ in tables:
+        m = wn_mask(wtab, min_wn, max_wn)
+        w = np.asarray(wtab)[m][::wl_thinning]
+        if len(w) != len(wn) or np.any(np.abs(1.0 - w / wn) > 0.01):
+            raise ValueError('wavenumber arrays of the cross-section files do not match')
+        if np.amax(press) / np.amax(ptab) - 1 > 1e-3:
+            raise ValueError('Pressure profile extends beyond the maximum tabulated pressure')
+        if sp not in species:
+            species.append(sp)
+        index.append(species.index(sp))
+    table = np.zeros((len(species), len(temp), len(press), len(wn)))
+    for (sp, ttab, ptab, wtab, cs), idx in zip(tables, index):
+        m = wn_mask(wtab, min_wn, max_wn)
+        sub = np.asarray(cs)[:, :, m][:, :, ::wl_thinning]
+        table[idx] += interpolate_opacity(sub, np.asarray(ttab, float), np.asarray(ptab, float),
+                                          temp, press)
+    return np.array(species), temp, press, wn, table

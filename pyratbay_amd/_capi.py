@@ -71,6 +71,8 @@ _PROTOS = {
     'pb_interp_ec': [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp],
     'pb_interp_ec_set': [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp],
     'pb_transit_path': [vp, vp, i32, i32, i32, vp],
+    'pb_resample_cross_section': [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32,
+                                  i32, vp],
     'pb_interp_ec_batch': [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp],
     'pb_transit_work_doubles': [i32, i32, i32, i32, i32],
     'pb_transit_spectrum_batch': [vp, vp, vp, vp, vp, vp, f64, i32, i32, f64, i32, i32, i32, vp, vp],

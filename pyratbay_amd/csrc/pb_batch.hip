@@ -856,6 +856,58 @@ __global__ __launch_bounds__(kBlock) void k_reject_walkers(double *bandflux, con
             bandflux[(int64_t)w * nbands + b] = INFINITY;
 }
 
+// ---------------------------------------------------------------------------
+// Loader of sampled cross sections: one species' table of one opacity file brought onto the
+// run's (temperature, pressure, wavenumber) grid -- tools.interpolate_opacity
+// (pyratbay/tools/tools.py:1026-1107) as called by Line_Sample.__init__
+// (opacity/line_sampling.py:245-275): linear in log(cs) over log(p), then over T, constant
+// beyond the table; a zero cross section enters as exp(-230).  The brackets and weights of the
+// two axes are prepared on the host (a handful of values); `wsel` are the kept wavenumber
+// samples (window + thinning); `accumulate` adds to what the table holds (a species spread over
+// several files is the sum of its files).  kResample = false: the grids agree with the file's,
+// values are copied (or added) untouched, like the reference does.
+// ---------------------------------------------------------------------------
+template <bool kResample>
+__global__ __launch_bounds__(kBlock) void k_resample_cs(
+    double *out, const double *in, const int32_t *wsel, const int32_t *tlo, const double *ta,
+    const int32_t *plo, const double *pa, int nlay_in, int nwave_in, int ntemp_out, int nlay_out,
+    int nwave_out, int accumulate)
+{
+    const int w = blockIdx.x * kBlock + threadIdx.x;
+    const int p2 = blockIdx.y, t2 = blockIdx.z;
+    if (w >= nwave_out)
+        return;
+    const int64_t wi = wsel[w];
+    auto at = [&](int t, int p) { return in[((int64_t)t * nlay_in + p) * nwave_in + wi]; };
+    double v;
+    if (!kResample) {
+        v = at(tlo[t2], plo[p2]);
+    } else {
+        auto lg = [&](int t, int p) {
+            const double y = log(at(t, p));
+            return isfinite(y) ? y : -230.0;
+        };
+        auto over_p = [&](int t) {
+            const double a = pa[p2];
+            const int p = plo[p2];
+            if (a == 0.0)
+                return lg(t, p);
+            const double lo = lg(t, p), hi = lg(t, p + 1);
+            return lo + a * (hi - lo);                   // np.interp / slinear: lo + slope*(x - xlo)
+        };
+        const double b = ta[t2];
+        const int t = tlo[t2];
+        double y = over_p(t);
+        if (b != 0.0) {
+            const double hi = over_p(t + 1);
+            y = y + b * (hi - y);
+        }
+        v = exp(y);
+    }
+    const int64_t o = ((int64_t)t2 * nlay_out + p2) * nwave_out + w;
+    out[o] = accumulate ? out[o] + v : v;
+}
+
 }  // namespace
 
 // rows per block of the fused kernel for a launch of nwave x nwalkers columns
@@ -1105,6 +1157,33 @@ int pb_interp_ec_batch(double *ec_d, const double *etable_d, const double *ttabl
     else
         PB_INTERP(8, false);
 #undef PB_INTERP
+    PB_LAUNCH_CHECK();
+    return PB_OK;
+}
+
+int pb_resample_cross_section(double *out_d, const double *in_d, const int32_t *wsel_d,
+                              const int32_t *tlo_d, const double *tweight_d,
+                              const int32_t *plo_d, const double *pweight_d, int ntemp_in,
+                              int nlay_in, int nwave_in, int ntemp_out, int nlay_out,
+                              int nwave_out, int resample, int accumulate, void *stream)
+{
+    PB_REQUIRE(ntemp_in >= 1 && nlay_in >= 1 && nwave_in >= 1 && ntemp_out >= 1 && nlay_out >= 1 &&
+                   nwave_out >= 0,
+               "pb_resample_cross_section: bad shape");
+    if (nwave_out == 0)
+        return PB_OK;
+    PB_REQUIRE(out_d && in_d && wsel_d && tlo_d && tweight_d && plo_d && pweight_d,
+               "pb_resample_cross_section: null pointer");
+    PB_REQUIRE(nlay_out <= 65535 && ntemp_out <= 65535, "pb_resample_cross_section: grid too large");
+    dim3 grid(pb::div_up(nwave_out, kBlock), nlay_out, ntemp_out);
+    if (resample)
+        k_resample_cs<true><<<grid, kBlock, 0, pb::as_stream(stream)>>>(
+            out_d, in_d, wsel_d, tlo_d, tweight_d, plo_d, pweight_d, nlay_in, nwave_in, ntemp_out,
+            nlay_out, nwave_out, accumulate);
+    else
+        k_resample_cs<false><<<grid, kBlock, 0, pb::as_stream(stream)>>>(
+            out_d, in_d, wsel_d, tlo_d, tweight_d, plo_d, pweight_d, nlay_in, nwave_in, ntemp_out,
+            nlay_out, nwave_out, accumulate);
     PB_LAUNCH_CHECK();
     return PB_OK;
 }

@@ -86,3 +86,120 @@ def read_opacity(ofile, extract='all'):
     if extract == 'arrays':
         return species, temp, press, wn
     return units, species, temp, press, wn, opacity
+
+
+# ---------------------------------------------------------------------------------------------
+# Loader of sampled cross sections: what Line_Sample.__init__ builds from a list of opacity files
+# (pyratbay/opacity/line_sampling.py:60-275), with the table assembled on the device
+# ---------------------------------------------------------------------------------------------
+def _wn_mask(wn, wn_min, wn_max, tol=1.0e-8):
+    """pyratbay/spectrum/spec_tools.py:778-814."""
+    wn = np.asarray(wn, float)
+    mask = (wn >= wn_min) & (wn <= wn_max)
+    if np.sum(mask) < 2:
+        min_dwn = max_dwn = 0
+    else:
+        min_dwn = np.abs(np.ediff1d(wn[mask][0:2]))
+        max_dwn = np.abs(np.ediff1d(wn[mask][-2:]))
+    return (wn >= wn_min - min_dwn * tol) & (wn <= wn_max + max_dwn * tol)
+
+
+def _brackets(x_table, x_new):
+    """Lower node and weight of the upper node of every x_new in the ascending x_table; values
+    beyond the table take its end node with weight 0 (constant extrapolation, the reference's
+    fill_value)."""
+    x_table, x_new = np.asarray(x_table, float), np.asarray(x_new, float)
+    if np.any(np.diff(x_table) <= 0):
+        raise ValueError('tabulated grid must be strictly ascending')
+    lo = np.clip(np.searchsorted(x_table, x_new, side='right') - 1, 0, len(x_table) - 1)
+    lo = np.where(x_new >= x_table[-1], len(x_table) - 1, lo)
+    hi = np.minimum(lo + 1, len(x_table) - 1)
+    span = x_table[hi] - x_table[lo]
+    with np.errstate(divide='ignore', invalid='ignore'):
+        a = np.where(span > 0, (x_new - x_table[lo]) / span, 0.0)
+    a = np.where((x_new <= x_table[0]) | (x_new >= x_table[-1]), 0.0, a)
+    return lo.astype(np.int32), a
+
+
+class CrossSections:
+    """species[nspec], temp[ntemp] (K), press[nlayers] (bar), wn[nwave] (cm-1) and
+    cs_table[nspec, ntemp, nlayers, nwave] (cm2 molecule-1, device tensor): the attributes of
+    the reference's Line_Sample that the retrieval path reads."""
+
+    def __init__(self, species, temp, press, wn, cs_table):
+        self.species, self.temp, self.press, self.wn = species, temp, press, wn
+        self.cs_table = cs_table
+        self.nspec, self.ntemp, self.nlayers, self.nwave = cs_table.shape
+        self.tmin, self.tmax = float(np.amin(temp)), float(np.amax(temp))
+
+    def table_spectrum(self, radius, rstar, **kw):
+        """An engine.TableSpectrum on this table (the path of Pyrat.eval())."""
+        return engine.TableSpectrum(self.cs_table, self.temp, self.wn, radius, rstar, **kw)
+
+
+def load_cross_sections(cs_files, temperature=None, pressure=None, min_wn=None, max_wn=None,
+                        min_wl=None, max_wl=None, wl_thinning=1):
+    """Line_Sample.__init__ without its isotope-ratio parameters: read the opacity files, keep
+    the wavenumber window [min_wn, max_wn] (or wavelengths in microns) thinned by wl_thinning,
+    bring every file onto (temperature, pressure) -- default: the first file's -- with
+    tools.interpolate_opacity's rule, ADD the files of a species.  Same errors as the reference
+    for mismatching wavenumber grids and for a pressure profile beyond a table.  The table is
+    assembled on the device (pb_resample_cross_section): files are uploaded one at a time."""
+    if isinstance(cs_files, str):
+        cs_files = [cs_files]
+    if min_wn is not None and max_wl is not None:
+        raise ValueError('Either define min_wn or max_wl, not both')
+    if max_wn is not None and min_wl is not None:
+        raise ValueError('Either define min_wl or max_wn, not both')
+    um = 1e-4
+    if min_wn is None:
+        min_wn = 0.0 if max_wl is None else 1.0 / (max_wl * um)
+    if max_wn is None:
+        max_wn = np.inf if min_wl is None else 1.0 / (min_wl * um)
+    _, temp0, press0, wn0 = read_opacity(cs_files[0], extract='arrays')
+    temp = np.asarray(temp0 if temperature is None else temperature, float)
+    press = np.asarray(press0 if pressure is None else pressure, float)
+    wn = np.asarray(wn0)[_wn_mask(wn0, min_wn, max_wn)][::wl_thinning]
+    species, index, masks, grids = [], [], [], []
+    for f in cs_files:
+        sp, ttab, ptab, wtab = read_opacity(f, extract='arrays')
+        mask = _wn_mask(wtab, min_wn, max_wn)
+        w = np.asarray(wtab)[mask][::wl_thinning]
+        if len(w) != len(wn) or np.any(np.abs(1.0 - w / wn) > 0.01):
+            raise ValueError(f"Wavenumber array of cross-section file '{f}' does not match "
+                             'with previous arrays')
+        if np.amax(press) / np.amax(ptab) - 1 > 1e-3:
+            raise ValueError('Pressure profile extends beyond the maximum tabulated pressure')
+        if sp not in species:
+            species.append(sp)
+        index.append(species.index(sp))
+        masks.append(mask)
+        grids.append((np.asarray(ttab, float), np.asarray(ptab, float)))
+    engine.require_gpu()
+    table = torch.zeros((len(species), len(temp), len(press), len(wn)), dtype=torch.float64,
+                        device='cuda')
+    for f, idx, mask, (ttab, ptab) in zip(cs_files, index, masks, grids):
+        cs = read_opacity(f, extract='opacity')
+        resample_p = len(ptab) != len(press) or np.any(np.abs(1.0 - ptab / press) > 0.01)
+        resample_t = len(ttab) != len(temp) or np.any(np.abs(1.0 - ttab / temp) > 0.01)
+        resample = bool(resample_p or resample_t)
+        if resample:
+            plo, pa = _brackets(np.log(ptab), np.log(press)) if resample_p else (
+                np.arange(len(press), dtype=np.int32), np.zeros(len(press)))
+            tlo, ta = _brackets(ttab, temp) if resample_t else (
+                np.arange(len(temp), dtype=np.int32), np.zeros(len(temp)))
+        else:
+            plo, pa = np.arange(len(press), dtype=np.int32), np.zeros(len(press))
+            tlo, ta = np.arange(len(temp), dtype=np.int32), np.zeros(len(temp))
+        wsel = np.flatnonzero(mask)[::wl_thinning].astype(np.int32)
+        # (named, so that every upload outlives the call: a c_void_p does not keep its tensor)
+        cs_d, dst = engine.dev(cs), table[idx]
+        wsel_d, tlo_d, plo_d = (engine.dev(x, torch.int32) for x in (wsel, tlo, plo))
+        ta_d, pa_d = engine.dev(ta), engine.dev(pa)
+        engine.call('pb_resample_cross_section', engine._ptr(dst), engine._ptr(cs_d),
+                    engine._ptr(wsel_d), engine._ptr(tlo_d), engine._ptr(ta_d),
+                    engine._ptr(plo_d), engine._ptr(pa_d), cs.shape[0], cs.shape[1],
+                    cs.shape[2], len(temp), len(press), len(wn), int(resample), 1,
+                    engine._stream())
+        torch.cuda.synchronize()
+    return CrossSections(np.array(species), temp, press, wn, table)
