@@ -147,8 +147,19 @@ int pb_lbl_set_ethresh(pb_lbl *p, double ethresh);
  * staged: isotope, phase, position).  In mode 0 the choice depends on the size of the launch
  * (layers x samples); with a fixed mode every tiling and sharding adds the same terms in the
  * same order, so shards concatenate bit-exactly.
- * last_gather_mode reports what the last call ran: 1 global, 2 staged, 3 resolution mode,
- * plus 8 when the resident-profile kernel ran as well. */
+ * Plans of the `resolution` mode (pb_lbl_create(resolution = 1)): any mode but 6 = the direct
+ * gather (two reference-layout table reads per (line, output): no set-up, what a one-off call
+ * wants); 6 = per-layer dynamic grids: the grid a layer's lines are summed on in the reference
+ * (step = ofactor fine samples, _extcoeff.c:185-195, 281-307) is a constant-step grid, so one
+ * constant-step sub-plan per factor in use (created on first use, kept: a copy of the Voigt table
+ * cut into phase rows modulo the factor, ~the size of the table each, at most PB_RES_DYN_MAX = 24
+ * of them, least recently used dropped) computes it with the staged kernels and the outputs are
+ * interpolated from it as utils.h:139-163 does.  Same terms, summed in the staged order (~1e-16
+ * of the direct gather).  Reads the layers' factors back: one stream synchronisation per call.
+ * Two-phase shard calls of such a plan use the direct gather.
+ * last_gather_mode reports what the last call ran: 1 global, 2 staged, 3 resolution mode (direct
+ * gather), 6 resolution mode through dynamic grids, plus 8 when the resident-profile kernel ran
+ * as well. */
 int pb_lbl_set_gather_mode(pb_lbl *p, int mode);
 int pb_lbl_last_gather_mode(const pb_lbl *p, int *mode);
 /* Hint: the caller keeps n independent calls in flight on n streams (the reference's callers

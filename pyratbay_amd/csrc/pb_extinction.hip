@@ -1982,6 +1982,30 @@ __global__ __launch_bounds__(kBlock) void k_ext_linterp(LblArgs a)
     }
 }
 
+// 3b'. `resolution` mode through the dynamic grids: the sums of a run of layers on their
+// dynamic grid (ktmp[layer][row][d0 .. d0+dcount), computed by a constant-step plan of step
+// ofactor) interpolated onto the output grid exactly as utils.h:139-163 does, accumulated into ext.
+// grid (output blocks, layers of the run x rows)
+__global__ __launch_bounds__(kBlock) void k_dyn_interp(double *ext, const double *ktmp,
+                                                      const double *wn, double wn0,
+                                                      const double *dwnstep, int64_t d0,
+                                                      int64_t dcount, int64_t wbegin,
+                                                      int64_t wcount, int nrows)
+{
+    const int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (j >= wcount)
+        return;
+    const int lr = blockIdx.y;
+    const double step = dwnstep[lr / nrows];
+    const double wn_i = wn[wbegin + j];
+    const int64_t ilo = (int)((wn_i - wn0) / step);
+    const double *src = ktmp + (int64_t)lr * dcount - d0;
+    const double v0 = ilo >= d0 && ilo < d0 + dcount ? src[ilo] : 0.0;
+    const double v1 = ilo + 1 >= d0 && ilo + 1 < d0 + dcount ? src[ilo + 1] : 0.0;
+    const double wnlo = wn0 + step * ilo;
+    ext[(int64_t)lr * wcount + j] += (v0 * (wnlo + step - wn_i) + v1 * (wn_i - wnlo)) / step;
+}
+
 // ---------------------------------------------------------------------------
 // _extcoeff.interp_ec / interp_ec_per_mol (src_c/_extcoeff.c:367-472)
 // grid (wavenumber blocks, layers, per_mol ? nmol : 1)
@@ -2128,6 +2152,28 @@ struct pb_lbl {
     } pending = {nullptr, 0, 0, nullptr, nullptr, nullptr, 0, 0, 0, 0, false};
     LblArgs last_args;               // arguments of the last launch (pb_lbl_last_work)
     bool last_packed = false;        // ... whose records are packed, one per (layer, group)
+    // `resolution` plans, gather mode 6: one constant-step plan per oversampling factor in use
+    // (the layer's dynamic grid IS a constant-step grid of step ofactor fine samples), with the
+    // Voigt table cut into phase rows modulo that factor (pb_voigt_rephase: kept by the table)
+    struct DynSub {
+        int f;
+        pb_voigt *voigt;
+        pb_lbl *plan;
+        double *ktmp;                // dynamic-grid sums of one run of layers
+        size_t ktmp_bytes;
+        uint64_t call;               // last call that used it, and on which side stream
+        int lane;
+    };
+    std::vector<DynSub> dyn;
+    uint64_t dyn_call = 0;
+    int dyn_runs = 0;                // runs of equal-factor layers of the last call
+    // the runs of a call are independent until ext: dealt to side streams (deep layers have
+    // short dynamic grids and factors of their own: launches of one layer that leave the chip idle)
+    std::vector<hipStream_t> dyn_streams;
+    std::vector<hipEvent_t> dyn_join;
+    hipEvent_t dyn_fork = nullptr;
+    std::vector<int32_t> h_ofactor, h_divisors, h_isoimol, h_isoiext0;   // (isoiext at creation)
+    std::vector<double> h_wn, h_molrad, h_molmass, h_isomass, h_isoratio;
 };
 
 extern "C" {
@@ -2378,6 +2424,16 @@ int pb_lbl_create(pb_lbl **out, pb_voigt *voigt, pb_lines *lines, const double *
     p->wnstep = wnstep;
     p->wn0 = wn_h[0];
     p->isoiext.assign(isoiext_h, isoiext_h + niso);
+    if (resolution) {
+        p->h_wn.assign(wn_h, wn_h + nwave);
+        p->h_divisors.assign(divisors_h, divisors_h + ndivs);
+        p->h_molrad.assign(molrad_h, molrad_h + nmol);
+        p->h_molmass.assign(molmass_h, molmass_h + nmol);
+        p->h_isoimol.assign(isoimol_h, isoimol_h + niso);
+        p->h_isoiext0.assign(isoiext_h, isoiext_h + niso);
+        p->h_isomass.assign(isomass_h, isomass_h + niso);
+        p->h_isoratio.assign(isoratio_h, isoratio_h + niso);
+    }
     int rows = 1;
     for (int i = 0; i < niso; i++)
         rows = std::max(rows, isoiext_h[i] + 1);
@@ -2570,7 +2626,9 @@ int pb_lbl_set_isoiext(pb_lbl *p, const int32_t *isoiext_h)
 
 int pb_lbl_set_gather_mode(pb_lbl *p, int mode)
 {
-    PB_REQUIRE(p && mode >= 0 && mode <= 5, "pb_lbl_set_gather_mode: mode must be 0..5");
+    PB_REQUIRE(p && mode >= 0 && mode <= 6, "pb_lbl_set_gather_mode: mode must be 0..6");
+    PB_REQUIRE(mode != 6 || p->resolution,
+               "pb_lbl_set_gather_mode: mode 6 (per-layer dynamic grids) is for `resolution` plans");
     p->gather_mode = mode;
     return PB_OK;
 }
@@ -2609,6 +2667,11 @@ int pb_lbl_set_ethresh(pb_lbl *p, double ethresh)
     p->ethresh = ethresh;
     return PB_OK;
 }
+
+static int lbl_resolution_dyn(pb_lbl *p, LblArgs &a, double *ext_d, int64_t wbegin, int64_t wcount,
+                              const double *temp_d, const double *dens_d, const double *isoz_d,
+                              int64_t z_iso_stride, int64_t z_layer_stride, int nlayers, int add,
+                              hipStream_t s);
 
 // phase 0: the whole call; 1: up to and including the records, per-row maxima over the shard's
 // own groups only (the caller all-reduces them); 2: the gather of the call begun with phase 1
@@ -2986,6 +3049,10 @@ static int lbl_extinction(pb_lbl *p, double *ext_d, int64_t wbegin, int64_t wcou
     }
     a.use_records = use_records ? 1 : 0;
 
+    if (p->resolution && p->gather_mode == 6 && phase == 0 && l->ngroups > 0 &&
+        !(getenv("PB_RES_DYN") && atoi(getenv("PB_RES_DYN")) == 0))
+        return lbl_resolution_dyn(p, a, ext_d, wbegin, wcount, temp_d, dens_d, isoz_d,
+                                  z_iso_stride, z_layer_stride, nlayers, add, s);
     if (phase != 2) {
     k_layer_state<<<nlayers, 64, ((size_t)a.nlor + a.ndop) * 8 + (size_t)a.ndivs * 4, s>>>(a);
     PB_LAUNCH_CHECK();
@@ -3448,6 +3515,165 @@ static int lbl_extinction(pb_lbl *p, double *ext_d, int64_t wbegin, int64_t wcou
     return PB_OK;
 }
 
+// `resolution` plans, gather mode 6.  The reference accumulates every line of a layer on the
+// layer's dynamic grid -- constant step, ofactor fine samples (_extcoeff.c:185-195, 281-307) -- and
+// interpolates the outputs from it (:320-326).  That grid is a constant-step output grid with
+// oversampling factor ofactor and nothing to resample, so a constant-step plan per factor computes
+// it with the staged kernels (phase rows modulo the factor, shared in LDS by every line of a
+// phase), and k_dyn_interp finishes.  Layers are walked in runs of equal factor.  The factors are
+// read back from the device (one stream synchronisation per call).
+static int dyn_subplan(pb_lbl *p, int f, hipStream_t s, pb_lbl::DynSub **out)
+{
+    for (pb_lbl::DynSub &d : p->dyn)
+        if (d.f == f) {
+            *out = &d;
+            return PB_OK;
+        }
+    const pb_lines *l = p->lines;
+    pb_lbl::DynSub d{f, nullptr, nullptr, nullptr, 0, 0, 0};
+    int rc = pb_voigt_rephase(&d.voigt, p->voigt, f, s);
+    if (rc)
+        return rc;
+    std::vector<int32_t> divs;
+    for (int32_t x : p->h_divisors)
+        if (x <= f && f % x == 0)
+            divs.push_back(x);
+    const int64_t dn = 1 + (l->onwn - 1) / f;
+    std::vector<double> wn((size_t)dn);
+    for (int64_t i = 0; i < dn; i++)
+        wn[(size_t)i] = l->own0 + (double)(i * f) * l->ownstep;
+    rc = pb_lbl_create(&d.plan, d.voigt, p->lines, wn.data(), (int)dn, divs.data(),
+                       (int)divs.size(), p->h_molrad.data(), p->h_molmass.data(), p->nmol,
+                       p->h_isoimol.data(), p->h_isomass.data(), p->h_isoratio.data(),
+                       p->h_isoiext0.data(), p->niso, p->cutoff, p->ethresh, 0, p->max_layers);
+    if (rc)
+        return rc;                                     // (the table stays with p->voigt)
+    // runs of one or two deep layers are small launches: the automatic choice would send them
+    // to the global gather (c2-res: 180-580 us per layer against 55-200 staged)
+    if (!getenv("PB_GATHER"))
+        d.plan->gather_mode = 2;
+    p->dyn.push_back(d);
+    *out = &p->dyn.back();
+    return PB_OK;
+}
+
+static int lbl_resolution_dyn(pb_lbl *p, LblArgs &a, double *ext_d, int64_t wbegin, int64_t wcount,
+                              const double *temp_d, const double *dens_d, const double *isoz_d,
+                              int64_t z_iso_stride, int64_t z_layer_stride, int nlayers, int add,
+                              hipStream_t s)
+{
+    const pb_lines *l = p->lines;
+    PB_REQUIRE(l->onwn < (1LL << 30), "pb_lbl_extinction: fine grid of %lld samples exceeds 2^30",
+               (long long)l->onwn);
+    k_layer_state<<<nlayers, 64, ((size_t)a.nlor + a.ndop) * 8 + (size_t)a.ndivs * 4, s>>>(a);
+    PB_LAUNCH_CHECK();
+    p->h_ofactor.resize((size_t)nlayers);
+    PB_HIP(hipMemcpyAsync(p->h_ofactor.data(), p->ls_ofactor, (size_t)nlayers * 4,
+                          hipMemcpyDeviceToHost, s));
+    PB_HIP(hipStreamSynchronize(s));      // (also: every run of the previous call has ended)
+    int lanes = 4;
+    if (const char *e = getenv("PB_RES_DYN_STREAMS"))
+        lanes = std::max(1, std::min(8, atoi(e)));
+    if (lanes > 1 && p->dyn_streams.empty()) {
+        PB_HIP(hipEventCreateWithFlags(&p->dyn_fork, hipEventDisableTiming));
+        for (int k = 0; k < 8; k++) {
+            hipStream_t t;
+            hipEvent_t e;
+            PB_HIP(hipStreamCreateWithFlags(&t, hipStreamNonBlocking));
+            p->dyn_streams.push_back(t);
+            PB_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            p->dyn_join.push_back(e);
+        }
+    }
+    const bool timed = p->ev_used + 2 <= (int)p->ev.size();
+    if (timed)
+        PB_HIP(hipEventRecord(p->ev[p->ev_used], s));
+    if (lanes > 1) {
+        PB_HIP(hipEventRecord(p->dyn_fork, s));        // ext as the caller left it (zeroed, or sums so far)
+        for (int k = 0; k < lanes; k++)
+            PB_HIP(hipStreamWaitEvent(p->dyn_streams[(size_t)k], p->dyn_fork, 0));
+    }
+    p->last_gather = 6;
+    p->dyn_runs = 0;
+    p->dyn_call++;
+    const double w_lo = p->h_wn[(size_t)wbegin], w_hi = p->h_wn[(size_t)(wbegin + wcount - 1)];
+    int rc = PB_OK;
+    for (int l0 = 0; l0 < nlayers && rc == PB_OK;) {
+        const int f = p->h_ofactor[(size_t)l0];
+        int l1 = l0 + 1;
+        while (l1 < nlayers && p->h_ofactor[(size_t)l1] == f)
+            l1++;
+        pb_lbl::DynSub *sub = nullptr;
+        rc = dyn_subplan(p, f, s, &sub);
+        if (rc)
+            break;
+        // a factor that comes back later in the same call (a temperature inversion) shares the
+        // sub-plan's workspaces with its first run: same side stream, hence in order
+        const int lane = sub->call == p->dyn_call ? sub->lane : p->dyn_runs % lanes;
+        sub->call = p->dyn_call;
+        sub->lane = lane;
+        hipStream_t t = lanes > 1 ? p->dyn_streams[(size_t)lane] : s;
+        pb_lbl *q = sub->plan;
+        q->ethresh = p->ethresh;
+        q->concurrency = std::max(p->concurrency, 1);
+        if (q->isoiext != p->isoiext) {
+            rc = pb_lbl_set_isoiext(q, p->isoiext.data());
+            if (rc)
+                break;
+        }
+        // the dynamic samples the outputs of this call read (one of margin on either side)
+        const double step = l->ownstep * f;
+        const int64_t dn = q->nwave;
+        int64_t d0 = (int64_t)((w_lo - p->wn0) / step) - 1;
+        int64_t d1 = (int64_t)((w_hi - p->wn0) / step) + 3;
+        d0 = std::max<int64_t>(0, std::min(d0, dn - 1));
+        d1 = std::max(d0 + 1, std::min(d1, dn));
+        const int nl = l1 - l0;
+        const size_t need = (size_t)nl * a.nrows * (size_t)(d1 - d0) * 8;
+        if (need > sub->ktmp_bytes) {
+            PB_HIP(hipStreamSynchronize(t));
+            (void)hipFree(sub->ktmp);
+            sub->ktmp = nullptr;
+            sub->ktmp_bytes = 0;
+            if (hipMalloc(&sub->ktmp, need) != hipSuccess) {
+                pb::set_error("pb_lbl_extinction: cannot allocate %zu B of dynamic-grid sums", need);
+                rc = PB_ERR_NOMEM;
+                break;
+            }
+            sub->ktmp_bytes = need;
+        }
+        rc = lbl_extinction(q, sub->ktmp, d0, d1 - d0, temp_d + l0, dens_d + (int64_t)l0 * p->nmol,
+                            isoz_d + (int64_t)l0 * z_layer_stride, z_iso_stride, z_layer_stride,
+                            nl, add, t, 0);
+        if (rc)
+            break;
+        dim3 grid((unsigned)pb::div_up(wcount, (int64_t)kBlock), (unsigned)(nl * a.nrows));
+        k_dyn_interp<<<grid, kBlock, 0, t>>>(ext_d + (int64_t)l0 * a.nrows * wcount, sub->ktmp,
+                                            p->d_wn, p->wn0, p->ls_dwnstep + l0, d0, d1 - d0,
+                                            wbegin, wcount, a.nrows);
+        if (hipGetLastError() != hipSuccess) {
+            pb::set_error("pb_lbl_extinction: k_dyn_interp launch failed");
+            rc = PB_ERR_HIP;
+            break;
+        }
+        p->dyn_runs++;
+        l0 = l1;
+    }
+    // (joined on every path: the caller's stream must not run ahead of a side stream)
+    if (lanes > 1)
+        for (int k = 0; k < lanes; k++) {
+            PB_HIP(hipEventRecord(p->dyn_join[(size_t)k], p->dyn_streams[(size_t)k]));
+            PB_HIP(hipStreamWaitEvent(s, p->dyn_join[(size_t)k], 0));
+        }
+    if (rc)
+        return rc;
+    if (timed) {
+        PB_HIP(hipEventRecord(p->ev[p->ev_used + 1], s));
+        p->ev_used += 2;
+    }
+    return PB_OK;
+}
+
 int pb_lbl_extinction(pb_lbl *p, double *ext_d, int64_t wbegin, int64_t wcount,
                       const double *temp_d, const double *dens_d, const double *isoz_d,
                       int64_t z_iso_stride, int64_t z_layer_stride, int nlayers, int add,
@@ -3661,6 +3887,16 @@ void pb_lbl_destroy(pb_lbl *p)
     (void)hipFree(p->rec_i32);
     for (hipEvent_t e : p->ev)
         (void)hipEventDestroy(e);
+    for (pb_lbl::DynSub &d : p->dyn) {
+        pb_lbl_destroy(d.plan);                        // (their tables belong to p->voigt)
+        (void)hipFree(d.ktmp);
+    }
+    for (hipStream_t t : p->dyn_streams)
+        (void)hipStreamDestroy(t);
+    for (hipEvent_t e : p->dyn_join)
+        (void)hipEventDestroy(e);
+    if (p->dyn_fork)
+        (void)hipEventDestroy(p->dyn_fork);
     delete p;
 }
 

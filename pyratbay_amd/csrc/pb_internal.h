@@ -30,9 +30,11 @@ struct pb_voigt {
     int32_t *d_psize = nullptr, *d_pindex = nullptr, *d_pm_stride = nullptr;  // [nlor*ndop]
     int64_t *d_pm_base = nullptr;
     double *d_lorentz = nullptr, *d_doppler = nullptr;
+    std::vector<pb_voigt *> rephased;   // this table cut for other factors (pb_voigt_rephase)
 };
 
 int pb_voigt_ensure_flat(pb_voigt *v, hipStream_t stream);
+int pb_voigt_rephase(pb_voigt **out, pb_voigt *src, int osamp, hipStream_t stream);
 
 struct pb_lines;
 int pb_lines_group_device(pb_lines *l, const double *lwn_h, const int32_t *lid_h,

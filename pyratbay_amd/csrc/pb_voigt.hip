@@ -380,6 +380,53 @@ static int release_phase_major(pb_voigt *v, hipStream_t s)
     return PB_OK;
 }
 
+// The same table with its phase-major layout cut for another oversampling factor (the per-layer
+// dynamic grids of the `resolution` mode: sample d of a grid of step f reads element
+// half + f*d - iown of a profile, i.e. phase rows modulo f).  Reads src's reference layout; the
+// new handle holds a phase-major table only and BELONGS to src (kept for every plan that asks
+// for the same factor, destroyed with src): at most one per divisor of the fine grid's factor.
+int pb_voigt_rephase(pb_voigt **out, pb_voigt *src, int osamp, hipStream_t s)
+{
+    PB_REQUIRE(out && src && osamp > 0, "pb_voigt_rephase: bad argument");
+    *out = nullptr;
+    for (pb_voigt *r : src->rephased)
+        if (r->osamp == osamp) {
+            *out = r;
+            return PB_OK;
+        }
+    int rc = pb_voigt_ensure_flat(src, s);
+    if (rc)
+        return rc;
+    pb_voigt *v = new (std::nothrow) pb_voigt();
+    if (!v)
+        return PB_ERR_NOMEM;
+    std::vector<Cell> cells;
+    rc = plan_table(v, src->lorentz.data(), src->nlor, src->doppler.data(), src->ndop,
+                    src->psize.data(), src->pindex.data(), src->dwn, osamp, cells);
+    if (rc == PB_OK)
+        rc = upload_meta(v, cells);
+    unsigned g = 0;
+    if (rc == PB_OK)
+        rc = grid_for(v->npm, &g);
+    if (rc == PB_OK)
+        rc = alloc_pm(v, s);
+    if (rc == PB_OK) {
+        k_flat_to_pm<<<g, kBlock, 0, s>>>(v->d_pm, src->d_flat, (const Cell *)v->d_cells,
+                                         v->d_pm_bases, v->ncell, v->npm, osamp);
+        if (hipGetLastError() != hipSuccess || hipStreamSynchronize(s) != hipSuccess) {
+            pb::set_error("pb_voigt_rephase: permutation kernel failed");
+            rc = PB_ERR_HIP;
+        }
+    }
+    if (rc != PB_OK) {
+        pb_voigt_destroy(v);
+        return rc;
+    }
+    src->rephased.push_back(v);
+    *out = v;
+    return PB_OK;
+}
+
 extern "C" {
 
 int pb_voigt_create(pb_voigt **out, const double *lorentz_h, int nlor,
@@ -524,13 +571,18 @@ int64_t pb_voigt_device_bytes(const pb_voigt *v)
 {
     if (!v)
         return 0;
-    return ((v->d_pm_alloc ? v->npm + 2 * kPmPad : 0) + (v->d_flat ? v->nflat : 0)) * 8;
+    int64_t n = ((v->d_pm_alloc ? v->npm + 2 * kPmPad : 0) + (v->d_flat ? v->nflat : 0)) * 8;
+    for (const pb_voigt *r : v->rephased)
+        n += pb_voigt_device_bytes(r);
+    return n;
 }
 
 void pb_voigt_destroy(pb_voigt *v)
 {
     if (!v)
         return;
+    for (pb_voigt *r : v->rephased)
+        pb_voigt_destroy(r);
     (void)hipFree(v->d_pm_alloc);
     (void)hipFree(v->d_flat);
     (void)hipFree(v->d_cells);

@@ -260,10 +260,12 @@ class LBL:
     def set_ethresh(self, ethresh):
         call('pb_lbl_set_ethresh', self._h, float(ethresh))
 
-    GATHER = {'auto': 0, 'global': 1, 'staged': 2, 'resident': 3, 'scatter': 4, 'rounds': 5}
+    GATHER = {'auto': 0, 'global': 1, 'staged': 2, 'resident': 3, 'scatter': 4, 'rounds': 5,
+              'dynamic': 6}
 
     def set_gather_mode(self, mode):
-        """'auto' | 'global' | 'staged' | 'resident' (see pbhip.h: pb_lbl_set_gather_mode)."""
+        """'auto' | 'global' | 'staged' | 'resident'; 'dynamic' (`resolution` plans: the layers'
+        dynamic grids through constant-step sub-plans).  See pbhip.h: pb_lbl_set_gather_mode."""
         call('pb_lbl_set_gather_mode', self._h, self.GATHER[mode])
 
     def set_record_budget(self, nbytes):
@@ -286,7 +288,7 @@ class LBL:
         m = C.c_int(0)
         call('pb_lbl_last_gather_mode', self._h, C.byref(m))
         base = {0: None, 1: 'k_ext_resample', 2: 'k_ext_staged', 3: 'k_ext_linterp',
-                4: 'k_ext_scatter', 5: 'k_ext_rounds'}[m.value & 7]
+                4: 'k_ext_scatter', 5: 'k_ext_rounds', 6: 'dynamic grids'}[m.value & 7]
         return 'k_ext_resident+' + base if m.value & 8 else base
 
     def extinction(self, temp, dens, isoz, add=True, out=None, wbegin=0, wcount=None):
@@ -736,6 +738,10 @@ class LBLSpectrum:
                        atm['mol_mass'], iso['isoimol'], iso['isomass'], iso['isoratio'],
                        iso['isoiext'], vg['cutoff'], case['ethresh'],
                        resolution=self.resolution, max_layers=self.nlayers)
+        if self.resolution:
+            # an object made for many spectra: the one-time constant-step sub-plans of the layers'
+            # dynamic grids pay off from the second spectrum on (a bare LBL plan keeps the direct gather)
+            self.lbl.set_gather_mode('dynamic')
         # atmosphere state, resident (+ the host copy of the temperatures that the continuum
         # terms take their per-layer factors from)
         self.temp_host = np.array(atm['temp'], float)
