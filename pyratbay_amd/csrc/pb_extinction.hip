@@ -3598,6 +3598,12 @@ static int lbl_resolution_dyn(pb_lbl *p, LblArgs &a, double *ext_d, int64_t wbeg
     p->dyn_call++;
     const double w_lo = p->h_wn[(size_t)wbegin], w_hi = p->h_wn[(size_t)(wbegin + wcount - 1)];
     int rc = PB_OK;
+    // Dynamic sampling keeps the samples per line and layer about constant, so a run costs about
+    // its layers (c2-res: 43 us per layer in runs of 14-18, 55-200 us for a run of one) plus its
+    // small launches.  Runs that fill the chip by themselves queue on side stream 0; the others
+    // (deep layers: one or two layers on a short grid) are dealt to the remaining side streams,
+    // least work first, and run in the shadow of the large ones.
+    double load[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     for (int l0 = 0; l0 < nlayers && rc == PB_OK;) {
         const int f = p->h_ofactor[(size_t)l0];
         int l1 = l0 + 1;
@@ -3609,7 +3615,17 @@ static int lbl_resolution_dyn(pb_lbl *p, LblArgs &a, double *ext_d, int64_t wbeg
             break;
         // a factor that comes back later in the same call (a temperature inversion) shares the
         // sub-plan's workspaces with its first run: same side stream, hence in order
-        const int lane = sub->call == p->dyn_call ? sub->lane : p->dyn_runs % lanes;
+        int lane = 0;
+        const int64_t groups = (int64_t)(l1 - l0) * pb::div_up((int64_t)sub->plan->nwave, (int64_t)4096);
+        if (groups < 512 && lanes > 1) {
+            lane = 1;
+            for (int k = 2; k < lanes; k++)
+                if (load[k] < load[lane])
+                    lane = k;
+        }
+        if (sub->call == p->dyn_call)
+            lane = sub->lane;
+        load[lane] += 60.0 + 45.0 * (l1 - l0);
         sub->call = p->dyn_call;
         sub->lane = lane;
         hipStream_t t = lanes > 1 ? p->dyn_streams[(size_t)lane] : s;
@@ -3647,6 +3663,13 @@ static int lbl_resolution_dyn(pb_lbl *p, LblArgs &a, double *ext_d, int64_t wbeg
                             nl, add, t, 0);
         if (rc)
             break;
+        // (pb_lbl_last_state / pb_lbl_kmax_buffer of this plan report the run's maxima)
+        if (hipMemcpyAsync(p->kmax_bits + (size_t)l0 * a.nrows, q->kmax_bits,
+                           (size_t)nl * a.nrows * 8, hipMemcpyDeviceToDevice, t) != hipSuccess) {
+            pb::set_error("pb_lbl_extinction: copy of the per-row maxima failed");
+            rc = PB_ERR_HIP;
+            break;
+        }
         dim3 grid((unsigned)pb::div_up(wcount, (int64_t)kBlock), (unsigned)(nl * a.nrows));
         k_dyn_interp<<<grid, kBlock, 0, t>>>(ext_d + (int64_t)l0 * a.nrows * wcount, sub->ktmp,
                                             p->d_wn, p->wn0, p->ls_dwnstep + l0, d0, d1 - d0,

@@ -47,7 +47,7 @@ def build(eng, c, resolution, table_from_oracle, orc, ethresh=1e-30, cutoff=None
 @pytest.mark.parametrize('mode,gather', [('step', 'global'), ('step', 'staged'),
                                          ('step', 'resident'), ('step', 'scatter'),
                                          ('step', 'rounds'), ('step', 'auto'),
-                                         ('res', 'auto')])
+                                         ('res', 'auto'), ('res', 'dynamic')])
 @pytest.mark.parametrize('own_table', [False, True])
 def test_g2_extinction_golden(eng, golden, orc, mode, own_table, gather):
     g = golden('g2_extinction')
@@ -84,6 +84,7 @@ def test_g2_extinction_golden(eng, golden, orc, mode, own_table, gather):
     want_kernel = {'global': ('k_ext_resample',), 'staged': ('k_ext_staged',),
                    'resident': ('k_ext_resident+k_ext_resample',),
                    'scatter': ('k_ext_scatter',), 'rounds': ('k_ext_rounds',),
+                   'dynamic': ('dynamic grids',),
                    'auto': ('k_ext_linterp',) if mode == 'res' else
                            ('k_ext_resident+k_ext_resample', 'k_ext_resident+k_ext_staged')}[gather]
     assert lbl.last_gather_kernel in want_kernel
@@ -883,3 +884,94 @@ def test_per_layer_phase_split(eng, orc, monkeypatch, deep):
                        iso['isoz'][:, layer].copy(), iso['isoiext'], ln['lwn'], ln['elow'],
                        ln['gf'], ln['lid'], vg['cutoff'], 1e-30, atm['temp'][layer], 0, 1, 0)
         np.testing.assert_allclose(host(got)[layer], want, rtol=RTOL)
+
+
+def _resolution_case(seed=23, nlayers=8, nlines=6000):
+    from pyratbay_amd import synth
+    return synth.lbl_case(3001, nlayers, nlines, wnosamp=24, nlor=16, ndop=8, extent=60.0,
+                          cutoff=3.0, niso=2, seed=seed, resolution=50000.0)
+
+
+def _resolution_plan(eng, case, **kw):
+    g, atm, ln, iso, vg = (case[k] for k in ('grid', 'atm', 'lines', 'iso', 'voigt'))
+    vt = eng.VoigtTable.build(vg['lorentz'], vg['doppler'], vg['size'], g['ownstep'],
+                              g['wnosamp'], 2)
+    ll = eng.LineList(ln['lwn'], ln['elow'], ln['gf'], ln['lid'], len(iso['isomass']), g['own'])
+    lbl = eng.LBL(vt, ll, g['wn'], g['divisors'], atm['mol_radius'], atm['mol_mass'],
+                  iso['isoimol'], iso['isomass'], iso['isoratio'], iso['isoiext'], vg['cutoff'],
+                  case['ethresh'], resolution=True, max_layers=atm['nlayers'], **kw)
+    return vt, ll, lbl
+
+
+def test_resolution_dynamic_grids(eng, monkeypatch):
+    """`resolution` plans, gather mode 'dynamic' (one constant-step sub-plan per oversampling
+    factor, pbhip.h: pb_lbl_set_gather_mode) against the direct gather of the same plan: every
+    layer to 1e-12 with the same zero pattern, both add modes; the per-row maxima and factors
+    reported by the plan are the direct call's; a wavenumber shard equals the slice of the whole
+    call bit for bit; one side stream or four, the same bits; layers in an order that brings a
+    factor back after another one (a temperature inversion) give the permuted result; the
+    re-cut tables belong to the Voigt table and are shared by a second plan."""
+    import torch
+    case = _resolution_case()
+    atm, iso = case['atm'], case['iso']
+    nl = atm['nlayers']
+    vt, ll, lbl = _resolution_plan(eng, case)
+    bytes0 = vt.device_bytes
+    temp, dens, isoz = eng.dev(atm['temp']), eng.dev(atm['dens']), eng.dev(iso['isoz'])
+    for add in (True, False):
+        lbl.set_gather_mode('auto')
+        want = lbl.extinction(temp, dens, isoz, add=add)
+        assert lbl.last_gather_kernel == 'k_ext_linterp'
+        of0, kmax0 = lbl.last_state(nl, want.shape[1])
+        lbl.set_gather_mode('dynamic')
+        got = lbl.extinction(temp, dens, isoz, add=add)
+        assert lbl.last_gather_kernel == 'dynamic grids'
+        of1, kmax1 = lbl.last_state(nl, want.shape[1])
+        assert np.array_equal(of0, of1) and np.array_equal(kmax0, kmax1)
+        w, g_ = host(want), host(got)
+        assert np.array_equal(w == 0, g_ == 0)
+        np.testing.assert_allclose(g_, w, rtol=1e-12)
+        assert np.count_nonzero(w) > 0.3 * w.size
+    factors = len(set(of1.tolist()))
+    assert factors >= 3, of1                               # several sub-plans were exercised
+    assert vt.device_bytes > bytes0                        # the re-cut tables are accounted for
+    whole = lbl.extinction(temp, dens, isoz, add=True)
+    # a shard: the sub-plans compute the dynamic samples its outputs read, nothing else
+    w0, wc = 700, 1111
+    shard = lbl.extinction(temp, dens, isoz, add=True, wbegin=w0, wcount=wc)
+    assert torch.equal(shard, whole[:, :, w0:w0 + wc])
+    # accumulation: a second call into the same array doubles it
+    twice = lbl.extinction(temp, dens, isoz, add=True, out=whole.clone())
+    assert torch.equal(twice, whole + whole)
+    monkeypatch.setenv('PB_RES_DYN_STREAMS', '1')
+    assert torch.equal(lbl.extinction(temp, dens, isoz, add=True), whole)
+    monkeypatch.delenv('PB_RES_DYN_STREAMS')
+    # layers shuffled: equal factors are no longer neighbours
+    perm = torch.tensor([0, 4, 1, 5, 2, 6, 3, 7][:nl], device='cuda')
+    shuffled = lbl.extinction(temp[perm].contiguous(), dens[perm].contiguous(),
+                              isoz[:, perm].contiguous(), add=True)
+    assert torch.equal(shuffled, whole[perm])
+    # species flags and threshold reach the sub-plans
+    flags = iso['isoiext'].copy()
+    flags[1] = -1
+    for mode in ('auto', 'dynamic'):
+        lbl.set_gather_mode(mode)
+        lbl.set_isoiext(flags)
+        lbl.set_ethresh(1e-3)
+        out = host(lbl.extinction(temp, dens, isoz, add=True))
+        if mode == 'auto':
+            ref = out
+    assert np.array_equal(ref == 0, out == 0)
+    np.testing.assert_allclose(out, ref, rtol=1e-12)
+    assert not np.array_equal(ref, host(whole))
+    # a second plan on the same table re-uses the re-cut copies
+    before = vt.device_bytes
+    lbl2 = eng.LBL(vt, ll, case['grid']['wn'], case['grid']['divisors'], atm['mol_radius'],
+                   atm['mol_mass'], iso['isoimol'], iso['isomass'], iso['isoratio'],
+                   iso['isoiext'], case['voigt']['cutoff'], case['ethresh'], resolution=True,
+                   max_layers=nl)
+    lbl2.set_gather_mode('dynamic')
+    assert torch.equal(lbl2.extinction(temp, dens, isoz, add=True), whole)
+    assert vt.device_bytes == before
+    with pytest.raises(Exception, match='resolution'):
+        build(eng, cases.extinction_inputs(), False, False, None)[2].set_gather_mode('dynamic')

@@ -431,11 +431,18 @@ def test_resolution_mode_spectrum(eng, orc):
     g, atm, ln, iso, vg = (case[k] for k in ('grid', 'atm', 'lines', 'iso', 'voigt'))
     assert g['resolution'] == 60000.0 and abs(g['wn'][1] / g['wn'][0] - 1 - 1 / 60000.0) < 1e-9
     model = eng.LBLSpectrum(case, rt_path='transit')
-    first = model.run().clone()
-    assert model.lbl.last_gather_kernel == 'k_ext_linterp'
-    assert torch.equal(model.run(), first)                 # ec is zeroed per run, not summed up
     vt = model.voigt
     assert vt.device_bytes < 1.2 * 8 * vt.nprofile         # one layout on the device, not two
+    first = model.run().clone()
+    # (the model asks for the per-layer dynamic grids; a bare plan keeps the direct gather)
+    assert model.lbl.last_gather_kernel == 'dynamic grids'
+    assert torch.equal(model.run(), first)                 # ec is zeroed per run, not summed up
+    model.lbl.set_gather_mode('auto')
+    direct = model.run().clone()
+    assert model.lbl.last_gather_kernel == 'k_ext_linterp'
+    np.testing.assert_allclose(first.cpu().numpy(), direct.cpu().numpy(), rtol=1e-12)
+    model.lbl.set_gather_mode('dynamic')
+    model.run()
     profile = vt.flat()
     ec = model.ec.cpu().numpy()[:, 0]
     for layer in range(atm['nlayers']):
