@@ -151,10 +151,10 @@ int pb_lbl_set_ethresh(pb_lbl *p, double ethresh);
  * gather (two reference-layout table reads per (line, output): no set-up, what a one-off call
  * wants); 6 = per-layer dynamic grids: the grid a layer's lines are summed on in the reference
  * (step = ofactor fine samples, _extcoeff.c:185-195, 281-307) is a constant-step grid, so one
- * constant-step sub-plan per factor in use (created on first use, kept: a copy of the Voigt table
- * cut into phase rows modulo the factor, ~the size of the table each, at most PB_RES_DYN_MAX = 24
- * of them, least recently used dropped) computes it with the staged kernels and the outputs are
- * interpolated from it as utils.h:139-163 does.  Same terms, summed in the staged order (~1e-16
+ * constant-step sub-plan per factor in use (created on first use and kept, with the Lorentz rows
+ * of the Voigt table its layers read re-cut into phase rows modulo the factor -- all factors
+ * together about one more copy of the table) computes it with the staged kernels and the outputs
+ * are interpolated from it as utils.h:139-163 does.  Same terms, summed in the staged order (~1e-16
  * of the direct gather).  Reads the layers' factors back: one stream synchronisation per call.
  * Two-phase shard calls of such a plan use the direct gather.
  * last_gather_mode reports what the last call ran: 1 global, 2 staged, 3 resolution mode (direct

@@ -2172,7 +2172,7 @@ struct pb_lbl {
     std::vector<hipStream_t> dyn_streams;
     std::vector<hipEvent_t> dyn_join;
     hipEvent_t dyn_fork = nullptr;
-    std::vector<int32_t> h_ofactor, h_divisors, h_isoimol, h_isoiext0;   // (isoiext at creation)
+    std::vector<int32_t> h_ofactor, h_ilor, h_divisors, h_isoimol, h_isoiext0;   // (isoiext at creation)
     std::vector<double> h_wn, h_molrad, h_molmass, h_isomass, h_isoratio;
 };
 
@@ -2377,7 +2377,7 @@ int pb_lbl_create(pb_lbl **out, pb_voigt *voigt, pb_lines *lines, const double *
         PB_REQUIRE(isoimol_h[i] >= 0 && isoimol_h[i] < nmol,
                    "pb_lbl_create: isoimol[%d] out of range", i);
     PB_REQUIRE(divisors_h[0] >= 1, "pb_lbl_create: divisors must start at >= 1");
-    PB_REQUIRE(resolution || voigt->d_pm,
+    PB_REQUIRE(resolution || voigt->d_pm || voigt->lazy_parent,
                "pb_lbl_create: this Voigt table keeps the reference layout only (keep_flat = 2); "
                "constant-step plans need the phase-major layout");
     const double wnstep = wn_h[1] - wn_h[0];
@@ -3568,7 +3568,10 @@ static int lbl_resolution_dyn(pb_lbl *p, LblArgs &a, double *ext_d, int64_t wbeg
     k_layer_state<<<nlayers, 64, ((size_t)a.nlor + a.ndop) * 8 + (size_t)a.ndivs * 4, s>>>(a);
     PB_LAUNCH_CHECK();
     p->h_ofactor.resize((size_t)nlayers);
+    p->h_ilor.resize((size_t)nlayers * p->niso);
     PB_HIP(hipMemcpyAsync(p->h_ofactor.data(), p->ls_ofactor, (size_t)nlayers * 4,
+                          hipMemcpyDeviceToHost, s));
+    PB_HIP(hipMemcpyAsync(p->h_ilor.data(), p->li_ilor, (size_t)nlayers * p->niso * 4,
                           hipMemcpyDeviceToHost, s));
     PB_HIP(hipStreamSynchronize(s));      // (also: every run of the previous call has ended)
     int lanes = 4;
@@ -3630,6 +3633,16 @@ static int lbl_resolution_dyn(pb_lbl *p, LblArgs &a, double *ext_d, int64_t wbeg
         sub->lane = lane;
         hipStream_t t = lanes > 1 ? p->dyn_streams[(size_t)lane] : s;
         pb_lbl *q = sub->plan;
+        {
+            // the Lorentz rows of the re-cut table that the layers of this run read
+            std::vector<int> rows(p->h_ilor.begin() + (size_t)l0 * p->niso,
+                                  p->h_ilor.begin() + (size_t)l1 * p->niso);
+            std::sort(rows.begin(), rows.end());
+            rows.erase(std::unique(rows.begin(), rows.end()), rows.end());
+            rc = pb_voigt_ensure_rows(sub->voigt, rows.data(), (int)rows.size(), t);
+            if (rc)
+                break;
+        }
         q->ethresh = p->ethresh;
         q->concurrency = std::max(p->concurrency, 1);
         if (q->isoiext != p->isoiext) {

@@ -31,10 +31,17 @@ struct pb_voigt {
     int64_t *d_pm_base = nullptr;
     double *d_lorentz = nullptr, *d_doppler = nullptr;
     std::vector<pb_voigt *> rephased;   // this table cut for other factors (pb_voigt_rephase)
+    // a re-cut table is filled one Lorentz row at a time (pb_voigt_ensure_rows): the table it was
+    // cut from, the positions of the rows in the contiguous layout [nlor+1], the rows' allocations
+    pb_voigt *lazy_parent = nullptr;
+    std::vector<int64_t> row_pos;
+    std::vector<double *> row_data;
+    int64_t lazy_bytes = 0;
 };
 
 int pb_voigt_ensure_flat(pb_voigt *v, hipStream_t stream);
 int pb_voigt_rephase(pb_voigt **out, pb_voigt *src, int osamp, hipStream_t stream);
+int pb_voigt_ensure_rows(pb_voigt *v, const int *rows, int n, hipStream_t stream);
 
 struct pb_lines;
 int pb_lines_group_device(pb_lines *l, const double *lwn_h, const int32_t *lid_h,

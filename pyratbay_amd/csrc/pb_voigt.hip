@@ -164,10 +164,12 @@ __global__ __launch_bounds__(kBlock) void k_voigt_pm(double *pm, const Cell *cel
 }
 
 // Permutations between the two layouts.
+// (positions [pos0, npm) of the layout; pm points to position 0)
 __global__ void k_flat_to_pm(double *pm, const double *flat, const Cell *cells,
-                             const int64_t *pm_bases, int ncell, int64_t npm, int osamp)
+                             const int64_t *pm_bases, int ncell, int64_t npm, int osamp,
+                             int64_t pos0 = 0)
 {
-    int64_t pos = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    int64_t pos = pos0 + (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (pos >= npm)
         return;
     int ci = find_cell(pm_bases, ncell, pos);
@@ -382,9 +384,11 @@ static int release_phase_major(pb_voigt *v, hipStream_t s)
 
 // The same table with its phase-major layout cut for another oversampling factor (the per-layer
 // dynamic grids of the `resolution` mode: sample d of a grid of step f reads element
-// half + f*d - iown of a profile, i.e. phase rows modulo f).  Reads src's reference layout; the
-// new handle holds a phase-major table only and BELONGS to src (kept for every plan that asks
-// for the same factor, destroyed with src): at most one per divisor of the fine grid's factor.
+// half + f*d - iown of a profile, i.e. phase rows modulo f).  The new handle BELONGS to src (kept
+// for every plan that asks for the same factor, destroyed with src) and is filled LAZILY, one
+// Lorentz row of the table at a time (pb_voigt_ensure_rows): a layer reads the cells of its own
+// Lorentz row only, and the layers that meet a given factor share a few neighbouring rows, so all
+// the factors of a plan together hold about one copy of the table, not one each.
 int pb_voigt_rephase(pb_voigt **out, pb_voigt *src, int osamp, hipStream_t s)
 {
     PB_REQUIRE(out && src && osamp > 0, "pb_voigt_rephase: bad argument");
@@ -405,25 +409,94 @@ int pb_voigt_rephase(pb_voigt **out, pb_voigt *src, int osamp, hipStream_t s)
                     src->psize.data(), src->pindex.data(), src->dwn, osamp, cells);
     if (rc == PB_OK)
         rc = upload_meta(v, cells);
-    unsigned g = 0;
-    if (rc == PB_OK)
-        rc = grid_for(v->npm, &g);
-    if (rc == PB_OK)
-        rc = alloc_pm(v, s);
-    if (rc == PB_OK) {
-        k_flat_to_pm<<<g, kBlock, 0, s>>>(v->d_pm, src->d_flat, (const Cell *)v->d_cells,
-                                         v->d_pm_bases, v->ncell, v->npm, osamp);
-        if (hipGetLastError() != hipSuccess || hipStreamSynchronize(s) != hipSuccess) {
-            pb::set_error("pb_voigt_rephase: permutation kernel failed");
-            rc = PB_ERR_HIP;
-        }
-    }
     if (rc != PB_OK) {
         pb_voigt_destroy(v);
         return rc;
     }
+    // the positions of the contiguous layout that every Lorentz row would occupy; the rows
+    // themselves are allocated when a layer first needs them
+    v->lazy_parent = src;
+    v->row_pos.assign((size_t)v->nlor + 1, v->npm);
+    for (int m = 0; m < v->nlor; m++)
+        v->row_pos[(size_t)m] = v->pm_base[(size_t)m * v->ndop];
+    v->row_data.assign((size_t)v->nlor, nullptr);
     src->rephased.push_back(v);
     *out = v;
+    return PB_OK;
+}
+
+// Fill the Lorentz rows rows[0..n) of a lazily filled table (no-op for the rows already there and
+// for tables that are not lazy).  Each row gets its own allocation with kPmPad zero samples on
+// either side, and the offsets of its cells (host mirror and device copy) are re-based to it.
+// The kernels address a cell as d_pm + offset with offsets that the staged gather packs into 40
+// unsigned bits: d_pm of a lazy table is not an allocation but an ANCHOR 2^39 samples (4 TiB)
+// below the first row allocated, so every allocation within 4 TiB of that one has an offset in
+// range; one beyond (never seen: a process's device allocations lie within ~1 TiB) is refused.
+// Rows in use by kernels in flight are never touched: a row is filled before the first launch
+// that reads it.
+int pb_voigt_ensure_rows(pb_voigt *v, const int *rows, int n, hipStream_t s)
+{
+    PB_REQUIRE(v && (rows || n == 0), "pb_voigt_ensure_rows: null pointer");
+    if (!v->lazy_parent)
+        return PB_OK;
+    pb_voigt *src = v->lazy_parent;
+    for (int i = 0; i < n; i++) {
+        const int m = rows[i];
+        PB_REQUIRE(m >= 0 && m < v->nlor, "pb_voigt_ensure_rows: row %d outside [0,%d)", m, v->nlor);
+        if (v->row_data[(size_t)m])
+            continue;
+        const int64_t p0 = v->row_pos[(size_t)m], p1 = v->row_pos[(size_t)m + 1];
+        const size_t count = (size_t)(p1 - p0) + 2 * kPmPad;
+        double *block = nullptr;
+        if (hipMalloc(&block, count * sizeof(double)) != hipSuccess) {
+            pb::set_error("pb_voigt_ensure_rows: cannot allocate %zu B for Lorentz row %d",
+                          count * 8, m);
+            return PB_ERR_NOMEM;
+        }
+        double *data = block + kPmPad;               // position p0 of the layout
+        if (!v->d_pm)
+            v->d_pm = reinterpret_cast<double *>(reinterpret_cast<uintptr_t>(data) -
+                                                 ((uintptr_t)1 << 39) * sizeof(double));
+        // offset of layout position 0 of this row's frame from the anchor, in samples
+        const int64_t shift =
+            (int64_t)((reinterpret_cast<uintptr_t>(data) - reinterpret_cast<uintptr_t>(v->d_pm)) /
+                      sizeof(double)) - p0;
+        if (reinterpret_cast<uintptr_t>(data) < reinterpret_cast<uintptr_t>(v->d_pm) ||
+            shift + p0 - kPmPad < 0 || shift + p1 + kPmPad >= ((int64_t)1 << 40)) {
+            (void)hipFree(block);
+            pb::set_error("pb_voigt_ensure_rows: an allocation %lld samples from the table's "
+                          "anchor cannot be addressed with 40-bit offsets",
+                          (long long)(shift + p0));
+            return PB_ERR_UNSUPPORTED;
+        }
+        PB_HIP(hipMemsetAsync(block, 0, kPmPad * sizeof(double), s));
+        PB_HIP(hipMemsetAsync(data + (p1 - p0), 0, kPmPad * sizeof(double), s));
+        unsigned g = 0;
+        int rc = grid_for(p1 - p0, &g);
+        if (rc) {
+            (void)hipFree(block);
+            return rc;
+        }
+        // (the kernel works in layout positions: d_pm_bases / d_cells, not the re-based offsets)
+        k_flat_to_pm<<<g, kBlock, 0, s>>>(data - p0, src->d_flat, (const Cell *)v->d_cells,
+                                         v->d_pm_bases, v->ncell, p1, v->osamp, p0);
+        if (hipGetLastError() != hipSuccess) {
+            (void)hipFree(block);
+            pb::set_error("pb_voigt_ensure_rows: permutation kernel failed");
+            return PB_ERR_HIP;
+        }
+        const size_t k0 = (size_t)m * v->ndop;
+        std::vector<int64_t> based((size_t)v->ndop);
+        for (int d = 0; d < v->ndop; d++)           // (aliased cells repeat a base)
+            based[(size_t)d] = v->pm_base[k0 + d] + shift;
+        PB_HIP(hipMemcpyAsync(v->d_pm_base + k0, based.data(), (size_t)v->ndop * 8,
+                              hipMemcpyHostToDevice, s));
+        PB_HIP(hipStreamSynchronize(s));             // `based` is a local
+        for (int d = 0; d < v->ndop; d++)
+            v->pm_base[k0 + d] = based[(size_t)d];
+        v->row_data[(size_t)m] = block;
+        v->lazy_bytes += (int64_t)count * 8;
+    }
     return PB_OK;
 }
 
@@ -571,7 +644,9 @@ int64_t pb_voigt_device_bytes(const pb_voigt *v)
 {
     if (!v)
         return 0;
-    int64_t n = ((v->d_pm_alloc ? v->npm + 2 * kPmPad : 0) + (v->d_flat ? v->nflat : 0)) * 8;
+    int64_t n = v->lazy_parent
+                    ? v->lazy_bytes
+                    : ((v->d_pm_alloc ? v->npm + 2 * kPmPad : 0) + (v->d_flat ? v->nflat : 0)) * 8;
     for (const pb_voigt *r : v->rephased)
         n += pb_voigt_device_bytes(r);
     return n;
@@ -583,6 +658,8 @@ void pb_voigt_destroy(pb_voigt *v)
         return;
     for (pb_voigt *r : v->rephased)
         pb_voigt_destroy(r);
+    for (double *block : v->row_data)
+        (void)hipFree(block);
     (void)hipFree(v->d_pm_alloc);
     (void)hipFree(v->d_flat);
     (void)hipFree(v->d_cells);
