@@ -155,7 +155,9 @@ int pb_lbl_set_ethresh(pb_lbl *p, double ethresh);
  * of the Voigt table its layers read re-cut into phase rows modulo the factor -- all factors
  * together about one more copy of the table) computes it with the staged kernels and the outputs
  * are interpolated from it as utils.h:139-163 does.  Same terms, summed in the staged order (~1e-16
- * of the direct gather).  Reads the layers' factors back: one stream synchronisation per call.
+ * of the direct gather).  Reads the layers' factors back: one stream synchronisation per call
+ * (such a call cannot be captured into a HIP graph) and deals the runs of layers to side streams
+ * of its own that join the caller's stream before the call returns.
  * Two-phase shard calls of such a plan use the direct gather.
  * last_gather_mode reports what the last call ran: 1 global, 2 staged, 3 resolution mode (direct
  * gather), 6 resolution mode through dynamic grids, plus 8 when the resident-profile kernel ran
