@@ -248,6 +248,8 @@ class LayerShardedTransit:
         m, e = self.model, self.engine
         n = len(self.layers)
         if n:
+            if m.resolution:
+                self.ec[:n].zero_()      # that mode ACCUMULATES into ec (like the reference)
             m.lbl.extinction(self.temp, self.dens, self.isoz, add=True, out=self.ec[:n])
         ec_cols, _ = layer_exchange(self.ec.view(self.lp, self.nwave), self.nlayers,
                                     self.nwave, self.world, self.rank, self.group,
@@ -260,6 +262,8 @@ class LayerShardedTransit:
     def _produce(self, ec_mine):
         n = len(self.layers)
         if n:
+            if self.model.resolution:
+                self.ec[:n].zero_()
             self.model.lbl.extinction(self.temp, self.dens, self.isoz, add=True, out=self.ec[:n])
 
     def _consume(self, ec_cols):

@@ -799,7 +799,9 @@ class LBLSpectrum:
     def extinction(self):
         if self.resolution:
             self.ec.zero_()              # the interpolating kernel adds to what it finds
-        if self.kmax_exchange is not None:
+        if self.kmax_exchange is not None and not self.resolution:
+            # (`resolution` mode: the dynamic-grid path takes the maxima over every line itself
+            # and a shard equals the slice of the whole call bit for bit -- no exchange)
             # wavenumber shard of a multi-GPU run: every rank derives the records (and the
             # strengths, the exp() work) of its own groups only; the per-row maxima that set
             # the ethresh threshold are made global by ONE small all-reduce(MAX)
