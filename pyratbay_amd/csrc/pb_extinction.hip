@@ -3609,8 +3609,11 @@ static int lbl_resolution_dyn(pb_lbl *p, LblArgs &a, double *ext_d, int64_t wbeg
     double load[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     for (int l0 = 0; l0 < nlayers && rc == PB_OK;) {
         const int f = p->h_ofactor[(size_t)l0];
+        // (a run's dynamic-grid sums stay below 1 GiB: fine factors on long fine grids)
+        const int64_t run_max = std::max<int64_t>(
+            1, ((int64_t)1 << 27) / ((int64_t)a.nrows * (1 + (l->onwn - 1) / f)));
         int l1 = l0 + 1;
-        while (l1 < nlayers && p->h_ofactor[(size_t)l1] == f)
+        while (l1 < nlayers && l1 - l0 < run_max && p->h_ofactor[(size_t)l1] == f)
             l1++;
         pb_lbl::DynSub *sub = nullptr;
         rc = dyn_subplan(p, f, s, &sub);

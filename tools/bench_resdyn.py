@@ -53,3 +53,12 @@ for _ in range(steps):
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / steps
 print(f'{name} dynamic: {dt*1e3:.3f} ms per spectrum ({1/dt:.1f} spectra/s)')
+# host time of one call (the launches of every run are issued by one thread)
+torch.cuda.synchronize()
+hs = []
+for _ in range(steps):
+    t0 = time.perf_counter()
+    model.extinction()
+    hs.append(time.perf_counter() - t0)
+    torch.cuda.synchronize()
+print(f'{name} dynamic: host time of the call {np.median(hs)*1e3:.3f} ms (then the stream drains)')
