@@ -975,3 +975,39 @@ def test_resolution_dynamic_grids(eng, monkeypatch):
     assert vt.device_bytes == before
     with pytest.raises(Exception, match='resolution'):
         build(eng, cases.extinction_inputs(), False, False, None)[2].set_gather_mode('dynamic')
+
+
+@pytest.mark.parametrize('gather', ['auto', 'dynamic'])
+def test_wavelength_step_grid(eng, orc, gather):
+    """The reference's `wlstep` mode is the same code path as `resolution` (an output grid that
+    is not a constant wavenumber step, _extcoeff.c:320-326): a constant-WAVELENGTH-step grid,
+    direct gather and dynamic grids, every layer against the oracle."""
+    from pyratbay_amd import synth
+    case = synth.lbl_case(2501, 6, 5000, wnosamp=24, nlor=14, ndop=7, extent=60.0, cutoff=3.0,
+                          niso=2, seed=31, resolution=40000.0)
+    g, atm, ln, iso, vg = (case[k] for k in ('grid', 'atm', 'lines', 'iso', 'voigt'))
+    # same fine grid, outputs at a constant wavelength step between its ends (ascending wn)
+    wl = np.linspace(1.0 / g['own'][-1], 1.0 / g['own'][0], 1800)
+    wn = (1.0 / wl)[::-1].copy()
+    wn[0] = g['own'][0]                                    # the package keeps wn[0] == own[0]
+    wn = wn[wn <= g['own'][-1]]
+    assert abs((1 / wn[3] - 1 / wn[4]) / (1 / wn[1000] - 1 / wn[1001]) - 1) < 1e-9
+    vt = eng.VoigtTable.build(vg['lorentz'], vg['doppler'], vg['size'], g['ownstep'],
+                              g['wnosamp'], 2)
+    ll = eng.LineList(ln['lwn'], ln['elow'], ln['gf'], ln['lid'], 2, g['own'])
+    lbl = eng.LBL(vt, ll, wn, g['divisors'], atm['mol_radius'], atm['mol_mass'], iso['isoimol'],
+                  iso['isomass'], iso['isoratio'], iso['isoiext'], vg['cutoff'], 1e-30,
+                  resolution=True, max_layers=6)
+    lbl.set_gather_mode(gather)
+    got = host(lbl.extinction(eng.dev(atm['temp']), eng.dev(atm['dens']), eng.dev(iso['isoz'])))
+    profile = vt.flat()
+    for layer in range(atm['nlayers']):
+        want = np.zeros((1, len(wn)))
+        orc.extinction(want, profile, vt.size, vt.index, vg['lorentz'], vg['doppler'], wn,
+                       g['own'], g['divisors'], atm['dens'][layer], atm['mol_radius'],
+                       atm['mol_mass'], iso['isoimol'], iso['isomass'], iso['isoratio'],
+                       iso['isoz'][:, layer].copy(), iso['isoiext'], ln['lwn'], ln['elow'],
+                       ln['gf'], ln['lid'], vg['cutoff'], 1e-30, atm['temp'][layer], 0, 1, 1)
+        assert np.array_equal(got[layer] == 0, want == 0)
+        np.testing.assert_allclose(got[layer], want, rtol=RTOL)
+    assert np.count_nonzero(got) > 0.3 * got.size

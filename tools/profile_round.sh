@@ -18,7 +18,7 @@ rm -rf gpurun_out/prof_bench gpurun_out/prof_c2res gpurun_out/prof_c5
 # which bench.py measures in its un-pipelined pass
 PB_STREAMS=1 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_bench -- python bench.py --no-cpu-baseline --sustain-seconds 0 > gpurun_out/prof_bench.log 2>&1 || exit 1
 cp $(find gpurun_out/prof_bench -name '*kernel_stats.csv' | head -1) gpurun_out/${tag}_kernel_stats.csv
-PB_STREAMS=1 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_c2res -- python bench.py --workload c2-res --steps 5 --warmup 2 --no-cpu-baseline --sustain-seconds 0 > gpurun_out/prof_c2res.log 2>&1 || exit 1
+PB_STREAMS=1 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_c2res -- python bench.py --workload c2-res --steps 10 --warmup 4 --no-cpu-baseline --sustain-seconds 0 > gpurun_out/prof_c2res.log 2>&1 || exit 1
 cp $(find gpurun_out/prof_c2res -name '*kernel_stats.csv' | head -1) gpurun_out/${tag}_kernel_stats_c2res.csv
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_c5 -- python bench.py --workload c5 --steps 20 --no-cpu-baseline > gpurun_out/prof_c5.log 2>&1 || exit 1
 cp $(find gpurun_out/prof_c5 -name '*kernel_stats.csv' | head -1) gpurun_out/${tag}_kernel_stats_c5.csv
@@ -28,7 +28,7 @@ cp $(find gpurun_out/prof_marker -name '*marker_api_stats.csv' | head -1) gpurun
 echo "kernel stats done"
 python bench.py --workload c5 > gpurun_out/${tag}_bench_c5.json 2> gpurun_out/${tag}_bench_c5.err || exit 1
 PB_TRANSIT_MFMA=0 python bench.py --workload c5 --no-cpu-baseline > gpurun_out/${tag}_bench_c5_vector.json 2> gpurun_out/${tag}_bench_c5_vector.err || exit 1
-python bench.py --workload c2-res --steps 5 --warmup 2 --cpu-layers 8 > gpurun_out/${tag}_bench_c2res.json 2> gpurun_out/${tag}_bench_c2res.err || exit 1
+python bench.py --workload c2-res > gpurun_out/${tag}_bench_c2res.json 2> gpurun_out/${tag}_bench_c2res.err || exit 1
 python bench.py --workload c3 --steps 5 --warmup 2 --cpu-layers 4 > gpurun_out/${tag}_bench_c3.json 2> gpurun_out/${tag}_bench_c3.err || exit 1
 python bench.py --workload c4 --steps 3 --warmup 1 --cpu-layers 2 > gpurun_out/${tag}_bench_c4.json 2> gpurun_out/${tag}_bench_c4.err || exit 1
 echo "other workloads done"
