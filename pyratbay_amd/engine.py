@@ -252,6 +252,7 @@ class LBL:
              hptr(args[2]), hptr(args[3]), hptr(args[4]), hptr(isoiext), self.niso,
              float(cutoff), float(ethresh), int(bool(resolution)), int(max_layers))
         self.resolution = bool(resolution)
+        self.gather_mode = 'auto'
 
     def set_isoiext(self, isoiext):
         isoiext = i32h(isoiext)
@@ -267,6 +268,7 @@ class LBL:
         """'auto' | 'global' | 'staged' | 'resident'; 'dynamic' (`resolution` plans: the layers'
         dynamic grids through constant-step sub-plans).  See pbhip.h: pb_lbl_set_gather_mode."""
         call('pb_lbl_set_gather_mode', self._h, self.GATHER[mode])
+        self.gather_mode = mode
 
     def set_record_budget(self, nbytes):
         """Largest buffer of per-(layer, group) line records a call may allocate; beyond it the
@@ -845,7 +847,13 @@ class LBLSpectrum:
         return a replay function: the whole step -- layer state, records, gather, optical
         depth, spectrum -- is then ONE graph launch, with inputs read from and outputs
         written to the same device buffers (update the atmosphere with set_atmosphere()).
-        The first call allocates workspaces, so it runs once eagerly before the capture."""
+        The first call allocates workspaces, so it runs once eagerly before the capture.
+        Not for the `resolution` mode's dynamic-grid path: the set of launches there depends on the
+        atmosphere (the layers' oversampling factors are read back every call)."""
+        if self.resolution and self.lbl.gather_mode == 'dynamic':
+            raise RuntimeError("capture(): the dynamic-grid path of the `resolution` mode reads "
+                               "the layers' factors back on every call and cannot be captured; "
+                               "lbl.set_gather_mode('auto') selects the direct gather")
         self.run()
         torch.cuda.synchronize()
         graph = torch.cuda.CUDAGraph()

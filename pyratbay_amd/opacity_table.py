@@ -25,7 +25,10 @@ UNITS = {
 
 def compute_opacity(lbl, temp_grid, press_bar, vmr, iso_pf, chunk_bytes=8 << 30,
                     out=None):
-    """lbl: engine.LBL plan (built with max_layers >= the chunk size);
+    """lbl: engine.LBL plan (built with max_layers >= the chunk size; a plan of the `resolution`
+    mode -- the usual grid of such tables -- should have set_gather_mode('dynamic'): the cells of
+    a chunk are then walked in runs of equal oversampling factor on the layers' dynamic grids,
+    5x the direct gather);
     temp_grid[ntemp] K; press_bar[nlayers]; vmr[nlayers, nmol];
     iso_pf[niso, ntemp] partition functions at temp_grid.
     Returns etable[nrows, ntemp, nlayers, nwave] (device tensor; nrows = species rows)."""

@@ -50,6 +50,43 @@ def test_compute_opacity_vs_oracle(setup, orc, tmp_path):
     np.testing.assert_array_equal(o, got)
 
 
+def test_compute_opacity_on_a_constant_resolution_grid(orc):
+    """The usual grid of an opacity table: constant resolving power (the reference's `resolution`
+    mode, _extcoeff.c:320-326).  compute_opacity() with the plan's per-layer dynamic grids
+    (gather mode 'dynamic': the cells of a chunk in runs of equal oversampling factor) against the
+    direct gather (1e-12) and the oracle (1e-10), several cells, chunked."""
+    from pyratbay_amd import engine, synth, opacity_table as ot
+    case = synth.lbl_case(1501, 5, 3000, wnosamp=24, nlor=16, ndop=8, extent=60.0, cutoff=4.0,
+                          niso=2, seed=6, resolution=45000.0)
+    g, atm, ln, iso, vg = (case[k] for k in ('grid', 'atm', 'lines', 'iso', 'voigt'))
+    vt = engine.VoigtTable.build(vg['lorentz'], vg['doppler'], vg['size'], g['ownstep'], 24, 2)
+    ll = engine.LineList(ln['lwn'], ln['elow'], ln['gf'], ln['lid'], 2, g['own'])
+    lbl = engine.LBL(vt, ll, g['wn'], g['divisors'], atm['mol_radius'], atm['mol_mass'],
+                     iso['isoimol'], iso['isomass'], iso['isoratio'], iso['isoiext'],
+                     vg['cutoff'], 1e-30, resolution=True, max_layers=16)
+    tgrid = np.array([700.0, 1200.0, 1900.0])
+    pf = np.array([synth.partition_function(tgrid)] * 2)
+    tables = {}
+    for mode in ('auto', 'dynamic'):
+        lbl.set_gather_mode(mode)
+        tables[mode] = ot.compute_opacity(lbl, tgrid, atm['press'], atm['vmr'], pf,
+                                          chunk_bytes=4 * lbl.nwave * 8).cpu().numpy()[0]
+    assert lbl.last_gather_kernel == 'dynamic grids'
+    assert np.array_equal(tables['auto'] == 0, tables['dynamic'] == 0)
+    np.testing.assert_allclose(tables['dynamic'], tables['auto'], rtol=1e-12)
+    profile = vt.flat()
+    for itemp, ilayer in ((0, 0), (1, 4), (2, 2)):
+        t = tgrid[itemp]
+        dens = atm['vmr'][ilayer] * atm['press'][ilayer] * synth.BAR / (synth.K_B * t)
+        want = np.zeros((1, g['nwave']))
+        orc.extinction(want, profile, vt.size, vt.index, vg['lorentz'], vg['doppler'], g['wn'],
+                       g['own'], g['divisors'], dens, atm['mol_radius'], atm['mol_mass'],
+                       iso['isoimol'], iso['isomass'], iso['isoratio'], pf[:, itemp].copy(),
+                       iso['isoiext'], ln['lwn'], ln['elow'], ln['gf'], ln['lid'], vg['cutoff'],
+                       1e-30, t, 0, 0, 1)
+        np.testing.assert_allclose(tables['dynamic'][itemp, ilayer], want[0], rtol=1e-10)
+
+
 def test_table_path_equals_lbl_on_grid_nodes(setup):
     """With layer temperatures on table nodes the interpolated cross sections times the
     density reproduce the line-by-line extinction, and so does the spectrum."""

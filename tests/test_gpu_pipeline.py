@@ -473,6 +473,8 @@ def test_resolution_mode_spectrum(eng, orc):
     np.testing.assert_allclose(first.cpu().numpy(), direct.cpu().numpy(), rtol=1e-12)
     model.lbl.set_gather_mode('dynamic')
     model.run()
+    with pytest.raises(RuntimeError, match='cannot be captured'):
+        model.capture()                                    # (the direct gather can be: not tried here)
     profile = vt.flat()
     ec = model.ec.cpu().numpy()[:, 0]
     for layer in range(atm['nlayers']):
