@@ -1,5 +1,6 @@
 """compute_opacity (runmode = opacity): every (T, p) cell of a cross-section grid as one
-batched extinction job.  usage: python tools/bench_opacity.py [ntemp] [workload]"""
+batched extinction job.  usage: python tools/bench_opacity.py [ntemp] [workload] [gather mode]
+(workload c2-res: a constant-resolving-power grid, gather mode 'dynamic' or 'auto' = direct)"""
 import os
 import sys
 import time
@@ -12,16 +13,18 @@ from pyratbay_amd import engine, synth, opacity_table as ot
 ntemp = int(sys.argv[1]) if len(sys.argv) > 1 else 10
 name = sys.argv[2] if len(sys.argv) > 2 else 'c2'
 w = bench.WORKLOADS[name]
-case = synth.lbl_case(w['nwave'], w['nlayers'], w['nlines'], wnstep=w['wnstep'],
-                      niso=w['niso'], seed=42)
+case = bench.make_case(w)
+res = case['grid'].get('resolution') is not None
 g, atm, ln, iso, vg = (case[k] for k in ('grid', 'atm', 'lines', 'iso', 'voigt'))
 nl = atm['nlayers']
 vt = engine.VoigtTable.build(vg['lorentz'], vg['doppler'], vg['size'], g['ownstep'],
-                             g['wnosamp'])
+                             g['wnosamp'], 2 if res else 0)
 ll = engine.LineList(ln['lwn'], ln['elow'], ln['gf'], ln['lid'], len(iso['isomass']), g['own'])
 lbl = engine.LBL(vt, ll, g['wn'], g['divisors'], atm['mol_radius'], atm['mol_mass'],
                  iso['isoimol'], iso['isomass'], iso['isoratio'], iso['isoiext'],
-                 vg['cutoff'], case['ethresh'], max_layers=ntemp * nl)
+                 vg['cutoff'], case['ethresh'], resolution=res, max_layers=ntemp * nl)
+if len(sys.argv) > 3:
+    lbl.set_gather_mode(sys.argv[3])
 tgrid = np.linspace(500.0, 2500.0, ntemp)
 pf = np.stack([synth.partition_function(tgrid)] * len(iso['isomass']))
 out = None
