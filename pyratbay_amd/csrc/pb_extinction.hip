@@ -3607,6 +3607,9 @@ static int lbl_resolution_dyn(pb_lbl *p, LblArgs &a, double *ext_d, int64_t wbeg
     // (deep layers: one or two layers on a short grid) are dealt to the remaining side streams,
     // least work first, and run in the shadow of the large ones.
     double load[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int nbig = 1;
+    if (const char *e = getenv("PB_RES_DYN_BIG"))
+        nbig = std::max(1, std::min(7, atoi(e)));
     for (int l0 = 0; l0 < nlayers && rc == PB_OK;) {
         const int f = p->h_ofactor[(size_t)l0];
         // (a run's dynamic-grid sums stay below 1 GiB: fine factors on long fine grids)
@@ -3623,12 +3626,12 @@ static int lbl_resolution_dyn(pb_lbl *p, LblArgs &a, double *ext_d, int64_t wbeg
         // sub-plan's workspaces with its first run: same side stream, hence in order
         int lane = 0;
         const int64_t groups = (int64_t)(l1 - l0) * pb::div_up((int64_t)sub->plan->nwave, (int64_t)4096);
-        if (groups < 512 && lanes > 1) {
-            lane = 1;
-            for (int k = 2; k < lanes; k++)
-                if (load[k] < load[lane])
-                    lane = k;
-        }
+        const int lo = groups < 512 ? std::min(nbig, lanes - 1) : 0;
+        const int hi = groups < 512 ? lanes : std::min(nbig, lanes);
+        lane = lo;
+        for (int k = lo + 1; k < hi; k++)
+            if (load[k] < load[lane])
+                lane = k;
         if (sub->call == p->dyn_call)
             lane = sub->lane;
         load[lane] += 60.0 + 45.0 * (l1 - l0);
