@@ -3049,7 +3049,9 @@ static int lbl_extinction(pb_lbl *p, double *ext_d, int64_t wbegin, int64_t wcou
     }
     a.use_records = use_records ? 1 : 0;
 
+    // (a fine grid shorter than two steps of the coarsest dynamic grid has no constant-step form)
     if (p->resolution && p->gather_mode == 6 && phase == 0 && l->ngroups > 0 &&
+        l->onwn > 2 * (int64_t)v->osamp &&
         !(getenv("PB_RES_DYN") && atoi(getenv("PB_RES_DYN")) == 0))
         return lbl_resolution_dyn(p, a, ext_d, wbegin, wcount, temp_d, dens_d, isoz_d,
                                   z_iso_stride, z_layer_stride, nlayers, add, s);
