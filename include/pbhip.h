@@ -443,6 +443,22 @@ int pb_transit_spectrum_batch(double *spectrum_d, double *depth_d, int32_t *idee
                               const double *radius_d, double rstar, int itop, int ibottom,
                               double maxdepth, int nlayers, int nwave, int nwalkers,
                               void *work_d, void *stream);
+/* interp_ec + optical depth + transmission of a batch in ONE pass (the retrieval inner loop,
+ * pyrat_obj.py:225-385: opacity/line_sampling.py:394-463 -> _extcoeff.c:367-418, then
+ * opacity/optic_depth.py:103-112 and spectrum/radiative_transfer.py:57-71, no cloud deck):
+ * etable_d[nmol,ntemp,nlayers,nwave], temps_d[nwalkers,nlayers], density_d[nwalkers,nlayers,nmol],
+ * raypath_d[nwalkers, n(n-1)/2], radius_d[nwalkers,nlayers] -> spectrum_d[nwalkers,nwave].
+ * The interpolated extinction is formed in registers as the operand of the FP64 matrix products
+ * and never stored.  pb_table_transit_supported(...) != 0 says whether the shape has this form
+ * (2..128 impact parameters, nwave >= 2, one species' block of the table below 4 GiB); work_d: pb_table_transit_work_doubles(...) doubles. */
+int pb_table_transit_supported(int nmol, int ntemp, int nlayers, int itop, int ibottom,
+                               int nwave);
+int64_t pb_table_transit_work_doubles(int nmol, int nlayers, int itop, int ibottom, int nwalkers);
+int pb_table_transit_batch(double *spectrum_d, const double *etable_d, const double *ttable_d,
+                           const double *temps_d, const double *density_d,
+                           const double *raypath_d, const double *radius_d, double rstar,
+                           int itop, int ibottom, double maxdepth, int nmol, int ntemp,
+                           int nlayers, int nwave, int nwalkers, void *work_d, void *stream);
 /* Emission geometry for a batch: plane_parallel_optical_depth (src_c/_trapezoid.c:175-213) +
  * blackbody + intensity + quadrature sum (pyrat/spectrum.py:366-377) in one pass, no cloud deck:
  * ec_d[nwalkers,nlayers,nwave], intervals_d[nwalkers,nlayers-1], temp_d[nwalkers,nlayers] ->

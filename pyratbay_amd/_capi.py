@@ -76,6 +76,10 @@ _PROTOS = {
     'pb_interp_ec_batch': [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp],
     'pb_transit_work_doubles': [i32, i32, i32, i32, i32],
     'pb_transit_spectrum_batch': [vp, vp, vp, vp, vp, vp, f64, i32, i32, f64, i32, i32, i32, vp, vp],
+    'pb_table_transit_supported': [i32, i32, i32, i32, i32, i32],
+    'pb_table_transit_work_doubles': [i32, i32, i32, i32, i32],
+    'pb_table_transit_batch': [vp, vp, vp, vp, vp, vp, vp, f64, i32, i32, f64, i32, i32, i32, i32,
+                               i32, vp, vp],
     'pb_emission_flux_batch': [vp, vp, vp, vp, vp, vp, vp, i32, f64, i32, i32, i32, i32, i32, vp],
     'pb_band_integrate_batch': [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp],
     'pb_reject_walkers': [vp, vp, f64, f64, i32, i32, i32, vp],
@@ -101,7 +105,8 @@ _PROTOS = {
     'pb_ediff': [vp, vp, i32, vp],
     'pb_band_integrate': [vp, vp, vp, vp, vp, vp, vp, i32, i64, i64, vp],
 }
-_RESTYPES = {'pb_transit_work_doubles': C.c_int64, 'pb_voigt_destroy': None, 'pb_lines_destroy': None, 'pb_lbl_destroy': None,
+_RESTYPES = {'pb_transit_work_doubles': C.c_int64, 'pb_table_transit_work_doubles': C.c_int64,
+             'pb_table_transit_supported': C.c_int, 'pb_voigt_destroy': None, 'pb_lines_destroy': None, 'pb_lbl_destroy': None,
              'pb_voigt_device_bytes': i64, 'pb_timer_destroy': None}
 _NO_CHECK = set(_RESTYPES) | {'pb_version', 'pb_roctx_available'}
 

@@ -551,6 +551,52 @@ __global__ __launch_bounds__(kBlock) void k_path_qblocks(double *out, const doub
 typedef double v4d __attribute__((ext_vector_type(4)));
 typedef double d2u __attribute__((ext_vector_type(2), aligned(8)));
 
+// Epilogue of the matrix-core transit kernels on the accumulator layout: lane (kq = l >> 4,
+// n = l & 15) holds the rows 16m + 4j + kq of its two columns (col0, col0 + 1).
+template <int MT>
+__device__ __forceinline__ void mfma_transit_epilogue(
+    const v4d (&C)[2][MT], const double *s_rad, double *spectrum_w, int col0, const bool (&ok)[2],
+    int lane, int nimpact, double maxdepth, double rstar)
+{
+    const int kq = lane >> 4;
+    const double rtop = s_rad[0];
+    const double *srad = s_rad + kq;
+    const int src_lane = (lane + 48) & 63;                // the lane one row above (16 below)
+#pragma unroll
+    for (int t = 0; t < 2; t++) {
+        int first = INT_MAX;
+#pragma unroll
+        for (int m = 0; m < MT; m++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int r = 16 * m + 4 * j + kq;
+                if (r < nimpact && C[t][m][j] > maxdepth)
+                    first = min(first, r);
+            }
+        first = min(first, __shfl_xor(first, 16));
+        first = min(first, __shfl_xor(first, 32));
+        double acc = 0.0, carry = 0.0;                    // carry: row 16m + 4j - 1 seen from q = 0
+#pragma unroll
+        for (int m = 0; m < MT; m++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int r = 16 * m + 4 * j + kq;
+                const bool in = r < nimpact && r <= first;
+                const double rr = srad[16 * m + 4 * j];
+                const double f = in ? pb::exp_s(-C[t][m][j]) * rr : 0.0;
+                const double up = __shfl(f, src_lane);    // q > 0: row r - 1; q = 0: row r + 3
+                const double fprev = kq > 0 ? up : carry;
+                carry = up;
+                if (in && r >= 1)
+                    acc += (rr - srad[16 * m + 4 * j - 1]) * (fprev + f);
+            }
+        acc += __shfl_xor(acc, 16);
+        acc += __shfl_xor(acc, 32);
+        if (kq == 0 && ok[t])
+            spectrum_w[col0 + t] = (rtop * rtop + 2 * (acc * 0.5)) / (rstar * rstar);
+    }
+}
+
 // A wavefront owns 32 columns = two 16-column tiles (the even and the odd columns of its range:
 // one 16-byte load per lane fetches both) and all MT row tiles: 2 x MT accumulators stay in
 // registers while the layers stream past once, four K-steps (16 layers) in flight ahead of the
@@ -627,43 +673,156 @@ __global__ __launch_bounds__(TB, WPS) void k_transit_mfma(
             }
         }
     }
-    // epilogue on the accumulator layout: rows 16m + 4j + kq of my two columns
-    const double rtop = s_rad[0];
-    const double *srad = s_rad + kq;
-    const int src_lane = (lane + 48) & 63;                // the lane one row above (16 below)
-#pragma unroll
-    for (int t = 0; t < 2; t++) {
-        int first = INT_MAX;
-#pragma unroll
-        for (int m = 0; m < MT; m++)
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const int r = 16 * m + 4 * j + kq;
-                if (r < nimpact && C[t][m][j] > maxdepth)
-                    first = min(first, r);
-            }
-        first = min(first, __shfl_xor(first, 16));
-        first = min(first, __shfl_xor(first, 32));
-        double acc = 0.0, carry = 0.0;                    // carry: row 16m + 4j - 1 seen from q = 0
-#pragma unroll
-        for (int m = 0; m < MT; m++)
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const int r = 16 * m + 4 * j + kq;
-                const bool in = r < nimpact && r <= first;
-                const double rr = srad[16 * m + 4 * j];
-                const double f = in ? pb::exp_s(-C[t][m][j]) * rr : 0.0;
-                const double up = __shfl(f, src_lane);    // q > 0: row r - 1; q = 0: row r + 3
-                const double fprev = kq > 0 ? up : carry;
-                carry = up;
-                if (in && r >= 1)
-                    acc += (rr - srad[16 * m + 4 * j - 1]) * (fprev + f);
-            }
-        acc += __shfl_xor(acc, 16);
-        acc += __shfl_xor(acc, 32);
-        if (kq == 0 && ok[t])
-            spectrum[(int64_t)w * nwave + col0 + t] = (rtop * rtop + 2 * (acc * 0.5)) / (rstar * rstar);
+    mfma_transit_epilogue<MT>(C, s_rad, spectrum + (int64_t)w * nwave, col0, ok, lane, nimpact,
+                              maxdepth, rstar);
+}
+
+// ---------------------------------------------------------------------------
+// Interpolation + optical depth + transmission of the retrieval batch in ONE pass: the B operand of
+// k_transit_mfma -- 4 layers x 16 columns of a walker's ec -- is not loaded but FORMED from the
+// cross-section table (the sums of interp_ec, _extcoeff.c:367-418: sum_s d_s (w_lo T[s][tlo] +
+// w_hi T[s][tlo+1]), same products and order as k_interp_ec_batch2), so ec[walker][layer][sample]
+// -- 4.1 GB per 64 walkers at C5's shape, written by one kernel and read back by the next -- never
+// exists.  What makes that affordable is the ORDER of the workgroups: the table slices a walker
+// brackets are shared with the other walkers of the batch, so all walkers of one column block run
+// at the same time on ONE XCD (workgroup id -> xcd = id & 7; the XCD's slots walk its column
+// blocks one after the other, the walkers of a block in consecutive slots): a slice element comes
+// from HBM once per batch and from that XCD's L2 for the other walkers.
+// LDS: the walker's Q blocks and radii as in k_transit_mfma, its per-layer coefficients
+// (k_interp_weights) and table offsets.  PD = K-steps whose table loads are in flight ahead of the
+// one being multiplied (2 x kS 16-byte loads per lane and K-step, wave-uniform bases in SGPRs +
+// one 32-bit offset per lane: no vector address arithmetic).
+// MEASURED (C5's shape, tools/bench_tt.py) and NOT the default of TableSpectrum.eval_bands: 3.10 ms
+// per 64 walkers against 2.70 for the two passes.  HBM traffic is what it should be (PMC: 1.5 GB
+// fetched per launch against 4.4 GB for k_transit_mfma alone; L2 hit rate 96 %), but the 8 slice
+// reads per walker, layer and sample now come from the XCD's L2 -- 32.8 GB per batch -- and L2 ->
+// L1 delivers ~12 TB/s of them: with the table loads taken out the kernel runs 1.4 ms, with the
+// matrix products taken out 2.7.  Per-walker Q blocks (30 KB of LDS each) leave no room to share
+// the slices of several walkers through LDS.  Kept (opt-in) for what it saves: the 4.1 GB of ec per
+// 64 walkers are never allocated.
+// ---------------------------------------------------------------------------
+template <int MT, int WPS, int TB, int kS, int PD>
+__global__ __launch_bounds__(TB, WPS) void k_table_transit_mfma(
+    double *spectrum, const double *etable, const int32_t *tlo, const double *coef,
+    const double *qblk, const double *radius, int nblk, double rstar, int itop, int ibottom,
+    double maxdepth, int nmol, int ntemp, int nlayers, int nwave, int nwalkers, int ncolblk)
+{
+    extern __shared__ __align__(16) double s_q[];         // [nblk][64] | rad[16 MT] | coef[16 MT][2 kS] | off[16 MT]
+    // XCD-aware order: see above
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int cb = (slot / nwalkers) * 8 + xcd;
+    const int w = slot % nwalkers;
+    if (cb >= ncolblk)
+        return;                                           // (whole workgroup, before the barrier)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nimpact = min(ibottom, nlayers) - itop;
+    double *s_rad = s_q + (size_t)nblk * 64;
+    double *s_coef = s_rad + 16 * MT;
+    uint32_t *s_off = reinterpret_cast<uint32_t *>(s_coef + 16 * MT * 2 * kS);
+    {
+        const double *q = qblk + (int64_t)w * nblk * 64;
+        for (int e = tid; e < nblk * 64; e += TB)
+            s_q[e] = q[e];
+        for (int r = tid; r < 16 * MT; r += TB) {
+            s_rad[r] = r < nimpact ? radius[(int64_t)w * nlayers + itop + r] : 0.0;
+            // byte offset of (bracket's lower slice, layer) inside one species' block of the table
+            // (< 4 GiB: checked by the launcher); rows beyond the last layer repeat it (their Q is 0)
+            const int rr = min(r, nimpact - 1);
+            const int64_t t = tlo[(int64_t)w * nlayers + itop + rr];
+            s_off[r] = (uint32_t)(((t * nlayers + itop + rr) * (int64_t)nwave) * 8);
+        }
+        for (int e = tid; e < 16 * MT * 2 * kS; e += TB) {
+            const int r = min(e / (2 * kS), nimpact - 1);
+            s_coef[e] = coef[((int64_t)w * nlayers + itop + r) * 2 * kS + e % (2 * kS)];
+        }
     }
+    __syncthreads();
+    const int c0 = (cb * (TB / 64) + wave) * 32;
+    if (c0 >= nwave)
+        return;                                           // (after the only barrier)
+    const int kq = lane >> 4, n = lane & 15;
+    const int col0 = c0 + 2 * n;                          // tile 0: even columns, tile 1: odd ones
+    const bool ok[2] = {col0 < nwave, col0 + 1 < nwave};
+    const int cpair = max(min(col0, nwave - 2), 0);       // first column of the pair I load
+    const bool second = col0 != cpair;                    // my column 0 is the pair's second one
+    const int64_t slice = (int64_t)nlayers * nwave;
+    // wave-uniform bases (SGPR pairs) + one 32-bit byte offset per lane and K-step: the loads need
+    // no vector address arithmetic (species beyond nmol: a valid block, their coefficients are 0)
+    const char *base_lo[kS], *base_hi[kS];
+#pragma unroll
+    for (int sp = 0; sp < kS; sp++) {
+        base_lo[sp] = reinterpret_cast<const char *>(etable + (int64_t)min(sp, nmol - 1) * ntemp * slice);
+        base_hi[sp] = base_lo[sp] + slice * 8;
+    }
+    const uint32_t lane_off = (uint32_t)cpair * 8u;
+    v4d C[2][MT];
+#pragma unroll
+    for (int t = 0; t < 2; t++)
+#pragma unroll
+        for (int m = 0; m < MT; m++)
+            C[t][m] = v4d{0.0, 0.0, 0.0, 0.0};
+    d2u raw[PD][2 * kS];
+    // K-steps of one group of four (same row tiles) are taken in an order rotated by the walker
+    // index: the walkers of a column block run at the same time and would otherwise all ask the
+    // XCD's L2 for the same lines at the same moment
+    const int rot = w & 3;
+    auto kstep = [&](int ks) { return (ks & ~3) | ((ks + rot) & 3); };
+    auto issue = [&](int ks0, d2u (&r)[2 * kS]) {
+        const int ks = kstep(ks0);
+        const uint32_t off = s_off[4 * ks + kq] + lane_off;
+#pragma unroll
+        for (int sp = 0; sp < kS; sp++) {
+            r[sp] = *reinterpret_cast<const d2u *>(base_lo[sp] + off);
+            r[kS + sp] = *reinterpret_cast<const d2u *>(base_hi[sp] + off);
+        }
+    };
+    auto combine = [&](int ks0, const d2u (&r)[2 * kS], double (&b)[2]) {
+        const int ks = kstep(ks0);
+        const double *co = s_coef + (4 * ks + kq) * 2 * kS;
+        double ax = 0.0, ay = 0.0;
+#pragma unroll
+        for (int sp = 0; sp < kS; sp++) {
+            // the sums of interp_ec with fused multiply-adds (k_interp_ec_batch2 rounds every
+            // product: the two forms agree to ~1e-16 relative)
+            ax = fma(r[sp].x, co[sp], ax);
+            ay = fma(r[sp].y, co[sp], ay);
+            ax = fma(r[kS + sp].x, co[kS + sp], ax);
+            ay = fma(r[kS + sp].y, co[kS + sp], ay);
+        }
+        b[0] = second ? ay : ax;
+        b[1] = ay;
+    };
+    // All 4 MT K-steps run whatever the number of layers (rows beyond the last one: Q = 0, the
+    // table address of the last row): no branch inside the loop, ONE basic block, so that the
+    // scheduler can place a step's loads and sums between the previous step's matrix products.
+#pragma unroll
+    for (int d = 0; d < PD; d++)
+        if (d < 4 * MT)
+            issue(d, raw[d]);
+    double bcur[2], bnxt[2] = {0.0, 0.0};
+    combine(0, raw[0], bcur);
+    if (PD < 4 * MT)
+        issue(PD, raw[0]);
+    const double *sq = s_q + lane;
+#pragma unroll
+    for (int ks = 0; ks < 4 * MT; ks++) {
+        // the next K-step's operand is formed in the shadow of this step's matrix products
+        if (ks + 1 < 4 * MT) {
+            combine(ks + 1, raw[(ks + 1) % PD], bnxt);
+            if (ks + 1 + PD < 4 * MT)
+                issue(ks + 1 + PD, raw[(ks + 1) % PD]);
+        }
+#pragma unroll
+        for (int m = ks / 4; m < MT; m++) {
+            const double a = sq[(qblocks(m) + kstep(ks)) * 64];
+            C[0][m] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bcur[0], C[0][m], 0, 0, 0);
+            C[1][m] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bcur[1], C[1][m], 0, 0, 0);
+        }
+        bcur[0] = bnxt[0];
+        bcur[1] = bnxt[1];
+    }
+    mfma_transit_epilogue<MT>(C, s_rad, spectrum + (int64_t)w * nwave, col0, ok, lane, nimpact,
+                              maxdepth, rstar);
 }
 
 // ---------------------------------------------------------------------------
@@ -1221,6 +1380,113 @@ int pb_transit_spectrum_batch(double *spectrum_d, double *depth_d, int32_t *idee
     return pb_transit_fused_launch(depth_d, ideep_d, spectrum_d, ec_d, raypath_d, radius_d, npath,
                                    rstar, itop, ibottom, maxdepth, nlayers, nwave, nwalkers, -1,
                                    0.0, pb::as_stream(stream), reinterpret_cast<double *>(work_d));
+}
+
+int pb_table_transit_supported(int nmol, int ntemp, int nlayers, int itop, int ibottom, int nwave)
+{
+    if (nmol < 1 || nmol > 8 || nlayers < 1 || itop < 0 || itop >= nlayers || ibottom > nlayers ||
+        ntemp < 2)
+        return 0;
+    // one species' block of the table is addressed with 32-bit byte offsets
+    if ((int64_t)ntemp * nlayers * nwave * 8 + 16 > 0xffffffffll)
+        return 0;
+    const int nimpact = std::min(ibottom, nlayers) - itop;
+    const int mt = pb::div_up(std::max(nimpact, 1), 16);
+    return nimpact > 1 && mt <= 8 && nwave >= 2;
+}
+
+int64_t pb_table_transit_work_doubles(int nmol, int nlayers, int itop, int ibottom, int nwalkers)
+{
+    if (!pb_table_transit_supported(nmol, 2, nlayers, itop, ibottom, 2))
+        return 0;
+    const int nimpact = std::min(ibottom, nlayers) - itop;
+    const int ncoef = nmol <= 4 ? 4 : 8;
+    const int64_t n = (int64_t)std::max(nwalkers, 0) * nlayers;
+    // Q blocks | coef[n][2 ncoef] | tlo[n] (ints, rounded up to doubles)
+    return (int64_t)qblocks(pb::div_up(nimpact, 16)) * 64 * std::max(nwalkers, 0) + n * 2 * ncoef +
+           (n + 1) / 2 + 8;
+}
+
+int pb_table_transit_batch(double *spectrum_d, const double *etable_d, const double *ttable_d,
+                           const double *temps_d, const double *density_d,
+                           const double *raypath_d, const double *radius_d, double rstar,
+                           int itop, int ibottom, double maxdepth, int nmol, int ntemp,
+                           int nlayers, int nwave, int nwalkers, void *work_d, void *stream)
+{
+    PB_REQUIRE(nmol >= 1 && nmol <= 8 && ntemp >= 2 && nlayers >= 1 && nwave >= 0 && nwalkers >= 0,
+               "pb_table_transit_batch: bad shape (1-8 species, >= 2 table temperatures)");
+    PB_REQUIRE(itop >= 0 && itop < nlayers, "pb_table_transit_batch: itop out of range");
+    PB_REQUIRE(ibottom <= nlayers, "pb_table_transit_batch: ibottom > nlayers");
+    if (nwave == 0 || nwalkers == 0)
+        return PB_OK;
+    PB_REQUIRE(pb_table_transit_supported(nmol, ntemp, nlayers, itop, ibottom, nwave),
+               "pb_table_transit_batch: shape outside the one-pass form (ask "
+               "pb_table_transit_supported; use pb_interp_ec_batch + pb_transit_spectrum_batch)");
+    PB_REQUIRE(spectrum_d && etable_d && ttable_d && temps_d && density_d && raypath_d &&
+                   radius_d && work_d,
+               "pb_table_transit_batch: null pointer");
+    PB_REQUIRE((int64_t)nwalkers * pb::div_up(nwave, 128) * 8 + 8 * (int64_t)nwalkers < (1ll << 31),
+               "pb_table_transit_batch: too many workgroups");
+    hipStream_t s = pb::as_stream(stream);
+    const int nrow = nlayers - itop;
+    const int nimpact = std::min(ibottom, nlayers) - itop;
+    const int64_t npath = ((int64_t)nrow * (nrow - 1)) / 2;
+    const int mt = pb::div_up(nimpact, 16);
+    const int nblk = qblocks(mt);
+    const int ncoef = nmol <= 4 ? 4 : 8;
+    const int64_t n = (int64_t)nwalkers * nlayers;
+    double *qwork = reinterpret_cast<double *>(work_d);
+    double *coef = qwork + (int64_t)nblk * 64 * nwalkers;
+    int32_t *tlo = reinterpret_cast<int32_t *>(coef + n * 2 * ncoef);
+    k_interp_weights<<<pb::div_up(n, kBlock), kBlock, 0, s>>>(tlo, coef, ttable_d, temps_d,
+                                                            density_d, nmol, ncoef, ntemp, n);
+    PB_LAUNCH_CHECK();
+    dim3 qgrid((unsigned)std::min(16, pb::div_up((int64_t)nblk * 64, kBlock)), nwalkers);
+    k_path_qblocks<<<qgrid, kBlock, 0, s>>>(qwork, raypath_d, npath, nblk, nimpact);
+    PB_LAUNCH_CHECK();
+    const size_t lds = ((size_t)nblk * 64 + (size_t)mt * 16 * (1 + 2 * ncoef)) * 8 + (size_t)mt * 16 * 4;
+#define PB_TT(M, W, T, S, P)                                                                       \
+    do {                                                                                           \
+        if (lds > 64 * 1024)                                                                       \
+            PB_HIP(hipFuncSetAttribute(                                                            \
+                reinterpret_cast<const void *>(k_table_transit_mfma<M, W, T, S, P>),               \
+                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                            \
+        const int ncb = pb::div_up(nwave, (T / 64) * 32);                                          \
+        const unsigned grid = (unsigned)(8 * (int64_t)pb::div_up(ncb, 8) * nwalkers);              \
+        k_table_transit_mfma<M, W, T, S, P><<<grid, T, lds, s>>>(                                  \
+            spectrum_d, etable_d, tlo, coef, qwork, radius_d, nblk, rstar, itop, ibottom, maxdepth, \
+            nmol, ntemp, nlayers, nwave, nwalkers, ncb);                                           \
+    } while (0)
+    // Geometry measured at C5's shape (80 layers, 4 species; tools/bench_tt.py, ms per 64 walkers,
+    // two passes over a stored ec 2.70): 384 threads, one K-step of loads in flight, 3 wavefronts
+    // per SIMD (148 registers, no spill) 3.10; 512 threads, two K-steps in flight, 2 per SIMD (176
+    // registers) 3.19; every 128-register form spills (4.2-4.3).
+    if (ncoef == 8) {
+        switch (mt) {
+        case 1: PB_TT(1, 2, 256, 8, 1); break;
+        case 2: PB_TT(2, 2, 256, 8, 1); break;
+        case 3: PB_TT(3, 2, 256, 8, 1); break;
+        case 4: PB_TT(4, 2, 256, 8, 1); break;
+        case 5: PB_TT(5, 2, 256, 8, 1); break;
+        case 6: PB_TT(6, 2, 256, 8, 1); break;
+        case 7: PB_TT(7, 2, 256, 8, 1); break;
+        default: PB_TT(8, 2, 256, 8, 1); break;
+        }
+    } else {
+        switch (mt) {
+        case 1: PB_TT(1, 3, 384, 4, 1); break;
+        case 2: PB_TT(2, 3, 384, 4, 1); break;
+        case 3: PB_TT(3, 3, 384, 4, 1); break;
+        case 4: PB_TT(4, 3, 384, 4, 1); break;
+        case 5: PB_TT(5, 3, 384, 4, 1); break;
+        case 6: PB_TT(6, 2, 256, 4, 1); break;
+        case 7: PB_TT(7, 2, 256, 4, 1); break;
+        default: PB_TT(8, 2, 256, 4, 1); break;
+        }
+    }
+#undef PB_TT
+    PB_LAUNCH_CHECK();
+    return PB_OK;
 }
 
 int pb_band_integrate_batch(double *bandflux_d, const double *spectrum_d, const double *wn_d,

@@ -303,3 +303,102 @@ def test_transit_on_the_matrix_cores(eng, orc, monkeypatch, nlayers, nwave, itop
         stops |= set(np.unique(wi // 16))
     if L >= 80:
         assert len(stops) >= 2          # exits in several row tiles
+
+
+@pytest.mark.parametrize('nlayers,nwave,itop,nmol', [(80, 1000, 0, 4), (80, 131, 2, 4),
+                                                      (17, 99, 0, 1), (48, 40, 5, 3),
+                                                      (33, 257, 0, 6), (120, 300, 3, 8),
+                                                      (128, 130, 0, 4), (2, 64, 0, 2),
+                                                      (16, 16, 0, 5), (96, 2, 1, 4)])
+def test_table_transit_one_pass(eng, orc, monkeypatch, nlayers, nwave, itop, nmol):
+    """pb_table_transit_batch -- interp_ec, optical depth and transmission of a batch in one pass,
+    the interpolated extinction formed in registers as the operand of the matrix products -- against
+    the two-pass form (pb_interp_ec_batch + pb_transit_spectrum_batch on a stored ec; 1e-13: the one
+    pass forms the sums of interp_ec with fused multiply-adds) and against the oracle's interp_ec +
+    optdepth loop + transmission (1e-12).  Shapes: 1-8 row tiles, 1-8 species (both register
+    widths, species beyond nmol padded), ragged rows / columns, itop > 0, the smallest grid,
+    temperatures on table nodes and at both table ends, per-walker radii."""
+    rng = np.random.default_rng(23)
+    L, W, nw, ntemp = nlayers, nwave, 5, 6
+    assert eng.table_transit_supported(nmol, ntemp, L, itop, L, W)
+    ttable = np.linspace(300.0, 3000.0, ntemp)
+    press = np.logspace(-6, 2, L)
+    # columns from transparent to opaque, so that the exits fall in every row tile
+    colscale = 10.0**rng.uniform(-33.5, -27.0, W)
+    etable = (10.0**rng.uniform(-0.3, 0.3, (nmol, ntemp, L, W)) * colscale *
+              np.linspace(1.0, 2.0, ntemp)[None, :, None, None])
+    etable[:, :, :, :2] = 0.0
+    temps = rng.uniform(300.0, 3000.0, (nw, L))
+    temps[0] = ttable[rng.integers(0, ntemp, L)]
+    temps[1] = 300.0
+    temps[2] = 3000.0
+    dens = press[None, :, None]**0.9 * 10.0**rng.uniform(17, 18, (nw, L, nmol))
+    radius = np.array([np.sort(np.linspace(8.0e9, 7.0e9, L) * (1 + 0.01 * rng.uniform(-1, 1)) +
+                               rng.uniform(-1e5, 1e5, L))[::-1] for _ in range(nw)])
+    rstar = 8.8e10
+    et, tt = eng.dev(etable), eng.dev(ttable)
+    td, dd, rd = eng.dev(temps), eng.dev(dens), eng.dev(radius)
+    path = eng.transit_path_device(rd, itop)
+    got = host(eng.table_transit_batch(et, tt, td, dd, path, rd, rstar, itop, L, 10.0))
+    ec = eng.interp_ec_batch(et, tt, td, dd)
+    two = host(eng.transit_spectrum_batch(ec, path, rd, rstar, itop, L, 10.0))
+    np.testing.assert_allclose(got, two, rtol=1e-13)
+    stops = set()
+    for w in range(nw):
+        want_ec = np.zeros((L, W))
+        orc.interp_ec(want_ec, etable, ttable, temps[w], dens[w], 0, L)
+        wd, wi = orc.optical_depth_transit(want_ec, radius[w], itop, L, 10.0)
+        ws = orc.transmission(wd, radius[w], rstar, wi, itop)
+        np.testing.assert_allclose(got[w], ws, rtol=RTOL)
+        stops |= set(np.unique(wi // 16))
+    if L >= 80 and W >= 100:
+        assert len(stops) >= 2
+
+
+def test_eval_bands_one_pass_equals_two_passes(eng):
+    """TableSpectrum.eval_bands with one_pass = True (pb_table_transit_batch) against its default
+    (interpolation and optical depth as two passes over a stored ec): band fluxes to 1e-13, the
+    rejected walker +inf in both."""
+    import torch
+    rng = np.random.default_rng(5)
+    nmol, ntemp, L, W, nw = 4, 6, 40, 3000, 9
+    ttable = np.linspace(300.0, 3000.0, ntemp)
+    wn = np.linspace(4000.0, 4150.0, W)
+    press = np.logspace(-6, 2, L)
+    etable = 10.0**rng.uniform(-30, -24, (nmol, ntemp, L, W))
+    temps = rng.uniform(900.0, 1800.0, (nw, L))
+    temps[3, 5] = 3200.0                                   # outside the table: rejected
+    dens = press[None, :, None]**0.9 * 10.0**rng.uniform(14, 15, (nw, L, nmol))
+    radius = np.array([np.sort(np.linspace(8.0e9, 7.0e9, L) * (1 + 0.01 * rng.uniform(-1, 1)))[::-1]
+                       for _ in range(nw)])
+    model = eng.TableSpectrum(etable, ttable, wn, radius[0], 8.8e10, rt_path='transit')
+    bands = eng.PassBands(wn, [(100, np.ones(500), 1.0), (1500, np.linspace(0.2, 1.0, 900), 0.5)])
+    td, dd, rd = eng.dev(np.clip(temps, 300.0, 3000.0)), eng.dev(dens), eng.dev(radius)
+    td[3, 5] = 3200.0
+    two = host(model.eval_bands(td, dd, bands, radius=rd))
+    model.one_pass = True
+    one = host(model.eval_bands(td, dd, bands, radius=rd))
+    assert np.all(np.isinf(two[3])) and np.all(np.isinf(one[3]))
+    keep = np.arange(nw) != 3
+    np.testing.assert_allclose(one[keep], two[keep], rtol=1e-13)
+
+
+def test_table_transit_refuses_other_shapes(eng):
+    """One impact parameter, more than 8 row tiles, a one-sample grid or a table whose species blocks
+    exceed 32-bit byte offsets have no one-pass form:
+    pb_table_transit_supported says so and the entry returns an error instead of a wrong launch."""
+    assert not eng.table_transit_supported(4, 3, 1, 0, 1, 100)
+    assert not eng.table_transit_supported(4, 3, 130, 0, 130, 100)
+    assert not eng.table_transit_supported(4, 3, 80, 0, 80, 1)
+    assert not eng.table_transit_supported(9, 3, 80, 0, 80, 100)
+    assert not eng.table_transit_supported(4, 30, 80, 0, 80, 1000001)   # 19 GB per species
+    assert eng.table_transit_supported(4, 3, 130, 2, 130, 100)
+    import torch
+    et = torch.zeros((4, 3, 130, 10), dtype=torch.float64, device='cuda')
+    tt = eng.dev(np.array([300.0, 700.0, 1100.0]))
+    temps = torch.full((2, 130), 500.0, dtype=torch.float64, device='cuda')
+    dens = torch.ones((2, 130, 4), dtype=torch.float64, device='cuda')
+    rad = eng.dev(np.tile(np.linspace(8e9, 7e9, 130), (2, 1)))
+    path = eng.transit_path_device(rad, 0)
+    with pytest.raises(Exception, match='one-pass'):
+        eng.table_transit_batch(et, tt, temps, dens, path, rad, 8.8e10, 0, 130, 10.0)
