@@ -521,7 +521,7 @@ __global__ __launch_bounds__(kBlock) void k_transit_pair(
 // of a column.  Sums of a column are added in a different order than the reference's loop:
 // spectra agree to ~1e-15 relative with the vector form, not bit for bit.
 // ---------------------------------------------------------------------------
-__host__ __device__ inline int qblocks(int mt) { return 2 * mt * mt + 2 * mt; }
+__host__ __device__ constexpr int qblocks(int mt) { return 2 * mt * mt + 2 * mt; }
 
 __global__ __launch_bounds__(kBlock) void k_path_qblocks(double *out, const double *raypath,
                                                          int64_t npath, int nblk, int nimpact)
@@ -597,6 +597,29 @@ __device__ __forceinline__ void mfma_transit_epilogue(
     }
 }
 
+// A walker's Q blocks (qblocks(MT) x 64 doubles: 30 KB at 80 layers) -> LDS.  The count is a
+// compile-time constant of the instantiation, so every thread issues ALL of its 16-byte loads
+// before the first LDS store: one L2 round trip per workgroup instead of one per 8-byte element of
+// a run-time loop (7.5 at 512 threads).
+template <int MT, int TB>
+__device__ __forceinline__ void stage_qblocks(double *s_q, const double *q, int tid)
+{
+    constexpr int N2 = qblocks(MT) * 32;                  // 16-byte units
+    constexpr int PER = (N2 + TB - 1) / TB;
+    const d2u *src = reinterpret_cast<const d2u *>(q);
+    d2u tmp[PER];
+#pragma unroll
+    for (int i = 0; i < PER; i++)
+        if (tid + i * TB < N2)
+            tmp[i] = src[tid + i * TB];
+#pragma unroll
+    for (int i = 0; i < PER; i++)
+        if (tid + i * TB < N2) {
+            s_q[2 * (tid + i * TB)] = tmp[i].x;
+            s_q[2 * (tid + i * TB) + 1] = tmp[i].y;
+        }
+}
+
 // A wavefront owns 32 columns = two 16-column tiles (the even and the odd columns of its range:
 // one 16-byte load per lane fetches both) and all MT row tiles: 2 x MT accumulators stay in
 // registers while the layers stream past once, four K-steps (16 layers) in flight ahead of the
@@ -614,9 +637,7 @@ __global__ __launch_bounds__(TB, WPS) void k_transit_mfma(
     const int nimpact = min(ibottom, nlayers) - itop;
     double *s_rad = s_q + (size_t)nblk * 64;
     {
-        const double *q = qblk + (int64_t)w * nblk * 64;
-        for (int e = tid; e < nblk * 64; e += TB)
-            s_q[e] = q[e];
+        stage_qblocks<MT, TB>(s_q, qblk + (int64_t)w * nblk * 64, tid);
         for (int r = tid; r < 16 * MT; r += TB)
             s_rad[r] = r < nimpact ? radius[(int64_t)w * nlayers + itop + r] : 0.0;
     }
@@ -692,8 +713,8 @@ __global__ __launch_bounds__(TB, WPS) void k_transit_mfma(
 // (k_interp_weights) and table offsets.  PD = K-steps whose table loads are in flight ahead of the
 // one being multiplied (2 x kS 16-byte loads per lane and K-step, wave-uniform bases in SGPRs +
 // one 32-bit offset per lane: no vector address arithmetic).
-// MEASURED (C5's shape, tools/bench_tt.py) and NOT the default of TableSpectrum.eval_bands: 3.10 ms
-// per 64 walkers against 2.70 for the two passes.  HBM traffic is what it should be (PMC: 1.5 GB
+// MEASURED (C5's shape, tools/bench_tt.py) and NOT the default of TableSpectrum.eval_bands: 2.86 ms
+// per 64 walkers against 2.67 for the two passes.  HBM traffic is what it should be (PMC: 1.5 GB
 // fetched per launch against 4.4 GB for k_transit_mfma alone; L2 hit rate 96 %), but the 8 slice
 // reads per walker, layer and sample now come from the XCD's L2 -- 32.8 GB per batch -- and L2 ->
 // L1 delivers ~12 TB/s of them: with the table loads taken out the kernel runs 1.4 ms, with the
@@ -705,13 +726,17 @@ template <int MT, int WPS, int TB, int kS, int PD>
 __global__ __launch_bounds__(TB, WPS) void k_table_transit_mfma(
     double *spectrum, const double *etable, const int32_t *tlo, const double *coef,
     const double *qblk, const double *radius, int nblk, double rstar, int itop, int ibottom,
-    double maxdepth, int nmol, int ntemp, int nlayers, int nwave, int nwalkers, int ncolblk)
+    double maxdepth, int nmol, int ntemp, int nlayers, int nwave, int nwalkers, int ncolblk,
+    int ginter)
 {
     extern __shared__ __align__(16) double s_q[];         // [nblk][64] | rad[16 MT] | coef[16 MT][2 kS] | off[16 MT]
     // XCD-aware order: see above
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-    const int cb = (slot / nwalkers) * 8 + xcd;
-    const int w = slot % nwalkers;
+    // (ginter column blocks of an XCD walked together, their walkers alternating -- PB_TT_GINTER;
+    // measured 2.86 / 2.88 / 2.89 / 3.05 / 3.25 ms for 1 / 2 / 3 / 4 / 8: the default is 1)
+    const int grp = slot / (ginter * nwalkers), within = slot % (ginter * nwalkers);
+    const int cb = (grp * ginter + within % ginter) * 8 + xcd;
+    const int w = within / ginter;
     if (cb >= ncolblk)
         return;                                           // (whole workgroup, before the barrier)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -720,9 +745,7 @@ __global__ __launch_bounds__(TB, WPS) void k_table_transit_mfma(
     double *s_coef = s_rad + 16 * MT;
     uint32_t *s_off = reinterpret_cast<uint32_t *>(s_coef + 16 * MT * 2 * kS);
     {
-        const double *q = qblk + (int64_t)w * nblk * 64;
-        for (int e = tid; e < nblk * 64; e += TB)
-            s_q[e] = q[e];
+        stage_qblocks<MT, TB>(s_q, qblk + (int64_t)w * nblk * 64, tid);
         for (int r = tid; r < 16 * MT; r += TB) {
             s_rad[r] = r < nimpact ? radius[(int64_t)w * nlayers + itop + r] : 0.0;
             // byte offset of (bracket's lower slice, layer) inside one species' block of the table
@@ -1425,7 +1448,7 @@ int pb_table_transit_batch(double *spectrum_d, const double *etable_d, const dou
     PB_REQUIRE(spectrum_d && etable_d && ttable_d && temps_d && density_d && raypath_d &&
                    radius_d && work_d,
                "pb_table_transit_batch: null pointer");
-    PB_REQUIRE((int64_t)nwalkers * pb::div_up(nwave, 128) * 8 + 8 * (int64_t)nwalkers < (1ll << 31),
+    PB_REQUIRE((int64_t)nwalkers * pb::div_up(nwave, 128) * 8 + 64 * (int64_t)nwalkers < (1ll << 31),
                "pb_table_transit_batch: too many workgroups");
     hipStream_t s = pb::as_stream(stream);
     const int nrow = nlayers - itop;
@@ -1452,15 +1475,17 @@ int pb_table_transit_batch(double *spectrum_d, const double *etable_d, const dou
                 reinterpret_cast<const void *>(k_table_transit_mfma<M, W, T, S, P>),               \
                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                            \
         const int ncb = pb::div_up(nwave, (T / 64) * 32);                                          \
-        const unsigned grid = (unsigned)(8 * (int64_t)pb::div_up(ncb, 8) * nwalkers);              \
+        const unsigned grid = (unsigned)(8 * (int64_t)pb::div_up(ncb, 8 * ginter) * ginter * nwalkers); \
         k_table_transit_mfma<M, W, T, S, P><<<grid, T, lds, s>>>(                                  \
             spectrum_d, etable_d, tlo, coef, qwork, radius_d, nblk, rstar, itop, ibottom, maxdepth, \
-            nmol, ntemp, nlayers, nwave, nwalkers, ncb);                                           \
+            nmol, ntemp, nlayers, nwave, nwalkers, ncb, ginter);                                   \
     } while (0)
+    const int ginter = getenv("PB_TT_GINTER") ? std::max(1, std::min(8, atoi(getenv("PB_TT_GINTER")))) : 1;
     // Geometry measured at C5's shape (80 layers, 4 species; tools/bench_tt.py, ms per 64 walkers,
-    // two passes over a stored ec 2.70): 384 threads, one K-step of loads in flight, 3 wavefronts
-    // per SIMD (148 registers, no spill) 3.10; 512 threads, two K-steps in flight, 2 per SIMD (176
-    // registers) 3.19; every 128-register form spills (4.2-4.3).
+    // two passes over a stored ec 2.70, before the one-round-trip Q staging): 384 threads, one
+    // K-step of loads in flight, 3 wavefronts per SIMD (148 registers, no spill) 3.10; 512 threads,
+    // two K-steps in flight, 2 per SIMD (176 registers) 3.19; every 128-register form spills
+    // (4.2-4.3).
     if (ncoef == 8) {
         switch (mt) {
         case 1: PB_TT(1, 2, 256, 8, 1); break;

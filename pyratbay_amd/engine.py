@@ -1141,7 +1141,7 @@ class TableSpectrum:
         """The transit batch through pb_table_transit_batch (interpolation, optical depth and
         transmission in one pass, ec never stored): opt-in (`one_pass = True` or
         PB_TABLE_TRANSIT=1) -- it saves the ec[walkers, L, W] buffer, 4.1 GB per 64 walkers at
-        C5's shape, but runs 3.10 ms per 64 walkers there against 2.70 for the two passes."""
+        C5's shape, but runs 2.86 ms per 64 walkers there against 2.67 for the two passes."""
         want = getattr(self, 'one_pass', None)
         if want is None:
             want = os.environ.get('PB_TABLE_TRANSIT', '0') == '1'

@@ -40,9 +40,10 @@ def main():
         return out.cpu().numpy()
 
     ref = run('two passes (stored ec)', {'PB_TABLE_TRANSIT': '0'})
-    got = run('one pass (ec never stored)', {'PB_TABLE_TRANSIT': '1'})
-    err = float(np.max(np.abs(got / ref - 1)))
-    assert err <= 1e-13, err
+    for gi in os.environ.get('GINTER', '2').split():
+        got = run(f'one pass (ec never stored) G={gi}', {'PB_TABLE_TRANSIT': '1', 'PB_TT_GINTER': gi})
+        err = float(np.max(np.abs(got / ref - 1)))
+        assert err <= 1e-13, err
     ref2 = run('two passes (stored ec), again', {'PB_TABLE_TRANSIT': '0'})
     assert np.array_equal(ref, ref2)
 
