@@ -511,9 +511,11 @@ def main():
             exchange = os.environ.get('PB_KMAX_EXCHANGE', '1') != '0'
             if streams > 1 and world > 1 and not replicas:
                 from pyratbay_amd.dist import ShardPipeline
+                # (no stage timers in the rank loop: four library calls per spectrum less for the
+                # host, which at 8 ranks has ~0.18 ms per spectrum to submit everything)
                 pipe = ShardPipeline(case, world, rank, depth=streams, kmax_exchange=exchange,
                                      voigt=shared.get('voigt'), lines=shared.get('lines'),
-                                     rt_path=rt_path)
+                                     rt_path=rt_path, timestamps=False)
                 model, gather = pipe.models[0], pipe.gathers[0]
                 res['streams'] = streams
             elif streams > 1:

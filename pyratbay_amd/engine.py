@@ -22,7 +22,17 @@ from . import _capi
 from ._capi import call, hptr, f64h, i32h
 
 
+_RAW_STREAM = getattr(torch._C, '_cuda_getCurrentRawStream', None)
+_RAW_DEVICE = getattr(torch._C, '_cuda_getDevice', None)
+
+
 def _stream():
+    """The current HIP stream of torch as the `void *stream` of the C ABI.  Every library call
+    asks for it; torch.cuda.current_stream() builds a Stream object through several Python layers
+    (~8 us, a fifth of the host's submission time of a rank-size spectrum), the raw getters are
+    one C call each."""
+    if _RAW_STREAM is not None and _RAW_DEVICE is not None:
+        return C.c_void_p(_RAW_STREAM(_RAW_DEVICE()))
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
@@ -516,14 +526,18 @@ def optical_depth_transit(ec, raypath_packed, itop, ibottom, maxdepth):
 
 
 def transit_spectrum(ec, raypath_packed, radius, rstar, itop, ibottom, maxdepth,
-                     deck_rsurf=None, deck_itop=None):
+                     deck_rsurf=None, deck_itop=None, out=None):
     """optic_depth.py:103-112 + radiative_transfer.py:57-71 in one call:
     ec[L,W] -> spectrum[W], depth[L,W], ideep[W].  With an opaque cloud deck pass its
-    radius and the index of the layer right below it (and ibottom = deck_itop + 1)."""
+    radius and the index of the layer right below it (and ibottom = deck_itop + 1).
+    out: a contiguous [W] tensor to receive the spectrum (a shard's slot of a gather buffer)."""
     nlayers, nwave = ec.shape
     depth = torch.empty_like(ec)
     ideep = torch.empty(nwave, dtype=torch.int32, device=ec.device)
-    spectrum = torch.empty(nwave, dtype=torch.float64, device=ec.device)
+    if out is not None:
+        assert out.shape == (nwave,) and out.dtype == torch.float64 and out.is_contiguous()
+    spectrum = out if out is not None else torch.empty(nwave, dtype=torch.float64,
+                                                       device=ec.device)
     call('pb_transit_spectrum_deck', _ptr(spectrum), _ptr(depth), _ptr(ideep), _ptr(ec),
          _ptr(raypath_packed), _ptr(radius), float(rstar), int(itop), int(ibottom),
          float(maxdepth), -1 if deck_rsurf is None else int(deck_itop),
@@ -798,6 +812,9 @@ class LBLSpectrum:
         self.ec = torch.empty((self.nlayers, 1, self.wcount), dtype=torch.float64,
                               device='cuda')
         self.depth = self.ideep = self.spectrum = None
+        # a [wcount] tensor the transit spectrum is written to instead of a fresh one (the shard's
+        # slot of a gather buffer: dist.SpectrumGather(uniform=True))
+        self.spectrum_out = None
         # set to a function(tensor) that all-reduces (MAX) over the ranks to switch the
         # extinction of a wavenumber shard to its two-phase form (dist.kmax_allreduce)
         self.kmax_exchange = None
@@ -920,7 +937,7 @@ class LBLSpectrum:
         if self.rt_path == 'transit':
             self.spectrum, self.depth, self.ideep = transit_spectrum(
                 self.ec.view(self.nlayers, self.wcount), self.raypath, self.radius,
-                self.rstar, self.itop, self.nlayers, self.maxdepth)
+                self.rstar, self.itop, self.nlayers, self.maxdepth, out=self.spectrum_out)
             if t is not None:
                 t.mark('spectrum')
             return self.spectrum
@@ -982,7 +999,8 @@ class SpectrumPipeline:
         self.count += 1
         model, stream = self.models[j], self.streams[j]
         caller = torch.cuda.current_stream()
-        stream.wait_stream(caller)                          # inputs made on the caller's stream
+        if not caller.query():                              # (an idle stream has nothing to wait for)
+            stream.wait_stream(caller)                      # inputs made on the caller's stream
         with torch.cuda.stream(stream):
             if isinstance(atmosphere, dict):
                 model.set_atmosphere(**atmosphere)

@@ -46,7 +46,7 @@ def _partial_band(spectrum, wn, bands, wbegin, wcount):
     return out
 
 
-def _worker(rank, world, port, nwave, tmp):
+def _worker(rank, world, port, nwave, tmp, uniform=False):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, 'tests'))
     os.environ['MASTER_ADDR'] = '127.0.0.1'
@@ -57,13 +57,18 @@ def _worker(rank, world, port, nwave, tmp):
     from oracle import oracle as orc
 
     c = cases.column_case(seed=21, nlayers=12, nwave=nwave)
-    gather = pbd.SpectrumGather(nwave, world, rank, 'cpu')
+    gather = pbd.SpectrumGather(nwave, world, rank, 'cpu', uniform=uniform)
     a, n = gather.wbegin, gather.wcount
     # this rank's columns only, computed on the global grid
     depth, ideep = orc.optical_depth_transit(c['ec'][:, a:a + n].copy(), c['radius'], 0, 12,
                                              10.0)
     local = orc.transmission(depth, c['radius'], c['rstar'], ideep, 0)
-    full = gather(torch.from_numpy(local)).numpy().copy()
+    if uniform and gather.uniform:
+        # the way dist.ShardPipeline uses it: the shard is written straight into the slot
+        gather.slot.copy_(torch.from_numpy(local))
+        full = gather(gather.slot).numpy().copy()
+    else:
+        full = gather(torch.from_numpy(local)).numpy().copy()
     bands = _bands(c['wn'])
     partial = torch.from_numpy(_partial_band(full, c['wn'], bands, a, n))
     heights = torch.tensor([b[2] for b in bands], dtype=torch.float64)
@@ -91,6 +96,31 @@ def test_two_rank_shards_reassemble(tmp_path, orc, nwave, world):
         assert np.array_equal(got['full'], want)          # bit-exact re-assembly
         np.testing.assert_allclose(got['bandflux'], want_flux, rtol=1e-13)
         assert got['bounds'][0] == 0 and got['bounds'][-1] == nwave
+
+
+@pytest.mark.parametrize('nwave,world', [(1001, 2), (1003, 3), (1001, 8), (1000, 8), (10, 8)])
+def test_uniform_shards_need_no_unpacking(tmp_path, orc, nwave, world):
+    """SpectrumGather(uniform=True): shards of one size (the last one shorter), every rank writes
+    its shard into its slot of the send buffer and the receive buffer of ONE all-gather is the
+    spectrum -- no copy in, no unpacking.  (10 samples on 8 ranks: a rank would own nothing, the
+    object falls back to the balanced shards.)"""
+    import cases
+    from pyratbay_amd.dist import uniform_bounds
+    mp.spawn(_worker, args=(world, _free_port(), nwave, str(tmp_path), True), nprocs=world,
+             join=True)
+    c = cases.column_case(seed=21, nlayers=12, nwave=nwave)
+    depth, ideep = orc.optical_depth_transit(c['ec'], c['radius'], 0, 12, 10.0)
+    want = orc.transmission(depth, c['radius'], c['rstar'], ideep, 0)
+    ub = uniform_bounds(nwave, world)
+    assert (ub is None) == (nwave == 10)
+    for rank in range(world):
+        got = np.load(tmp_path / f'rank{rank}.npz')
+        assert np.array_equal(got['full'], want)
+        assert got['bounds'][0] == 0 and got['bounds'][-1] == nwave
+        if ub is not None:
+            assert np.array_equal(got['bounds'], ub)
+            sizes = np.diff(ub)
+            assert np.all(sizes[:-1] == sizes[0]) and 0 < sizes[-1] <= sizes[0]
 
 
 def test_shard_bounds_properties():

@@ -1,0 +1,87 @@
+#!/usr/bin/env python3
+"""What ONE rank of an N-GPU wavenumber-sharded run costs per spectrum on a one-GPU box, the
+collectives INCLUDED as far as one GPU can show them: a one-rank RCCL process group, the
+all-reduce(MAX) of the maxima and the closing all-gather issued exactly as dist.ShardPipeline issues
+them (same tensors, same streams; the all-gather of this rank's padded shard into a buffer of its
+own size).  What it measures beyond tools/bench_wshard.py: the host's submission cost of a spectrum
+(library calls + torch ops + two collectives) against the 0.18 ms of GPU work of a 1/8 shard.
+usage: python tools/bench_rank_rccl.py <world> [workload] [streams]"""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+os.environ.setdefault('MASTER_PORT', '29577')
+os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+import bench
+from pyratbay_amd import dist as pbdist
+from pyratbay_amd import engine
+
+
+class OneRankGather(pbdist.SpectrumGather):
+    """SpectrumGather of rank r of `world`, the all-gather on a one-rank group (own block only)."""
+
+    def __call__(self, local):
+        if local.data_ptr() != self.send.data_ptr():
+            self.send[:self.wcount].copy_(local)
+        pbdist.all_gather_flat(self.recv[:self.pad], self.send)
+        if self.uniform:
+            return self.full
+        blocks = self.recv.view(self.world, self.pad)
+        base, rem = divmod(self.nwave, self.world)
+        if rem:
+            self.full[:rem * (base + 1)].view(rem, base + 1).copy_(blocks[:rem, :base + 1])
+        if base:
+            self.full[rem * (base + 1):].view(self.world - rem, base).copy_(blocks[rem:, :base])
+        return self.full
+
+
+def main():
+    world = int(sys.argv[1])
+    name = sys.argv[2] if len(sys.argv) > 2 else 'c2'
+    streams = int(sys.argv[3]) if len(sys.argv) > 3 else 3
+    steps = int(os.environ.get('PB_WSHARD_STEPS', '200'))
+    torch.cuda.set_device(0)
+    dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))
+    case = bench.make_case(bench.WORKLOADS[name])
+    nwave = case['grid']['nwave']
+    r = world // 2
+    pipe = pbdist.ShardPipeline(case, world, r, depth=streams, kmax_exchange=True,
+                                timestamps=os.environ.get('PB_TIMESTAMPS', '0') == '1')
+    pipe.gathers = [OneRankGather(nwave, world, r, 'cuda', uniform=True) for _ in range(streams)]
+    for m, g in zip(pipe.models, pipe.gathers):
+        m.spectrum_out = g.slot if g.uniform else None
+    for label, coll in (('collectives through RCCL (one rank)', True), ('no collectives', False)):
+        for i, m in enumerate(pipe.models):
+            m.kmax_exchange = pbdist.kmax_allreduce() if coll else (lambda t: None)
+        if not coll:
+            for m in pipe.models:
+                m.spectrum_out = None
+            pipe.gathers = [pbdist.SpectrumGather(nwave, 1, 0, 'cuda') for _ in range(streams)]
+            for g, m in zip(pipe.gathers, pipe.models):   # (world 1: returns the local shard)
+                g.bounds = np.array([0, m.wcount])
+        for _ in range(4 * streams):
+            pipe.submit()
+        pipe.flush()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            pipe.submit()
+        t_submit = time.perf_counter() - t0
+        pipe.flush()
+        torch.cuda.synchronize()
+        t_all = time.perf_counter() - t0
+        print(f'{name} rank {r}/{world}, {streams} in flight, {label}: '
+              f'{1e3 * t_all / steps:.3f} ms/spectrum, host submission {1e3 * t_submit / steps:.3f} '
+              f'ms/spectrum', flush=True)
+    dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()
