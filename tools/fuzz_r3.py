@@ -168,6 +168,43 @@ def transit_case(eng, rng, seed):
     np.testing.assert_allclose(got, vec, rtol=1e-12)
 
 
+def table_transit_case(eng, rng, seed):
+    """pb_table_transit_batch (interpolation + optical depth + transmission in one pass) against
+    pb_interp_ec_batch + pb_transit_spectrum_batch on random shapes: 1-8 species, 2-128 layers,
+    ragged grids, itop, temperatures on nodes and at the table's ends (1e-12)."""
+    nmol = int(rng.integers(1, 9))
+    ntemp = int(rng.integers(2, 9))
+    L = int(rng.integers(2, 129))
+    W = int(rng.integers(2, 600))
+    nw = int(rng.integers(1, 7))
+    itop = int(rng.integers(0, max(1, L // 3)))
+    if L - itop < 2:
+        itop = 0
+    if not eng.table_transit_supported(nmol, ntemp, L, itop, L, W):
+        return
+    ttable = np.sort(rng.uniform(300.0, 3000.0, ntemp))
+    ttable[0], ttable[-1] = 300.0, 3000.0
+    press = np.logspace(-6, 2, L)
+    colscale = 10.0**rng.uniform(-33.5, -27.0, W)
+    etable = 10.0**rng.uniform(-0.3, 0.3, (nmol, ntemp, L, W)) * colscale
+    temps = rng.uniform(300.0, 3000.0, (nw, L))
+    temps[0] = ttable[rng.integers(0, ntemp, L)]
+    if nw > 1:
+        temps[1] = rng.choice([300.0, 3000.0])
+    dens = press[None, :, None]**0.9 * 10.0**rng.uniform(17, 18, (nw, L, nmol))
+    radius = np.array([np.sort(np.linspace(8.0e9, 7.0e9, L) * (1 + 0.01 * rng.uniform(-1, 1)) +
+                               rng.uniform(-1e5, 1e5, L))[::-1] for _ in range(nw)])
+    maxdepth = float(rng.choice([10.0, 1.0, np.inf]))
+    et, tt = eng.dev(etable), eng.dev(ttable)
+    td, dd, rd = eng.dev(temps), eng.dev(dens), eng.dev(radius)
+    path = eng.transit_path_device(rd, itop)
+    one = host(eng.table_transit_batch(et, tt, td, dd, path, rd, 8.8e10, itop, L, maxdepth))
+    ec = eng.interp_ec_batch(et, tt, td, dd)
+    two = host(eng.transit_spectrum_batch(ec, path, rd, 8.8e10, itop, L, maxdepth))
+    assert np.all(np.isfinite(one)), 'one-pass table transit: non-finite spectrum'
+    np.testing.assert_allclose(one, two, rtol=1e-12)
+
+
 def main():
     count = int(sys.argv[1]) if len(sys.argv) > 1 else 100
     seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 31000
@@ -186,6 +223,7 @@ def main():
             wm += info['wm']
             for j in range(3):
                 transit_case(engine, np.random.default_rng(seed * 7 + j), seed * 7 + j)
+                table_transit_case(engine, np.random.default_rng(seed * 11 + j), seed * 11 + j)
         except Exception:                                  # noqa: BLE001
             bad.append(seed)
             print('FAIL seed', seed)
@@ -193,7 +231,7 @@ def main():
         if i % 50 == 49:
             print(f'{i + 1} seeds, {len(bad)} failures', flush=True)
     print(f'{count} seeds: {chunks} chunked, {deep} with a per-layer split, {wm} window-map shards, '
-          f'{3 * count} transit batches')
+          f'{3 * count} transit batches, {3 * count} one-pass table batches')
     print('failures:', bad)
     return 1 if bad else 0
 
