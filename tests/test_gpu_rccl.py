@@ -16,8 +16,15 @@ pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
+def _free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
+
+
 def test_collectives_through_rccl_one_rank():
-    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT='29591', RANK='0',
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT=str(_free_port()), RANK='0',
                WORLD_SIZE='1', LOCAL_RANK='0',
                HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
     run = subprocess.run([sys.executable, os.path.join(HERE, 'rccl_one_rank.py')], env=env,
