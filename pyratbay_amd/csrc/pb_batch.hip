@@ -552,49 +552,58 @@ typedef double v4d __attribute__((ext_vector_type(4)));
 typedef double d2u __attribute__((ext_vector_type(2), aligned(8)));
 
 // Epilogue of the matrix-core transit kernels on the accumulator layout: lane (kq = l >> 4,
-// n = l & 15) holds the rows 16m + 4j + kq of its two columns (col0, col0 + 1).
+// n = l & 15) holds the rows 16m + 4j + kq of one column per 16-column tile.  One tile:
 template <int MT>
-__device__ __forceinline__ void mfma_transit_epilogue(
-    const v4d (&C)[2][MT], const double *s_rad, double *spectrum_w, int col0, const bool (&ok)[2],
-    int lane, int nimpact, double maxdepth, double rstar)
+__device__ __forceinline__ void mfma_transit_epilogue_tile(
+    const v4d (&C)[MT], const double *s_rad, double *dst, bool ok, int lane, int nimpact,
+    double maxdepth, double rstar)
 {
     const int kq = lane >> 4;
     const double rtop = s_rad[0];
     const double *srad = s_rad + kq;
     const int src_lane = (lane + 48) & 63;                // the lane one row above (16 below)
+    int first = INT_MAX;
 #pragma unroll
-    for (int t = 0; t < 2; t++) {
-        int first = INT_MAX;
+    for (int m = 0; m < MT; m++)
 #pragma unroll
-        for (int m = 0; m < MT; m++)
+        for (int j = 0; j < 4; j++) {
+            const int r = 16 * m + 4 * j + kq;
+            if (r < nimpact && C[m][j] > maxdepth)
+                first = min(first, r);
+        }
+    first = min(first, __shfl_xor(first, 16));
+    first = min(first, __shfl_xor(first, 32));
+    double acc = 0.0, carry = 0.0;                        // carry: row 16m + 4j - 1 seen from q = 0
 #pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const int r = 16 * m + 4 * j + kq;
-                if (r < nimpact && C[t][m][j] > maxdepth)
-                    first = min(first, r);
-            }
-        first = min(first, __shfl_xor(first, 16));
-        first = min(first, __shfl_xor(first, 32));
-        double acc = 0.0, carry = 0.0;                    // carry: row 16m + 4j - 1 seen from q = 0
+    for (int m = 0; m < MT; m++)
 #pragma unroll
-        for (int m = 0; m < MT; m++)
+        for (int j = 0; j < 4; j++) {
+            const int r = 16 * m + 4 * j + kq;
+            const bool in = r < nimpact && r <= first;
+            const double rr = srad[16 * m + 4 * j];
+            const double f = in ? pb::exp_s(-C[m][j]) * rr : 0.0;
+            const double up = __shfl(f, src_lane);        // q > 0: row r - 1; q = 0: row r + 3
+            const double fprev = kq > 0 ? up : carry;
+            carry = up;
+            if (in && r >= 1)
+                acc += (rr - srad[16 * m + 4 * j - 1]) * (fprev + f);
+        }
+    acc += __shfl_xor(acc, 16);
+    acc += __shfl_xor(acc, 32);
+    if (kq == 0 && ok)
+        *dst = (rtop * rtop + 2 * (acc * 0.5)) / (rstar * rstar);
+}
+
+// the two column tiles of a wavefront (columns col0 and col0 + 1 of one walker)
+template <int MT>
+__device__ __forceinline__ void mfma_transit_epilogue(
+    const v4d (&C)[2][MT], const double *s_rad, double *spectrum_w, int col0, const bool (&ok)[2],
+    int lane, int nimpact, double maxdepth, double rstar)
+{
 #pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const int r = 16 * m + 4 * j + kq;
-                const bool in = r < nimpact && r <= first;
-                const double rr = srad[16 * m + 4 * j];
-                const double f = in ? pb::exp_s(-C[t][m][j]) * rr : 0.0;
-                const double up = __shfl(f, src_lane);    // q > 0: row r - 1; q = 0: row r + 3
-                const double fprev = kq > 0 ? up : carry;
-                carry = up;
-                if (in && r >= 1)
-                    acc += (rr - srad[16 * m + 4 * j - 1]) * (fprev + f);
-            }
-        acc += __shfl_xor(acc, 16);
-        acc += __shfl_xor(acc, 32);
-        if (kq == 0 && ok[t])
-            spectrum_w[col0 + t] = (rtop * rtop + 2 * (acc * 0.5)) / (rstar * rstar);
-    }
+    for (int t = 0; t < 2; t++)
+        mfma_transit_epilogue_tile<MT>(C[t], s_rad, spectrum_w + col0 + t, ok[t], lane, nimpact,
+                                       maxdepth, rstar);
 }
 
 // A walker's Q blocks (qblocks(MT) x 64 doubles: 30 KB at 80 layers) -> LDS.  The count is a
@@ -698,6 +707,13 @@ __global__ __launch_bounds__(TB, WPS) void k_transit_mfma(
                               maxdepth, rstar);
 }
 
+// a wave-uniform flag written by an earlier kernel, by a scalar load
+__device__ __forceinline__ int uniform_flag(const int32_t *p)
+{
+    typedef const int32_t __attribute__((address_space(4))) *cptr;
+    return *((cptr)(unsigned long long)p);
+}
+
 // ---------------------------------------------------------------------------
 // Interpolation + optical depth + transmission of the retrieval batch in ONE pass: the B operand of
 // k_transit_mfma -- 4 layers x 16 columns of a walker's ec -- is not loaded but FORMED from the
@@ -713,8 +729,8 @@ __global__ __launch_bounds__(TB, WPS) void k_transit_mfma(
 // (k_interp_weights) and table offsets.  PD = K-steps whose table loads are in flight ahead of the
 // one being multiplied (2 x kS 16-byte loads per lane and K-step, wave-uniform bases in SGPRs +
 // one 32-bit offset per lane: no vector address arithmetic).
-// MEASURED (C5's shape, tools/bench_tt.py) and NOT the default of TableSpectrum.eval_bands: 2.86 ms
-// per 64 walkers against 2.67 for the two passes.  HBM traffic is what it should be (PMC: 1.5 GB
+// MEASURED (C5's shape, tools/bench_tt.py): 2.86 ms per 64 walkers against 2.67 for the two passes
+// (the two-walker form below: 2.54).  HBM traffic is what it should be (PMC: 1.5 GB
 // fetched per launch against 4.4 GB for k_transit_mfma alone; L2 hit rate 96 %), but the 8 slice
 // reads per walker, layer and sample now come from the XCD's L2 -- 32.8 GB per batch -- and L2 ->
 // L1 delivers ~12 TB/s of them: with the table loads taken out the kernel runs 1.4 ms, with the
@@ -727,9 +743,11 @@ __global__ __launch_bounds__(TB, WPS) void k_table_transit_mfma(
     double *spectrum, const double *etable, const int32_t *tlo, const double *coef,
     const double *qblk, const double *radius, int nblk, double rstar, int itop, int ibottom,
     double maxdepth, int nmol, int ntemp, int nlayers, int nwave, int nwalkers, int ncolblk,
-    int ginter)
+    int ginter, const int32_t *skip_if)
 {
     extern __shared__ __align__(16) double s_q[];         // [nblk][64] | rad[16 MT] | coef[16 MT][2 kS] | off[16 MT]
+    if (skip_if && uniform_flag(skip_if))
+        return;                                           // the two-walker kernel runs this batch
     // XCD-aware order: see above
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
     // (ginter column blocks of an XCD walked together, their walkers alternating -- PB_TT_GINTER;
@@ -846,6 +864,261 @@ __global__ __launch_bounds__(TB, WPS) void k_table_transit_mfma(
     }
     mfma_transit_epilogue<MT>(C, s_rad, spectrum + (int64_t)w * nwave, col0, ok, lane, nimpact,
                               maxdepth, rstar);
+}
+
+// ---------------------------------------------------------------------------
+// The one-pass kernel with TWO walkers per wavefront.  What binds k_table_transit_mfma is the
+// delivery of table slices from L2 (8 loads per walker, layer and sample); two walkers that
+// bracket the same table temperatures at a layer need the SAME eight values there -- only their
+// coefficients differ.  A wavefront therefore owns 16 columns (one tile) of a PAIR of walkers: one
+// set of slice loads per K-step feeds both operands (two sets where the pair's brackets differ at
+// one of the step's four layers: a wave-uniform branch), the accumulators are the pair's 2 x MT
+// row tiles, the A operands come from the two walkers' Q blocks.  The pairs are neighbours in an
+// order of the walkers by their table brackets (k_walker_order), so that pairs share almost all of
+// them whenever the walkers of a batch resemble one another (the walkers of a sampler do).
+// LDS per workgroup: 2 x (Q blocks + radii + coefficients + offsets) = 73 KB at 80 layers.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void k_walker_order(int32_t *perm, int32_t *use_pair,
+                                                      const int32_t *tlo, const double *temps,
+                                                      int nlayers, int nwalkers, int itop,
+                                                      int nimpact, int force)
+{
+    // rank sort of up to 1024 walkers by (sum of their brackets, mid-layer temperature, index),
+    // then the share of K-steps (groups of four layers) in which the pairs of neighbours bracket
+    // different table temperatures: the two-walker kernel pays for each of those with an exposed
+    // load latency, beyond a fifth of the steps the one-walker kernel is the faster one
+    __shared__ long long s_key[1024];
+    __shared__ double s_t[1024];
+    __shared__ int s_perm[1024];
+    __shared__ int s_diff;
+    const int w = threadIdx.x;
+    if (w == 0)
+        s_diff = 0;
+    if (w < nwalkers) {
+        long long k = 0;
+        for (int l = 0; l < nlayers; l++)
+            k += tlo[(int64_t)w * nlayers + l];
+        s_key[w] = k;
+        s_t[w] = temps[(int64_t)w * nlayers + nlayers / 2];
+    }
+    __syncthreads();
+    if (w < nwalkers) {
+        const long long k = s_key[w];
+        const double t = s_t[w];
+        int rank = 0;
+        for (int v = 0; v < nwalkers; v++) {
+            const long long kv = s_key[v];
+            const double tv = s_t[v];
+            rank += (kv < k) || (kv == k && (tv < t || (tv == t && v < w)));
+        }
+        perm[rank] = w;
+        s_perm[rank] = w;
+    }
+    __syncthreads();
+    const int npair = nwalkers >> 1;
+    const int nsteps = (nimpact + 3) / 4;
+    if (w < npair) {
+        const int32_t *ta = tlo + (int64_t)s_perm[2 * w] * nlayers + itop;
+        const int32_t *tb = tlo + (int64_t)s_perm[2 * w + 1] * nlayers + itop;
+        int diff = 0;
+        for (int ks = 0; ks < nsteps; ks++) {
+            bool same = true;
+            for (int q = 0; q < 4; q++) {
+                const int r = min(4 * ks + q, nimpact - 1);
+                same = same && ta[r] == tb[r];
+            }
+            diff += same ? 0 : 1;
+        }
+        if (diff)
+            atomicAdd(&s_diff, diff);
+    }
+    __syncthreads();
+    if (w == 0)
+        *use_pair = force || (npair > 0 && 5 * (int64_t)s_diff <= (int64_t)npair * nsteps);
+}
+
+template <int MT, int WPS, int TB, int kS, int PD>
+__global__ __launch_bounds__(TB, WPS) void k_table_transit_pair(
+    double *spectrum, const double *etable, const int32_t *tlo, const double *coef,
+    const double *qblk, const double *radius, const int32_t *perm, const int32_t *use_pair,
+    int nblk, double rstar, int itop, int ibottom, double maxdepth, int nmol, int ntemp,
+    int nlayers, int nwave, int nwalkers, int ncolblk)
+{
+    // per walker x: Q[nblk][64] | rad[16 MT] | coef[16 MT][2 kS] ; then off[2][16 MT] | same[4 MT]
+    extern __shared__ __align__(16) double s_q[];
+    if (!uniform_flag(use_pair))
+        return;                                           // the one-walker kernel runs this batch
+    constexpr int kPerWalker = qblocks(MT) * 64 + 16 * MT + 16 * MT * 2 * kS;
+    const int npair = (nwalkers + 1) >> 1;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int cb = (slot / npair) * 8 + xcd;
+    const int pi = slot % npair;
+    if (cb >= ncolblk)
+        return;                                           // (whole workgroup, before the barrier)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nimpact = min(ibottom, nlayers) - itop;
+    const bool haveb = 2 * pi + 1 < nwalkers;             // an odd batch: the last walker twice
+    const int wx[2] = {perm[2 * pi], perm[haveb ? 2 * pi + 1 : 2 * pi]};
+    double *s_rad[2], *s_coef[2];
+    const double *s_qx[2];
+    uint32_t *s_off = reinterpret_cast<uint32_t *>(s_q + 2 * kPerWalker);   // [2][16 MT]
+    int32_t *s_same = reinterpret_cast<int32_t *>(s_off + 2 * 16 * MT);     // [4 MT]
+#pragma unroll
+    for (int x = 0; x < 2; x++) {
+        double *base = s_q + x * kPerWalker;
+        s_qx[x] = base;
+        s_rad[x] = base + qblocks(MT) * 64;
+        s_coef[x] = s_rad[x] + 16 * MT;
+        const int w = wx[x];
+        stage_qblocks<MT, TB>(base, qblk + (int64_t)w * nblk * 64, tid);
+        for (int r = tid; r < 16 * MT; r += TB) {
+            s_rad[x][r] = r < nimpact ? radius[(int64_t)w * nlayers + itop + r] : 0.0;
+            const int rr = min(r, nimpact - 1);
+            const int64_t t = tlo[(int64_t)w * nlayers + itop + rr];
+            s_off[x * 16 * MT + r] = (uint32_t)(((t * nlayers + itop + rr) * (int64_t)nwave) * 8);
+        }
+        for (int e = tid; e < 16 * MT * 2 * kS; e += TB) {
+            const int r = min(e / (2 * kS), nimpact - 1);
+            s_coef[x][e] = coef[((int64_t)w * nlayers + itop + r) * 2 * kS + e % (2 * kS)];
+        }
+    }
+    for (int ks = tid; ks < 4 * MT; ks += TB) {
+        bool same = true;
+        for (int q = 0; q < 4; q++) {
+            const int rr = min(4 * ks + q, nimpact - 1);
+            same = same && tlo[(int64_t)wx[0] * nlayers + itop + rr] ==
+                               tlo[(int64_t)wx[1] * nlayers + itop + rr];
+        }
+        s_same[ks] = same ? 1 : 0;
+    }
+    __syncthreads();
+    const int c0 = (cb * (TB / 64) + wave) * 16;
+    if (c0 >= nwave)
+        return;                                           // (after the only barrier)
+    const int kq = lane >> 4, n = lane & 15;
+    const bool ok = c0 + n < nwave;
+    const int col = min(c0 + n, nwave - 1);
+    const int64_t slice = (int64_t)nlayers * nwave;
+    const char *base_lo[kS], *base_hi[kS];
+#pragma unroll
+    for (int sp = 0; sp < kS; sp++) {
+        base_lo[sp] = reinterpret_cast<const char *>(etable + (int64_t)min(sp, nmol - 1) * ntemp * slice);
+        base_hi[sp] = base_lo[sp] + slice * 8;
+    }
+    const uint32_t lane_off = (uint32_t)col * 8u;
+    v4d C[2][MT];
+#pragma unroll
+    for (int x = 0; x < 2; x++)
+#pragma unroll
+        for (int m = 0; m < MT; m++)
+            C[x][m] = v4d{0.0, 0.0, 0.0, 0.0};
+    const int rot = pi & 3;                               // (see k_table_transit_mfma)
+    auto kstep = [&](int ks) { return (ks & ~3) | ((ks + rot) & 3); };
+    auto issue = [&](int x, int ks, double (&r)[2 * kS]) {
+        const uint32_t off = s_off[x * 16 * MT + 4 * ks + kq] + lane_off;
+#pragma unroll
+        for (int sp = 0; sp < kS; sp++) {
+            r[sp] = *reinterpret_cast<const double *>(base_lo[sp] + off);
+            r[kS + sp] = *reinterpret_cast<const double *>(base_hi[sp] + off);
+        }
+    };
+    auto combine = [&](int x, int ks, const double (&r)[2 * kS]) {
+        const double *co = s_coef[x] + (4 * ks + kq) * 2 * kS;
+        double a = 0.0;
+#pragma unroll
+        for (int sp = 0; sp < kS; sp++) {
+            a = fma(r[sp], co[sp], a);
+            a = fma(r[kS + sp], co[kS + sp], a);
+        }
+        return a;
+    };
+    double rawa[PD][2 * kS];
+    double bcur[2], bnxt[2] = {0.0, 0.0};
+    static_assert(kS == 4, "the second walker's own loads are written out for four species");
+    auto fetch = [&](int ks, double (&ra)[2 * kS]) { issue(0, ks, ra); };
+    // Where the pair's brackets differ at one of the K-step's four layers (wave-uniform flag; rare
+    // between neighbours in bracket order) the second walker's operand needs slice values of its
+    // own.  As a branch in the source that splits the unrolled loop into ~40 basic blocks and the
+    // register allocator gives up (218-256 registers, spills); as loads in an asm statement that
+    // the compiler cannot see complete, any copy it makes of their destination registers reads
+    // stale data.  So the whole exception lives in ONE asm statement: skip if the brackets agree,
+    // else eight loads, the wait for them and the eight fused multiply-adds of combine() -- in the
+    // same order -- on scratch registers that are dead at its end.  Its latency is exposed; a
+    // batch whose pairs disagree often runs the one-walker kernel instead (k_walker_order decides).
+    auto form = [&](int ks, const double (&ra)[2 * kS], double (&b)[2]) {
+        b[0] = combine(0, ks, ra);
+        double bb = combine(1, ks, ra);
+        const double *co = s_coef[1] + (4 * ks + kq) * 2 * kS;
+        const int same = __builtin_amdgcn_readfirstlane(s_same[ks]);
+        const uint32_t offb = s_off[16 * MT + 4 * ks + kq] + lane_off;
+        double t0, t1, t2, t3, t4, t5, t6, t7;
+        asm volatile("s_cmp_lg_u32 %[same], 0\n\t"
+                     "s_cbranch_scc1 .Lpb_tt_skip%=\n\t"
+                     "global_load_dwordx2 %[t0], %[off], %[l0]\n\t"
+                     "global_load_dwordx2 %[t4], %[off], %[h0]\n\t"
+                     "global_load_dwordx2 %[t1], %[off], %[l1]\n\t"
+                     "global_load_dwordx2 %[t5], %[off], %[h1]\n\t"
+                     "global_load_dwordx2 %[t2], %[off], %[l2]\n\t"
+                     "global_load_dwordx2 %[t6], %[off], %[h2]\n\t"
+                     "global_load_dwordx2 %[t3], %[off], %[l3]\n\t"
+                     "global_load_dwordx2 %[t7], %[off], %[h3]\n\t"
+                     "s_waitcnt vmcnt(0)\n\t"
+                     "v_fma_f64 %[bb], %[t0], %[c0], 0\n\t"
+                     "v_fma_f64 %[bb], %[t4], %[c4], %[bb]\n\t"
+                     "v_fma_f64 %[bb], %[t1], %[c1], %[bb]\n\t"
+                     "v_fma_f64 %[bb], %[t5], %[c5], %[bb]\n\t"
+                     "v_fma_f64 %[bb], %[t2], %[c2], %[bb]\n\t"
+                     "v_fma_f64 %[bb], %[t6], %[c6], %[bb]\n\t"
+                     "v_fma_f64 %[bb], %[t3], %[c3], %[bb]\n\t"
+                     "v_fma_f64 %[bb], %[t7], %[c7], %[bb]\n\t"
+                     ".Lpb_tt_skip%=:"
+                     : [bb] "+v"(bb), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2),
+                       [t3] "=&v"(t3), [t4] "=&v"(t4), [t5] "=&v"(t5), [t6] "=&v"(t6),
+                       [t7] "=&v"(t7)
+                     : [same] "s"(same), [off] "v"(offb), [l0] "s"(base_lo[0]),
+                       [l1] "s"(base_lo[1]), [l2] "s"(base_lo[2]), [l3] "s"(base_lo[3]),
+                       [h0] "s"(base_hi[0]), [h1] "s"(base_hi[1]), [h2] "s"(base_hi[2]),
+                       [h3] "s"(base_hi[3]), [c0] "v"(co[0]), [c1] "v"(co[1]), [c2] "v"(co[2]),
+                       [c3] "v"(co[3]), [c4] "v"(co[4]), [c5] "v"(co[5]), [c6] "v"(co[6]),
+                       [c7] "v"(co[7])
+                     : "memory", "scc");
+        b[1] = bb;
+    };
+#pragma unroll
+    for (int d = 0; d < PD; d++)
+        if (d < 4 * MT)
+            fetch(kstep(d), rawa[d]);
+    form(kstep(0), rawa[0], bcur);
+    if (PD < 4 * MT)
+        fetch(kstep(PD), rawa[0]);
+    const double *sqa = s_qx[0] + lane, *sqb = s_qx[1] + lane;
+#pragma unroll
+    for (int ks = 0; ks < 4 * MT; ks++) {
+        if (ks + 1 < 4 * MT) {
+            // (the scheduling barriers keep a step's sums, loads and products apart: left to
+            // itself the scheduler spreads them over the unrolled loop and needs 192-256 registers)
+            form(kstep(ks + 1), rawa[(ks + 1) % PD], bnxt);
+            __builtin_amdgcn_sched_barrier(0);
+            if (ks + 1 + PD < 4 * MT)
+                fetch(kstep(ks + 1 + PD), rawa[(ks + 1) % PD]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        const int kse = kstep(ks);
+#pragma unroll
+        for (int m = ks / 4; m < MT; m++) {
+            const double aa = sqa[(qblocks(m) + kse) * 64];
+            const double ab = sqb[(qblocks(m) + kse) * 64];
+            C[0][m] = __builtin_amdgcn_mfma_f64_16x16x4f64(aa, bcur[0], C[0][m], 0, 0, 0);
+            C[1][m] = __builtin_amdgcn_mfma_f64_16x16x4f64(ab, bcur[1], C[1][m], 0, 0, 0);
+        }
+        bcur[0] = bnxt[0];
+        bcur[1] = bnxt[1];
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    mfma_transit_epilogue_tile<MT>(C[0], s_rad[0], spectrum + (int64_t)wx[0] * nwave + c0 + n, ok,
+                                   lane, nimpact, maxdepth, rstar);
+    mfma_transit_epilogue_tile<MT>(C[1], s_rad[1], spectrum + (int64_t)wx[1] * nwave + c0 + n,
+                                   ok && haveb, lane, nimpact, maxdepth, rstar);
 }
 
 // ---------------------------------------------------------------------------
@@ -1425,9 +1698,10 @@ int64_t pb_table_transit_work_doubles(int nmol, int nlayers, int itop, int ibott
     const int nimpact = std::min(ibottom, nlayers) - itop;
     const int ncoef = nmol <= 4 ? 4 : 8;
     const int64_t n = (int64_t)std::max(nwalkers, 0) * nlayers;
-    // Q blocks | coef[n][2 ncoef] | tlo[n] (ints, rounded up to doubles)
+    // Q blocks | coef[n][2 ncoef] | tlo[n] (ints, rounded up to doubles) | walker order (ints) |
+    // the flag that selects the two-walker kernel
     return (int64_t)qblocks(pb::div_up(nimpact, 16)) * 64 * std::max(nwalkers, 0) + n * 2 * ncoef +
-           (n + 1) / 2 + 8;
+           (n + 1) / 2 + (std::max(nwalkers, 0) + 1) / 2 + 2 + 8;
 }
 
 int pb_table_transit_batch(double *spectrum_d, const double *etable_d, const double *ttable_d,
@@ -1467,6 +1741,57 @@ int pb_table_transit_batch(double *spectrum_d, const double *etable_d, const dou
     dim3 qgrid((unsigned)std::min(16, pb::div_up((int64_t)nblk * 64, kBlock)), nwalkers);
     k_path_qblocks<<<qgrid, kBlock, 0, s>>>(qwork, raypath_d, npath, nblk, nimpact);
     PB_LAUNCH_CHECK();
+    // two walkers per wavefront (default from 2 walkers on, up to 1024 of them and 96 layers: the
+    // pair's Q blocks must fit the LDS twice per CU); PB_TT_PAIR=0: one walker per wavefront, 2: two
+    // whatever the pairs' brackets (the default lets k_walker_order decide)
+    const char *pe = getenv("PB_TT_PAIR");
+    const bool pair = !(pe && atoi(pe) == 0) && nwalkers >= 2 && nwalkers <= 1024 && mt <= 5 &&
+                      ncoef == 4;
+    const int32_t *skip_if = nullptr;
+    if (pair) {
+        int32_t *perm = tlo + ((n + 1) / 2) * 2;
+        int32_t *use_pair = perm + ((nwalkers + 1) / 2) * 2;
+        skip_if = use_pair;
+        k_walker_order<<<1, 1024, 0, s>>>(perm, use_pair, tlo, temps_d, nlayers, nwalkers, itop,
+                                          nimpact, pe && atoi(pe) == 2);
+        PB_LAUNCH_CHECK();
+        const size_t plds = 2 * ((size_t)nblk * 64 + (size_t)mt * 16 * (1 + 2 * ncoef)) * 8 +
+                            2 * (size_t)mt * 16 * 4 + (size_t)mt * 4 * 4;
+        const int npair = (nwalkers + 1) / 2;
+#define PB_TP(M, W, T, P)                                                                          \
+    do {                                                                                           \
+        if (plds > 64 * 1024)                                                                      \
+            PB_HIP(hipFuncSetAttribute(                                                            \
+                reinterpret_cast<const void *>(k_table_transit_pair<M, W, T, 4, P>),               \
+                hipFuncAttributeMaxDynamicSharedMemorySize, (int)plds));                           \
+        const int ncb = pb::div_up(nwave, (T / 64) * 16);                                          \
+        const unsigned grid = (unsigned)(8 * (int64_t)pb::div_up(ncb, 8) * npair);                 \
+        k_table_transit_pair<M, W, T, 4, P><<<grid, T, plds, s>>>(                                 \
+            spectrum_d, etable_d, tlo, coef, qwork, radius_d, perm, use_pair, nblk, rstar, itop,   \
+            ibottom, maxdepth, nmol, ntemp, nlayers, nwave, nwalkers, ncb);                        \
+    } while (0)
+        // Geometry measured at C5's shape (ms per 64 walkers, tools/bench_tt.py; the two passes over
+        // a stored ec 2.65-2.69 on the same box): 256 threads (4 wavefronts x 16 columns x 2 walkers,
+        // two workgroups per CU) with two K-steps of loads in flight 2.54-2.55 (168 registers), one
+        // K-step 2.57-2.60; 512 threads 2.59 / 2.62; 384 threads 3.20 / 3.27.
+        const int tpd = getenv("PB_TP_PD") ? atoi(getenv("PB_TP_PD")) : 2;
+        switch (mt) {
+        case 1: PB_TP(1, 2, 256, 2); break;
+        case 2: PB_TP(2, 2, 256, 2); break;
+        case 3: PB_TP(3, 2, 256, 2); break;
+        case 4: PB_TP(4, 2, 256, 2); break;
+        default:
+            if (tpd == 1)
+                PB_TP(5, 2, 256, 1);
+            else
+                PB_TP(5, 2, 256, 2);
+            break;
+        }
+#undef PB_TP
+        PB_LAUNCH_CHECK();
+        // (the one-walker kernel follows: it returns at once unless k_walker_order found the
+        // pairs to disagree too often)
+    }
     const size_t lds = ((size_t)nblk * 64 + (size_t)mt * 16 * (1 + 2 * ncoef)) * 8 + (size_t)mt * 16 * 4;
 #define PB_TT(M, W, T, S, P)                                                                       \
     do {                                                                                           \
@@ -1478,7 +1803,7 @@ int pb_table_transit_batch(double *spectrum_d, const double *etable_d, const dou
         const unsigned grid = (unsigned)(8 * (int64_t)pb::div_up(ncb, 8 * ginter) * ginter * nwalkers); \
         k_table_transit_mfma<M, W, T, S, P><<<grid, T, lds, s>>>(                                  \
             spectrum_d, etable_d, tlo, coef, qwork, radius_d, nblk, rstar, itop, ibottom, maxdepth, \
-            nmol, ntemp, nlayers, nwave, nwalkers, ncb, ginter);                                   \
+            nmol, ntemp, nlayers, nwave, nwalkers, ncb, ginter, skip_if);                          \
     } while (0)
     const int ginter = getenv("PB_TT_GINTER") ? std::max(1, std::min(8, atoi(getenv("PB_TT_GINTER")))) : 1;
     // Geometry measured at C5's shape (80 layers, 4 species; tools/bench_tt.py, ms per 64 walkers,

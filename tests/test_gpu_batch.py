@@ -343,6 +343,39 @@ def test_table_transit_one_pass(eng, orc, monkeypatch, nlayers, nwave, itop, nmo
     ec = eng.interp_ec_batch(et, tt, td, dd)
     two = host(eng.transit_spectrum_batch(ec, path, rd, rstar, itop, L, 10.0))
     np.testing.assert_allclose(got, two, rtol=1e-13)
+    # (default: k_walker_order pairs neighbours in bracket order and picks the two-walker kernel
+    # unless the pairs' brackets differ in more than a fifth of the K-steps -- these random
+    # temperatures do; PB_TT_PAIR=2 forces it: every K-step then takes the exception path with the
+    # second walker's own loads, an odd walker is left over; PB_TT_PAIR=0: one walker per wavefront)
+    monkeypatch.setenv('PB_TT_PAIR', '2')
+    forced = host(eng.table_transit_batch(et, tt, td, dd, path, rd, rstar, itop, L, 10.0))
+    np.testing.assert_allclose(forced, two, rtol=1e-13)
+    monkeypatch.setenv('PB_TT_PAIR', '0')
+    single = host(eng.table_transit_batch(et, tt, td, dd, path, rd, rstar, itop, L, 10.0))
+    monkeypatch.delenv('PB_TT_PAIR')
+    np.testing.assert_allclose(single, two, rtol=1e-13)
+    np.testing.assert_allclose(got, single, rtol=1e-13)
+    # an even batch whose walkers share every bracket (one set of slice loads per pair)
+    t2 = np.tile(temps[3:4], (4, 1)) * (1 + 1e-6 * np.arange(4)[:, None])
+    d2 = np.tile(dens[3:4], (4, 1, 1)) * (1 + 0.1 * np.arange(4)[:, None, None])
+    r2 = np.tile(radius[3:4], (4, 1))
+    t2d, d2d, r2d = eng.dev(t2), eng.dev(d2), eng.dev(r2)
+    p2 = eng.transit_path_device(r2d, itop)
+    a = host(eng.table_transit_batch(et, tt, t2d, d2d, p2, r2d, rstar, itop, L, 10.0))
+    b = host(eng.transit_spectrum_batch(eng.interp_ec_batch(et, tt, t2d, d2d), p2, r2d, rstar,
+                                        itop, L, 10.0))
+    np.testing.assert_allclose(a, b, rtol=1e-13)
+    # ... and one whose pairs differ in a few layers only (the default picks the two-walker
+    # kernel and takes the exception path in those K-steps)
+    t3 = t2.copy()
+    t3[1, L // 2] = temps[4, L // 2]
+    t3[2, itop] = temps[4, itop]
+    t3[3, L - 1] = temps[4, L - 1]
+    t3d = eng.dev(t3)
+    a = host(eng.table_transit_batch(et, tt, t3d, d2d, p2, r2d, rstar, itop, L, 10.0))
+    b = host(eng.transit_spectrum_batch(eng.interp_ec_batch(et, tt, t3d, d2d), p2, r2d, rstar,
+                                        itop, L, 10.0))
+    np.testing.assert_allclose(a, b, rtol=1e-13)
     stops = set()
     for w in range(nw):
         want_ec = np.zeros((L, W))

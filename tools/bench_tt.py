@@ -40,8 +40,14 @@ def main():
         return out.cpu().numpy()
 
     ref = run('two passes (stored ec)', {'PB_TABLE_TRANSIT': '0'})
-    for gi in os.environ.get('GINTER', '2').split():
-        got = run(f'one pass (ec never stored) G={gi}', {'PB_TABLE_TRANSIT': '1', 'PB_TT_GINTER': gi})
+    for pair, tb, pd in (('1', '', ''), ('1', '', '1'), ('0', '', '')):
+        os.environ['PB_TP_TB'] = tb
+        os.environ['PB_TP_PD'] = pd
+        got = run(f"one pass, {'two walkers' if pair == '1' else 'one walker'} per wavefront {tb} {pd}",
+                  {'PB_TABLE_TRANSIT': '1', 'PB_TT_PAIR': pair})
+        os.environ.pop('PB_TT_PAIR', None)
+        os.environ.pop('PB_TP_TB', None)
+        os.environ.pop('PB_TP_PD', None)
         err = float(np.max(np.abs(got / ref - 1)))
         assert err <= 1e-13, err
     ref2 = run('two passes (stored ec), again', {'PB_TABLE_TRANSIT': '0'})

@@ -198,7 +198,9 @@ def table_transit_case(eng, rng, seed):
     et, tt = eng.dev(etable), eng.dev(ttable)
     td, dd, rd = eng.dev(temps), eng.dev(dens), eng.dev(radius)
     path = eng.transit_path_device(rd, itop)
+    os.environ['PB_TT_PAIR'] = str(rng.choice(['0', '1', '2', '2']))
     one = host(eng.table_transit_batch(et, tt, td, dd, path, rd, 8.8e10, itop, L, maxdepth))
+    os.environ.pop('PB_TT_PAIR')
     ec = eng.interp_ec_batch(et, tt, td, dd)
     two = host(eng.transit_spectrum_batch(ec, path, rd, 8.8e10, itop, L, maxdepth))
     assert np.all(np.isfinite(one)), 'one-pass table transit: non-finite spectrum'

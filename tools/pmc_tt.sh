@@ -28,7 +28,7 @@ for f in glob.glob(os.path.join(out, 'p*', '**', '*counter_collection.csv'), rec
 res = {k: {c: sum(v) / len(v) for c, v in d.items()} for k, d in acc.items()}
 json.dump(res, open(os.path.join(out, 'pmc_summary.json'), 'w'), indent=1, sort_keys=True)
 for k in sorted(res):
-    if 'transit_mfma' in k or 'interp_ec_batch' in k:
+    if 'transit' in k or 'interp_ec_batch' in k:
         print(k)
         for c in sorted(res[k]):
             print(f'   {c:36s} {res[k][c]:.4g}')
