@@ -6,6 +6,8 @@
 #   * bench JSONs of the other workloads (c2-res, c3, c4, c5)        -> gpurun_out/<tag>_bench_*.json
 #   * rocprofv3 kernel stats of c2-res and c5                        -> gpurun_out/<tag>_kernel_stats_{c2res,c5}.csv
 #   * per-rank times of the wavenumber decomposition                 -> gpurun_out/<tag>_wshard.log
+#   * the same with the collectives through a one-rank RCCL group    -> gpurun_out/<tag>_rank_rccl.log
+#   * retrieval batch: one pass against two passes                   -> gpurun_out/<tag>_table_transit_ab.log
 #   * PMC traffic of the dominant kernel keyed by the library hash   -> gpurun_out/pmc_traffic.json
 tag=${1:-r03}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
@@ -35,6 +37,8 @@ echo "other workloads done"
 { for n in 2 4 8; do python tools/bench_wshard.py $n c2 3; done; python tools/bench_wshard.py 8 c2-1e6 3; python tools/bench_wshard.py 8 c2 2; python tools/bench_wshard.py 8 c2-1e6 2; } 2>&1 | grep shard > gpurun_out/${tag}_wshard.log
 python tools/bench_dropin.py 2>&1 | grep drop-in > gpurun_out/${tag}_dropin.log
 python tools/bench_outofcore.py --lines 1e8 --budget-gib 16 --check --out gpurun_out/${tag}_outofcore_1e8.json > gpurun_out/${tag}_outofcore.log 2>&1 || { tail -3 gpurun_out/${tag}_outofcore.log; exit 1; }
+python tools/bench_tt.py > gpurun_out/${tag}_table_transit_ab.log 2>&1 || { tail -3 gpurun_out/${tag}_table_transit_ab.log; exit 1; }
+{ python tools/bench_rank_rccl.py 8 c2 3; python tools/bench_rank_rccl.py 4 c2 3; python tools/bench_rank_rccl.py 2 c2 3; } 2>&1 | grep "rank " > gpurun_out/${tag}_rank_rccl.log
 echo "rank shards done"
 python tools/pmc_traffic.py c2 > gpurun_out/pmc_traffic.log 2>&1 || { tail -5 gpurun_out/pmc_traffic.log; exit 1; }
 tail -2 gpurun_out/pmc_traffic.log
