@@ -449,7 +449,10 @@ int pb_transit_spectrum_batch(double *spectrum_d, double *depth_d, int32_t *idee
  * etable_d[nmol,ntemp,nlayers,nwave], temps_d[nwalkers,nlayers], density_d[nwalkers,nlayers,nmol],
  * raypath_d[nwalkers, n(n-1)/2], radius_d[nwalkers,nlayers] -> spectrum_d[nwalkers,nwave].
  * The interpolated extinction is formed in registers as the operand of the FP64 matrix products
- * and never stored.  pb_table_transit_supported(...) != 0 says whether the shape has this form
+ * and never stored.  From two walkers on, neighbours in an order of the walkers by their table
+ * brackets share a wavefront and one set of table loads (decided on the device; a batch whose
+ * pairs bracket different temperatures in more than a fifth of the layers runs one walker per
+ * wavefront).  pb_table_transit_supported(...) != 0 says whether the shape has this form
  * (2..128 impact parameters, nwave >= 2, one species' block of the table below 4 GiB); work_d: pb_table_transit_work_doubles(...) doubles. */
 int pb_table_transit_supported(int nmol, int ntemp, int nlayers, int itop, int ibottom,
                                int nwave);
