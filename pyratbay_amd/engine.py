@@ -1159,9 +1159,9 @@ class TableSpectrum:
         """The transit batch through pb_table_transit_batch (interpolation, optical depth and
         transmission in one pass, ec never stored): opt-in (`one_pass = True` or
         PB_TABLE_TRANSIT=1).  It saves the ec[walkers, L, W] buffer (4.1 GB per 64 walkers at
-        C5's shape); at that shape it runs 2.54 ms per 64 walkers against 2.67 for the two passes
-        when the walkers resemble one another (two walkers per wavefront share their table
-        loads), 2.86 when they do not -- which only the device knows, hence not the default."""
+        C5's shape); at that shape it runs 2.54 ms per 64 walkers when the walkers resemble one
+        another (two walkers per wavefront share their table loads; the two passes: 2.42-2.70 box
+        to box), 2.86 when they do not -- which only the device knows, hence not the default."""
         want = getattr(self, 'one_pass', None)
         if want is None:
             want = os.environ.get('PB_TABLE_TRANSIT', '0') == '1'
