@@ -544,10 +544,16 @@ def main():
 
         def run_steps(k):
             if pipelined and kind != 'layers':
+                # (SpectrumPipeline.submit returns this spectrum; ShardPipeline.submit the previous
+                # one -- its all-gather is issued behind the next all-reduce -- and flush() the last)
                 out = None
                 for _ in range(k):
-                    out, _ev = pipe.submit()
-                pipe.flush()
+                    r = pipe.submit()
+                    if r is not None:
+                        out = r[0]
+                last = pipe.flush()
+                if last is not None:
+                    out = last[0]
                 return [out]
             if pipelined:
                 for _ in range(k):

@@ -2872,9 +2872,15 @@ static int lbl_extinction(pb_lbl *p, double *ext_d, int64_t wbegin, int64_t wcou
     int S = 2;
     int nsplit = (int)std::min<int64_t>(
         8, pb::div_up((int64_t)(per_phase >= 64.0 ? 8000 : 2000), std::max<int64_t>(1, blocks2)));
-    if (shared_chip)           // about one round of workgroups on the chip's 1024 slots
-        nsplit = (int)std::max<int64_t>(
-            1, std::min<int64_t>(8, (1024 + blocks2 / 2) / std::max<int64_t>(1, blocks2)));
+    if (shared_chip) {
+        // the ~2000 workgroups of the rule above, counted over ALL the spectra in flight.  (Until
+        // the rank loop stopped being host-bound -- second session of round 3 -- one round of 1024
+        // per launch measured best; with the host out of the way, a 1/8 shard of C2 with three in
+        // flight: 1 / 2 / 3 / 4 pieces per tile 0.211 / 0.163 / 0.179 / 0.181 ms per spectrum, a
+        // 1/4 shard 0.276 / 0.279 / 0.291, a 1/2 shard 0.467 / 0.502.)
+        const int64_t inflight = blocks2 * std::max(1, p->concurrency);
+        nsplit = (int)std::max<int64_t>(1, std::min<int64_t>(8, (2000 + inflight / 2) / std::max<int64_t>(1, inflight)));
+    }
     {
         const int64_t plane = (int64_t)nlayers * a.nrows * wcount * 8;
         while (nsplit > 1 && (nsplit - 1) * plane > ((int64_t)1 << 30))

@@ -442,30 +442,55 @@ class ShardPipeline:
         self.streams = engine.side_streams(depth)
         self.done = [None] * depth
         self.count = 0
+        self.pending = None          # (context, shard) whose all-gather has not been issued yet
 
     def set_atmosphere(self, *args, **kw):
         for m in self.models:
             m.set_atmosphere(*args, **kw)
 
-    def submit(self):
-        j = self.count % len(self.models)
-        self.count += 1
-        model, stream, gather = self.models[j], self.streams[j], self.gathers[j]
-        caller = torch.cuda.current_stream()
-        if not caller.query():                   # (an idle stream has nothing to wait for)
-            stream.wait_stream(caller)
+    def _close(self):
+        """Issue the all-gather of the pending spectrum on its own stream -> (full, event)."""
+        j, local = self.pending
+        self.pending = None
+        stream = self.streams[j]
         with torch.cuda.stream(stream):
-            full = gather(model.run())
+            full = self.gathers[j](local)
             event = torch.cuda.Event()
             event.record(stream)
         self.done[j] = event
         return full, event
 
+    def submit(self):
+        """Enqueue one more spectrum; returns (full spectrum, event) of the spectrum submitted
+        BEFORE this one (None for the first): its closing all-gather is issued only now, AFTER this
+        spectrum's all-reduce of the maxima.  The collectives of one communicator run on one
+        stream in the order they are issued, and each waits there for the kernels that produce
+        its input: with the all-gather of spectrum i issued before the all-reduce of spectrum
+        i+1, that all-reduce -- and with it the whole gather of spectrum i+1 -- waited for the
+        last kernel of spectrum i, and the 'pipeline' ran one spectrum at a time plus its
+        collectives.  Every rank issues all-reduce(i+1), all-gather(i), all-reduce(i+2), ... in the
+        same order."""
+        j = self.count % len(self.models)
+        self.count += 1
+        model, stream = self.models[j], self.streams[j]
+        caller = torch.cuda.current_stream()
+        if not caller.query():                   # (an idle stream has nothing to wait for)
+            stream.wait_stream(caller)
+        with torch.cuda.stream(stream):
+            local = model.run()                  # ... all-reduce of the maxima inside
+        prev = self._close() if self.pending is not None else None
+        self.pending = (j, local)
+        return prev
+
     def flush(self):
+        """Close the spectrum still pending and join the caller's stream with every spectrum
+        submitted so far; returns (full spectrum, event) of the last one (None if none)."""
+        last = self._close() if self.pending is not None else None
         cur = torch.cuda.current_stream()
         for event in self.done:
             if event is not None:
                 cur.wait_event(event)
+        return last
 
 
 def walker_slice(nwalkers, world, rank):

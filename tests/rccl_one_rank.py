@@ -84,6 +84,38 @@ def main():
     assert err <= 1e-12, err
     assert torch.equal(sharded.step(), outs[-1])
 
+    # (5) dist.ShardPipeline as rank 1 of 3 (equal-size shards written straight into the gather
+    #     buffer, the all-reduce of the maxima, each spectrum's all-gather issued behind the next
+    #     spectrum's all-reduce), the all-gather on this one-rank group moving the rank's own block
+    class OneRankGather(pbdist.SpectrumGather):
+        def __call__(self, local):
+            assert local.data_ptr() == self.send.data_ptr()      # written in place by the model
+            pbdist.all_gather_flat(self.recv[self.rank * self.pad:(self.rank + 1) * self.pad],
+                                   self.send)
+            return self.full
+
+    nwave = case['grid']['nwave']
+    pipe = pbdist.ShardPipeline(case, 3, 1, depth=3, kmax_exchange=True, voigt=plain.voigt,
+                                lines=plain.lines, timestamps=False)
+    pipe.gathers = [OneRankGather(nwave, 3, 1, 'cuda', uniform=True) for _ in range(3)]
+    for m, g in zip(pipe.models, pipe.gathers):
+        assert g.uniform
+        m.spectrum_out = g.slot
+    g0 = pipe.gathers[0]
+    fulls = []
+    for i in range(7):
+        r = pipe.submit()
+        assert (r is None) == (i == 0)
+        if r is not None:
+            fulls.append(r[0].clone())
+    fulls.append(pipe.flush()[0].clone())
+    torch.cuda.synchronize()
+    assert len(fulls) == 7
+    a, b = g0.wbegin, g0.wbegin + g0.wcount
+    err = max(float(torch.max(torch.abs(f[a:b] / want[a:b] - 1)).item()) for f in fulls)
+    out['shard_pipeline_vs_single'] = err
+    assert err <= 1e-12, err
+
     # (4) walkers gathered over the ranks (replica form of the retrieval batch)
     local = torch.rand((7, 3), dtype=torch.float64, device='cuda')
     assert torch.equal(pbdist.gather_walkers(local, 7, 1, 0), local)

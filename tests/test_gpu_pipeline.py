@@ -431,12 +431,16 @@ def test_shard_pipeline_single_process(eng, case):
     want = serial.run().clone()
     pipe = ShardPipeline(case, 1, 0, depth=3, voigt=serial.voigt, lines=serial.lines)
     outs = []
-    for _ in range(5):
-        full, event = pipe.submit()
-        event.synchronize()
-        outs.append(full.clone())
-    pipe.flush()
+    for i in range(5):
+        r = pipe.submit()                  # (the spectrum submitted before this one, see submit())
+        assert (r is None) == (i == 0)
+        if r is not None:
+            r[1].synchronize()
+            outs.append(r[0].clone())
+    last = pipe.flush()
     torch.cuda.synchronize()
+    outs.append(last[0].clone())
+    assert len(outs) == 5 and pipe.flush() is None
     for o in outs:
         np.testing.assert_allclose(o.cpu().numpy(), want.cpu().numpy(), rtol=1e-12)
     # a plan told about the other spectra in flight gives the same extinction

@@ -34,3 +34,4 @@ def test_collectives_through_rccl_one_rank():
     assert res['backend'] == 'nccl'
     assert res['two_phase_vs_one_call'] <= 1e-12
     assert res['layer_pipeline_vs_single'] <= 1e-12
+    assert res['shard_pipeline_vs_single'] <= 1e-12
