@@ -412,14 +412,17 @@ class ShardPipeline:
 
     Why: a 1/8 shard of C2 is ~0.27 ms of launches of which the gather -- the only one that
     fills the chip -- is 0.17; every collective is a latency a single spectrum sits through.
-    With two spectra in flight a rank delivers one per ~0.21 ms (tools/bench_wshard.py), and the
-    N = 1 form of bench.py pipelines in the same way (engine.SpectrumPipeline), so the N-GPU and
-    the single-GPU numbers are like for like.
+    With three spectra in flight a rank delivers one per ~0.165 ms (tools/bench_rank_rccl.py),
+    and the N = 1 form of bench.py pipelines in the same way (engine.SpectrumPipeline), so the
+    N-GPU and the single-GPU numbers are like for like.
 
-    Every context has its own plan and its own SpectrumGather buffers; the Voigt table and the
-    line list are shared.  Every rank issues the collectives of spectrum i, then those of
-    spectrum i+1, in program order on one communicator, so they pair up across the ranks.
-    submit() -> (full spectrum on every rank, event); flush() joins the caller's stream."""
+    Every context has its own plan and its own SpectrumGather buffers (equal-size shards, the
+    model writes its shard straight into the send buffer, the receive buffer of the one all-gather
+    is the spectrum); the Voigt table and the line list are shared.  Every rank issues the
+    collectives in the same order on one communicator -- all-reduce(i+1) BEFORE all-gather(i), see
+    submit() -- so they pair up across the ranks.  submit() -> (full spectrum on every rank,
+    event) of the PREVIOUS submission or None; flush() -> those of the last one, and joins the
+    caller's stream."""
 
     def __init__(self, case, world, rank, depth=2, group=None, kmax_exchange=True,
                  voigt=None, lines=None, rt_path='transit', **model_kw):
