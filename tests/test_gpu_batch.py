@@ -435,3 +435,39 @@ def test_table_transit_refuses_other_shapes(eng):
     path = eng.transit_path_device(rad, 0)
     with pytest.raises(Exception, match='one-pass'):
         eng.table_transit_batch(et, tt, temps, dens, path, rad, 8.8e10, 0, 130, 10.0)
+
+
+@pytest.mark.parametrize('mode', ['0', '2'])
+def test_table_transit_reads_inside_the_table(eng, monkeypatch, mode):
+    """The one-pass kernels address the table with clamped rows / columns / species instead of
+    predicates.  Here the table is a view into a buffer whose surroundings are NaN: a read outside
+    the table would reach a sum (0 x NaN = NaN) and show in the spectrum.  Shapes whose last
+    wavefront, last pair and last row tile are ragged; one walker per wavefront (mode 0) and two
+    (mode 2: forced, so that the second walker's own loads run in every K-step)."""
+    import torch
+    rng = np.random.default_rng(31)
+    monkeypatch.setenv('PB_TT_PAIR', mode)
+    for nmol, L, W, nw, itop in ((4, 80, 1001, 5, 0), (3, 37, 131, 4, 3), (1, 18, 33, 3, 0),
+                                 (4, 66, 2, 2, 1)):
+        ntemp = 5
+        ttable = np.linspace(300.0, 3000.0, ntemp)
+        n = nmol * ntemp * L * W
+        pad = 8192
+        buf = torch.full((n + 2 * pad,), float('nan'), dtype=torch.float64, device='cuda')
+        colscale = 10.0**rng.uniform(-33.5, -27.0, W)
+        etable = 10.0**rng.uniform(-0.3, 0.3, (nmol, ntemp, L, W)) * colscale
+        buf[pad:pad + n] = eng.dev(etable).view(-1)
+        et = buf[pad:pad + n].view(nmol, ntemp, L, W)
+        temps = rng.uniform(300.0, 3000.0, (nw, L))
+        temps[0] = 3000.0
+        press = np.logspace(-6, 2, L)
+        dens = press[None, :, None]**0.9 * 10.0**rng.uniform(17, 18, (nw, L, nmol))
+        radius = np.array([np.sort(np.linspace(8.0e9, 7.0e9, L) * (1 + 0.01 * rng.uniform(-1, 1)))[::-1]
+                           for _ in range(nw)])
+        tt, td, dd, rd = eng.dev(ttable), eng.dev(temps), eng.dev(dens), eng.dev(radius)
+        path = eng.transit_path_device(rd, itop)
+        got = host(eng.table_transit_batch(et, tt, td, dd, path, rd, 8.8e10, itop, L, 10.0))
+        assert np.all(np.isfinite(got)), (nmol, L, W, nw, itop)
+        two = host(eng.transit_spectrum_batch(eng.interp_ec_batch(et, tt, td, dd), path, rd,
+                                              8.8e10, itop, L, 10.0))
+        np.testing.assert_allclose(got, two, rtol=1e-13)
