@@ -894,12 +894,21 @@ __global__ __launch_bounds__(1024) void k_walker_order(int32_t *perm, int32_t *u
     const int w = threadIdx.x;
     if (w == 0)
         s_diff = 0;
-    if (w < nwalkers) {
+    // keys: with up to 64 walkers sixteen lanes share a walker's layers (a serial loop over 80
+    // layers per thread was most of the kernel's 25 us)
+    const int per = nwalkers <= 64 ? 16 : 1;
+    {
+        const int ww = w / per, part = w % per;
         long long k = 0;
-        for (int l = 0; l < nlayers; l++)
-            k += tlo[(int64_t)w * nlayers + l];
-        s_key[w] = k;
-        s_t[w] = temps[(int64_t)w * nlayers + nlayers / 2];
+        if (ww < nwalkers)
+            for (int l = part; l < nlayers; l += per)
+                k += tlo[(int64_t)ww * nlayers + l];
+        for (int d = per >> 1; d >= 1; d >>= 1)
+            k += __shfl_down(k, d, 16);
+        if (ww < nwalkers && part == 0) {
+            s_key[ww] = k;
+            s_t[ww] = temps[(int64_t)ww * nlayers + nlayers / 2];
+        }
     }
     __syncthreads();
     if (w < nwalkers) {
@@ -917,11 +926,15 @@ __global__ __launch_bounds__(1024) void k_walker_order(int32_t *perm, int32_t *u
     __syncthreads();
     const int npair = nwalkers >> 1;
     const int nsteps = (nimpact + 3) / 4;
-    if (w < npair) {
-        const int32_t *ta = tlo + (int64_t)s_perm[2 * w] * nlayers + itop;
-        const int32_t *tb = tlo + (int64_t)s_perm[2 * w + 1] * nlayers + itop;
+    // one thread per (pair, K-step) while they fit the workgroup, else per pair
+    const bool fine = npair * nsteps <= 1024;
+    const int pi = fine ? w / max(nsteps, 1) : w;
+    if (pi < npair && (fine ? w < npair * nsteps : true)) {
+        const int32_t *ta = tlo + (int64_t)s_perm[2 * pi] * nlayers + itop;
+        const int32_t *tb = tlo + (int64_t)s_perm[2 * pi + 1] * nlayers + itop;
         int diff = 0;
-        for (int ks = 0; ks < nsteps; ks++) {
+        const int k0 = fine ? w % nsteps : 0, k1 = fine ? k0 + 1 : nsteps;
+        for (int ks = k0; ks < k1; ks++) {
             bool same = true;
             for (int q = 0; q < 4; q++) {
                 const int r = min(4 * ks + q, nimpact - 1);
