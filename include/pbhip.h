@@ -411,6 +411,18 @@ int pb_band_integrate(double *bandflux_d, const double *spectrum_d, const double
  * lower triangle pb_optical_depth_transit takes. */
 int pb_transit_path(double *raypath_d, const double *radius_d, int itop, int nlayers,
                     int nwalkers, void *stream);
+/* Partition functions of the isotopes of ONE TLI database at ntemp temperatures (the layers of
+ * one atmosphere, or of a batch of walkers): what Line_By_Line.__init__ prepares with
+ * scipy.interpolate.interp1d(db.temp, db.iso_pf[j], kind='slinear')
+ * (pyratbay/pyrat/line_by_line.py:156-158) and calc_extinction_coefficient evaluates at the
+ * temperature profile on EVERY call (:219-222).  ttab_d[ntab] ascending, pf_d[niso, ntab];
+ * z_d[i*z_iso_stride + t*z_t_stride] (the isoz operand of pb_lbl_extinction takes the same two
+ * strides).  Bit-equal to SciPy's first-order spline (its de Boor recurrence, restated).  A
+ * temperature outside [ttab[0], ttab[ntab-1]] makes interp1d raise; here NaN is written and,
+ * when nbad_d is not NULL, counted there (int32, zeroed by the caller). */
+int pb_iso_partition(double *z_d, int64_t z_iso_stride, int64_t z_t_stride,
+                     const double *temp_d, int64_t ntemp, const double *ttab_d, int ntab,
+                     const double *pf_d, int niso, int32_t *nbad_d, void *stream);
 /* Loader of sampled cross sections: one species' table of one opacity file
  * (in_d[ntemp_in, nlay_in, nwave_in], cm2 molecule-1) brought onto the run's grid
  * (out_d[ntemp_out, nlay_out, nwave_out]) -- tools.interpolate_opacity

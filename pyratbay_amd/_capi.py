@@ -71,6 +71,7 @@ _PROTOS = {
     'pb_interp_ec': [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp],
     'pb_interp_ec_set': [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp],
     'pb_transit_path': [vp, vp, i32, i32, i32, vp],
+    'pb_iso_partition': [vp, i64, i64, vp, i64, vp, i32, vp, i32, vp, vp],
     'pb_resample_cross_section': [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32,
                                   i32, vp],
     'pb_interp_ec_batch': [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp],

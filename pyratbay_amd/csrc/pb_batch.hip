@@ -47,6 +47,47 @@ __global__ __launch_bounds__(kBlock) void k_transit_path(double *raypath, const 
 }
 
 // ---------------------------------------------------------------------------
+// Partition functions Z_i(T) of the isotopes of one TLI database at the layer temperatures of a
+// batch of atmospheres (line_by_line.py:156-158: interp1d(db.temp, db.iso_pf[j], kind='slinear');
+// :219-222: evaluated at the temperature profile on every extinction call).  SciPy's first-order
+// spline is evaluated as its de Boor recurrence does (w = 1/(t_hi - t_lo); Z = z_lo (w (t_hi - T))
+// + z_hi (w (T - t_lo)), interval t_lo <= T < t_hi, the last one closed): bit-equal to it.  A
+// temperature outside the table is an error in the reference (interp1d raises): NaN is written
+// and counted in *nbad.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_iso_partition(
+    double *z, int64_t z_iso_stride, int64_t z_t_stride, const double *temp, int64_t ntemp,
+    const double *ttab, int ntab, const double *pf, int niso, int32_t *nbad)
+{
+    const int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (t >= ntemp)
+        return;
+    const double x = temp[t];
+    if (!(x >= ttab[0] && x <= ttab[ntab - 1])) {
+        for (int i = 0; i < niso; i++)
+            z[i * z_iso_stride + t * z_t_stride] = __longlong_as_double(0x7ff8000000000000ll);
+        if (nbad)
+            atomicAdd(nbad, 1);
+        return;
+    }
+    int lo = 0, hi = ntab - 1;                 // largest lo <= ntab - 2 with ttab[lo] <= x
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (ttab[mid] <= x)
+            lo = mid;
+        else
+            hi = mid;
+    }
+    const double xa = ttab[lo], xb = ttab[lo + 1];
+    const double w = 1.0 / (xb - xa);
+    const double h0 = w * (xb - x), h1 = w * (x - xa);
+    for (int i = 0; i < niso; i++) {
+        const double *row = pf + (int64_t)i * ntab;
+        z[i * z_iso_stride + t * z_t_stride] = row[lo] * h0 + row[lo + 1] * h1;
+    }
+}
+
+// ---------------------------------------------------------------------------
 // interp_ec for a batch of walkers, assigning form.  Workgroup = (256 wavenumbers, layer,
 // chunk of walkers).  Walkers of a chunk that share a temperature bracket share its two table
 // slices: the brackets the chunk uses at this layer are walked in ascending order, the upper
@@ -1566,6 +1607,21 @@ int pb_transit_path(double *raypath_d, const double *radius_d, int itop, int nla
     dim3 grid(std::min(nrow, 64), nwalkers);
     k_transit_path<<<grid, kBlock, 0, pb::as_stream(stream)>>>(raypath_d, radius_d, itop, nlayers,
                                                              npath);
+    PB_LAUNCH_CHECK();
+    return PB_OK;
+}
+
+int pb_iso_partition(double *z_d, int64_t z_iso_stride, int64_t z_t_stride,
+                     const double *temp_d, int64_t ntemp, const double *ttab_d, int ntab,
+                     const double *pf_d, int niso, int32_t *nbad_d, void *stream)
+{
+    PB_REQUIRE(ntemp >= 0 && niso >= 0 && ntab >= 2, "pb_iso_partition: bad shape (a partition-"
+               "function table needs at least two temperatures, got %d)", ntab);
+    if (ntemp == 0 || niso == 0)
+        return PB_OK;
+    PB_REQUIRE(z_d && temp_d && ttab_d && pf_d, "pb_iso_partition: null pointer");
+    k_iso_partition<<<(unsigned)pb::div_up(ntemp, kBlock), kBlock, 0, pb::as_stream(stream)>>>(
+        z_d, z_iso_stride, z_t_stride, temp_d, ntemp, ttab_d, ntab, pf_d, niso, nbad_d);
     PB_LAUNCH_CHECK();
     return PB_OK;
 }

@@ -116,7 +116,25 @@ struct pb_timer {
     std::vector<std::string> names;
     int used = 0;                        // events recorded since the last start
     int open_ranges = 0;
+    // a run is OPEN from pb_timer_start until a pb_timer_mark that names no next stage: only then
+    // may a fused entry point mark its internal boundary on this timer (a finished run must not
+    // collect the boundaries of later, unrelated calls of the same thread)
+    bool open = false;
 };
+
+namespace {
+// events recorded on a capturing stream become graph nodes: reading them later synchronises
+// nothing meaningful.  A stage timer records nothing while its stream is being captured.
+bool capturing(hipStream_t s)
+{
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &st) != hipSuccess) {
+        (void)hipGetLastError();
+        return false;
+    }
+    return st != hipStreamCaptureStatusNone;
+}
+}  // namespace
 
 namespace pb {
 
@@ -124,7 +142,7 @@ namespace pb {
 void stage_boundary(const char *name, const char *next_stage, hipStream_t s)
 {
     pb_timer *t = t_timer;
-    if (!t || t->used == 0 || t->used >= (int)t->ev.size())
+    if (!t || !t->open || t->used == 0 || t->used >= (int)t->ev.size() || capturing(s))
         return;
     if (hipEventRecord(t->ev[t->used], s) != hipSuccess) {
         (void)hipGetLastError();
@@ -189,8 +207,16 @@ int pb_timer_start(pb_timer *t, const char *first_stage, void *stream)
         pb::range_pop();
         t->open_ranges--;
     }
+    if (capturing(pb::as_stream(stream))) {
+        // (the run being captured keeps the timestamps of the last eager run)
+        t->open = false;
+        if (pb::t_timer == t)
+            pb::t_timer = nullptr;
+        return PB_OK;
+    }
     PB_HIP(hipEventRecord(t->ev[0], pb::as_stream(stream)));
     t->used = 1;
+    t->open = true;
     pb::t_timer = t;
     if (first_stage) {
         pb::range_push(first_stage);
@@ -202,6 +228,8 @@ int pb_timer_start(pb_timer *t, const char *first_stage, void *stream)
 int pb_timer_mark(pb_timer *t, const char *name, const char *next_stage, void *stream)
 {
     PB_REQUIRE(t && name, "pb_timer_mark: null pointer");
+    if (!t->open && capturing(pb::as_stream(stream)))
+        return PB_OK;                    // pb_timer_start skipped this (captured) run
     PB_REQUIRE(t->used >= 1, "pb_timer_mark: timer not started");
     PB_REQUIRE(t->used < (int)t->ev.size(), "pb_timer_mark: more than %d stages",
                (int)t->ev.size() - 1);
@@ -215,6 +243,11 @@ int pb_timer_mark(pb_timer *t, const char *name, const char *next_stage, void *s
     if (next_stage) {
         pb::range_push(next_stage);
         t->open_ranges++;
+    } else {
+        // the run is over: later fused calls of this thread belong to nobody's timer
+        t->open = false;
+        if (pb::t_timer == t)
+            pb::t_timer = nullptr;
     }
     return PB_OK;
 }

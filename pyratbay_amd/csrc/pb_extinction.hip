@@ -3058,9 +3058,14 @@ static int lbl_extinction(pb_lbl *p, double *ext_d, int64_t wbegin, int64_t wcou
     // (a fine grid shorter than two steps of the coarsest dynamic grid has no constant-step form)
     if (p->resolution && p->gather_mode == 6 && phase == 0 && l->ngroups > 0 &&
         l->onwn > 2 * (int64_t)v->osamp &&
-        !(getenv("PB_RES_DYN") && atoi(getenv("PB_RES_DYN")) == 0))
-        return lbl_resolution_dyn(p, a, ext_d, wbegin, wcount, temp_d, dens_d, isoz_d,
-                                  z_iso_stride, z_layer_stride, nlayers, add, s);
+        !(getenv("PB_RES_DYN") && atoi(getenv("PB_RES_DYN")) == 0)) {
+        const int rc = lbl_resolution_dyn(p, a, ext_d, wbegin, wcount, temp_d, dens_d, isoz_d,
+                                          z_iso_stride, z_layer_stride, nlayers, add, s);
+        // a re-cut table row that cannot be addressed (pb_voigt_ensure_rows) before any run has
+        // added to ext: the direct gather below computes the call instead
+        if (!(rc == PB_ERR_UNSUPPORTED && p->dyn_runs == 0))
+            return rc;
+    }
     if (phase != 2) {
     k_layer_state<<<nlayers, 64, ((size_t)a.nlor + a.ndop) * 8 + (size_t)a.ndivs * 4, s>>>(a);
     PB_LAUNCH_CHECK();
@@ -3674,7 +3679,13 @@ static int lbl_resolution_dyn(pb_lbl *p, LblArgs &a, double *ext_d, int64_t wbeg
         const int nl = l1 - l0;
         const size_t need = (size_t)nl * a.nrows * (size_t)(d1 - d0) * 8;
         if (need > sub->ktmp_bytes) {
-            PB_HIP(hipStreamSynchronize(t));
+            if (hipStreamSynchronize(t) != hipSuccess) {
+                // (not PB_HIP: the side streams below must be joined on every path)
+                pb::set_error("pb_lbl_extinction: side stream failed: %s",
+                              hipGetErrorString(hipGetLastError()));
+                rc = PB_ERR_HIP;
+                break;
+            }
             (void)hipFree(sub->ktmp);
             sub->ktmp = nullptr;
             sub->ktmp_bytes = 0;
@@ -3710,10 +3721,21 @@ static int lbl_resolution_dyn(pb_lbl *p, LblArgs &a, double *ext_d, int64_t wbeg
         l0 = l1;
     }
     // (joined on every path: the caller's stream must not run ahead of a side stream)
+    // Best effort, lane by lane: a failing record / wait must not leave the other lanes unjoined
+    // (their kernels still write ext_d and the sub-plans' sums); a lane that cannot be joined
+    // through its event is waited for on the host.
     if (lanes > 1)
         for (int k = 0; k < lanes; k++) {
-            PB_HIP(hipEventRecord(p->dyn_join[(size_t)k], p->dyn_streams[(size_t)k]));
-            PB_HIP(hipStreamWaitEvent(s, p->dyn_join[(size_t)k], 0));
+            hipStream_t t = p->dyn_streams[(size_t)k];
+            if (hipEventRecord(p->dyn_join[(size_t)k], t) != hipSuccess ||
+                hipStreamWaitEvent(s, p->dyn_join[(size_t)k], 0) != hipSuccess) {
+                (void)hipGetLastError();
+                (void)hipStreamSynchronize(t);
+                if (rc == PB_OK) {
+                    pb::set_error("pb_lbl_extinction: joining side stream %d failed", k);
+                    rc = PB_ERR_HIP;
+                }
+            }
         }
     if (rc)
         return rc;

@@ -454,9 +454,13 @@ int pb_voigt_ensure_rows(pb_voigt *v, const int *rows, int n, hipStream_t s)
             return PB_ERR_NOMEM;
         }
         double *data = block + kPmPad;               // position p0 of the layout
-        if (!v->d_pm)
-            v->d_pm = reinterpret_cast<double *>(reinterpret_cast<uintptr_t>(data) -
-                                                 ((uintptr_t)1 << 39) * sizeof(double));
+        if (!v->d_pm) {
+            // (clamped: a first row below 4 TiB anchors the table at address 0 -- the
+            // subtraction would wrap and every row then fail the range check for good)
+            const uintptr_t span = ((uintptr_t)1 << 39) * sizeof(double);
+            const uintptr_t at = reinterpret_cast<uintptr_t>(data);
+            v->d_pm = reinterpret_cast<double *>(at > span ? at - span : (uintptr_t)0);
+        }
         // offset of layout position 0 of this row's frame from the anchor, in samples
         const int64_t shift =
             (int64_t)((reinterpret_cast<uintptr_t>(data) - reinterpret_cast<uintptr_t>(v->d_pm)) /
@@ -469,8 +473,17 @@ int pb_voigt_ensure_rows(pb_voigt *v, const int *rows, int n, hipStream_t s)
                           (long long)(shift + p0));
             return PB_ERR_UNSUPPORTED;
         }
-        PB_HIP(hipMemsetAsync(block, 0, kPmPad * sizeof(double), s));
-        PB_HIP(hipMemsetAsync(data + (p1 - p0), 0, kPmPad * sizeof(double), s));
+        // (every failure from here on gives the row's allocation back)
+        auto fail = [&](const char *what) {
+            (void)hipGetLastError();
+            (void)hipStreamSynchronize(s);
+            (void)hipFree(block);
+            pb::set_error("pb_voigt_ensure_rows: %s failed for Lorentz row %d", what, m);
+            return PB_ERR_HIP;
+        };
+        if (hipMemsetAsync(block, 0, kPmPad * sizeof(double), s) != hipSuccess ||
+            hipMemsetAsync(data + (p1 - p0), 0, kPmPad * sizeof(double), s) != hipSuccess)
+            return fail("zeroing the pads");
         unsigned g = 0;
         int rc = grid_for(p1 - p0, &g);
         if (rc) {
@@ -489,9 +502,11 @@ int pb_voigt_ensure_rows(pb_voigt *v, const int *rows, int n, hipStream_t s)
         std::vector<int64_t> based((size_t)v->ndop);
         for (int d = 0; d < v->ndop; d++)           // (aliased cells repeat a base)
             based[(size_t)d] = v->pm_base[k0 + d] + shift;
-        PB_HIP(hipMemcpyAsync(v->d_pm_base + k0, based.data(), (size_t)v->ndop * 8,
-                              hipMemcpyHostToDevice, s));
-        PB_HIP(hipStreamSynchronize(s));             // `based` is a local
+        if (hipMemcpyAsync(v->d_pm_base + k0, based.data(), (size_t)v->ndop * 8,
+                           hipMemcpyHostToDevice, s) != hipSuccess)
+            return fail("uploading the cell offsets");
+        if (hipStreamSynchronize(s) != hipSuccess)   // `based` is a local
+            return fail("the stream");
         for (int d = 0; d < v->ndop; d++)
             v->pm_base[k0 + d] = based[(size_t)d];
         v->row_data[(size_t)m] = block;

@@ -240,6 +240,56 @@ class LineList:
 
 
 # --------------------------------------------------------------------------
+# Partition functions Z_i(T)
+# --------------------------------------------------------------------------
+class PartitionTable:
+    """The partition-function tables of a TLI file's databases on the device, evaluated at a
+    temperature profile the way Line_By_Line does on every extinction call
+    (pyratbay/pyrat/line_by_line.py:156-158: interp1d(db.temp, db.iso_pf[j], kind='slinear');
+    :219-222: iso_pf[i] = iso_pf_interp[i](temperature)).  `databases`: the header dicts of
+    pyratbay_amd.tli.read_tli (keys temperatures[ntemp], partition[niso, ntemp]); isotopes are
+    numbered over the concatenated databases, as the line list's isotope index is."""
+
+    def __init__(self, databases):
+        require_gpu()
+        self.tables = []
+        self.niso = 0
+        for db in databases:
+            t = np.ascontiguousarray(db['temperatures'], float)
+            pf = np.ascontiguousarray(np.atleast_2d(db['partition']), float)
+            if t.size < 2 or pf.shape[1] != t.size or np.any(np.diff(t) <= 0):
+                raise ValueError('partition-function table: temperatures must be strictly '
+                                 'ascending (at least two) and match partition[niso, ntemp]')
+            self.tables.append((dev(t), dev(pf), self.niso, pf.shape[0]))
+            self.niso += pf.shape[0]
+        self._nbad = torch.zeros(1, dtype=torch.int32, device='cuda')
+
+    def evaluate(self, temp, out=None, check=True):
+        """temp: device tensor of any shape [...] -> Z[niso, ...] (float64, device).  check=True
+        waits for the kernel and raises ValueError for a temperature outside a table, like
+        interp1d; check=False leaves NaN in those places and does not synchronise (a batch of
+        walkers whose out-of-range members the caller rejects by their NaN spectra)."""
+        temp = temp.contiguous()
+        n = temp.numel()
+        if out is None:
+            out = torch.empty((self.niso,) + tuple(temp.shape), dtype=torch.float64,
+                              device=temp.device)
+        assert out.is_contiguous() and out.numel() == self.niso * n
+        if check:
+            self._nbad.zero_()
+        for ttab, pf, first, niso in self.tables:
+            call('pb_iso_partition', out.data_ptr() + 8 * first * n, n, 1, _ptr(temp), n,
+                 _ptr(ttab), ttab.numel(), _ptr(pf), niso, _ptr(self._nbad) if check else None,
+                 _stream())
+        if check and int(self._nbad.item()) > 0:
+            lo = max(float(t[0][0]) for t in self.tables)
+            hi = min(float(t[0][-1]) for t in self.tables)
+            raise ValueError('A value in the temperature profile lies outside the partition-'
+                             f'function tables ({lo} - {hi} K)')
+        return out
+
+
+# --------------------------------------------------------------------------
 # LBL extinction
 # --------------------------------------------------------------------------
 class LBL:
@@ -812,6 +862,9 @@ class LBLSpectrum:
         self.ec = torch.empty((self.nlayers, 1, self.wcount), dtype=torch.float64,
                               device='cuda')
         self.depth = self.ideep = self.spectrum = None
+        # the TLI file's partition-function tables (from_tli): set_atmosphere() without `isoz`
+        # evaluates them at the new temperatures on the device
+        self.partition = None
         # a [wcount] tensor the transit spectrum is written to instead of a fresh one (the shard's
         # slot of a gather buffer: dist.SpectrumGather(uniform=True))
         self.spectrum_out = None
@@ -819,15 +872,94 @@ class LBLSpectrum:
         # extinction of a wavenumber shard to its two-phase form (dist.kmax_allreduce)
         self.kmax_exchange = None
 
-    def set_atmosphere(self, temp, dens, isoz, radius=None, continuum_density=None):
+    @classmethod
+    def from_tli(cls, tlifiles, atm, grid, *, nlor=100, ndop=50, extent=300.0, cutoff=25.0,
+                 dlratio=0.1, lorentz=None, doppler=None, tmin=100.0, tmax=3000.0,
+                 ethresh=1e-30, maxdepth=10.0, skip_species=(), **kw):
+        """TLI file(s) + atmosphere + spectral grid -> a model ready to run(): what
+        Line_By_Line.__init__ / Voigt.__init__ assemble before the reference's first extinction
+        call (pyratbay/pyrat/line_by_line.py:120-200, pyrat/voigt.py:20-149), with nothing taken
+        from a fixture -- lines and isotope data from the file(s) (tli.read_tli on the grid's
+        range, databases concatenated in file order), isotope -> species indices by molecule
+        name, Z_i(T_layer) by tli's restatement of the reference's interp1d, Voigt width grids
+        from the atmosphere (or given: the reference's voigt_dmin/dmax/lmin/lmax keys).
+
+        atm: dict with temp[L], dens[L, nspecies] (cm-3), radius[L], press[L] (bar; for the width
+        grids), species (names), mol_mass, mol_radius (cm), rstar.  grid: synth.spectral_grid /
+        resolution_grid (wn, own, ownstep, onwave, wnosamp, divisors)."""
+        from . import synth, tli
+        paths = [tlifiles] if isinstance(tlifiles, (str, bytes, os.PathLike)) else list(tlifiles)
+        species = list(atm['species'])
+        dbs, lwn, gf, elow, lid = [], [], [], [], []
+        niso = 0
+        for path in paths:
+            d, wn_, gf_, el_, _, meta = tli.read_tli(path, float(grid['wn'][0]),
+                                                      float(grid['wn'][-1]))
+            dbs += d
+            lwn.append(wn_); gf.append(gf_); elow.append(el_)
+            lid.append(meta['iso_global'].astype(np.int32) + niso)
+            niso += sum(len(db['isotopes']) for db in d)
+        isoimol, isomass, isoratio = [], [], []
+        for db in dbs:
+            if db['molecule'] not in species:
+                raise ValueError(f"The species '{db['molecule']}' is not present in the "
+                                 'atmosphere, required for LBL calculation')
+            isoimol += [species.index(db['molecule'])] * len(db['isotopes'])
+            isomass += list(db['iso_mass'])
+            isoratio += list(db['iso_ratio'])
+        isoimol = np.asarray(isoimol, np.int32)
+        # rows of the un-added extinction: one per line-carrying species, in np.unique's order
+        # (line_by_line.py:177-188); skip_species flags their isotopes -1 (extinction.py:165-168)
+        carriers = sorted({species[i] for i in isoimol})
+        isoiext = np.asarray([carriers.index(species[i]) for i in isoimol], np.int32)
+        for name in skip_species:
+            if name in carriers:
+                isoiext[isoiext == carriers.index(name)] = -1
+        iso = dict(isoimol=isoimol, isomass=np.asarray(isomass, float),
+                   isoratio=np.asarray(isoratio, float), isoiext=isoiext,
+                   isoz=tli.iso_partition(dbs, atm['temp']))
+        if lorentz is None or doppler is None:
+            used = np.unique(isoimol)
+            lor, dop = synth.voigt_widths(grid['wn'], atm['press'],
+                                          np.asarray(atm['mol_mass'])[used],
+                                          np.asarray(atm['mol_radius'])[used], nlor, ndop,
+                                          tmin, tmax)
+            lorentz = lor if lorentz is None else lorentz
+            doppler = dop if doppler is None else doppler
+        lorentz, doppler = np.asarray(lorentz, float), np.asarray(doppler, float)
+        size = synth.voigt_sizes(lorentz, doppler, extent, cutoff, grid['ownstep'],
+                                 grid['onwave'], dlratio)
+        atm = dict(atm)
+        atm['nlayers'] = len(atm['temp'])
+        case = dict(grid=grid, atm=atm, iso=iso,
+                    lines=dict(lwn=np.concatenate(lwn), elow=np.concatenate(elow),
+                               gf=np.concatenate(gf), lid=np.concatenate(lid)),
+                    voigt=dict(lorentz=lorentz, doppler=doppler, size=size, extent=extent,
+                               cutoff=cutoff, dlratio=dlratio),
+                    ethresh=ethresh, maxdepth=maxdepth)
+        model = cls(case, **kw)
+        model.partition = PartitionTable(dbs)
+        model.databases = dbs
+        return model
+
+    def set_atmosphere(self, temp, dens, isoz=None, radius=None, continuum_density=None):
         """New temperature / number-density / partition-function (and radius) profiles for the
-        next run().  With a Continuum attached pass its number densities {species: n[L]} too:
-        every opacity term of the next run then sees the SAME atmosphere."""
+        next run().  isoz=None (models made by from_tli): Z_i(T) is interpolated from the file's
+        tables at the new temperatures on the device, as the reference does on every extinction
+        call (line_by_line.py:219-222); a temperature outside a table raises ValueError.  With a
+        Continuum attached pass its number densities {species: n[L]} too: every opacity term of
+        the next run then sees the SAME atmosphere."""
         self.temp_host = np.array(temp.cpu().numpy() if isinstance(temp, torch.Tensor) else temp,
                                   float)
         self.temp.copy_(dev(temp))
         self.dens.copy_(dev(dens))
-        self.isoz.copy_(dev(isoz))
+        if isoz is not None:
+            self.isoz.copy_(dev(isoz))
+        elif self.partition is not None:
+            self.partition.evaluate(self.temp, out=self.isoz)
+        else:
+            raise _capi.PbError('set_atmosphere: pass isoz[niso, L] (this model has no '
+                                'partition-function tables: it was not made by from_tli)')
         if continuum_density is not None:
             self.continuum_density = continuum_density
         elif self.continuum is not None:

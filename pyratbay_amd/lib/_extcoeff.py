@@ -14,7 +14,13 @@ _cache = {}
 _seen = {}                         # buffer identity -> (content digest, probe digest)
 
 _FULL_HASH_BYTES = 256 << 20       # arrays up to this size are hashed in full
-_SMALL_BYTES = 64 << 10            # arrays up to this size are hashed in full on EVERY call
+# arrays up to this size are hashed in full on EVERY call: the line-list arrays (lwn, elow, gf,
+# lID: 8 MB each at 1e6 lines, ~0.5 ms at xxh3's 15 GB/s), the width grids, the species data.  The
+# reference re-reads its inputs on every call, so an in-place edit of ANY element of them (a few
+# gf values scaled, two lines swapped) must change the result -- a strided probe cannot promise
+# that.  Only the genuinely huge arrays (`own`: 144 MB at C2, the Voigt table: GBs) are
+# identified by buffer identity + a probe.
+_SMALL_BYTES = 32 << 20
 _PROBE_ELEMS = 8192                # elements of the per-call probe of a known buffer (64 KiB)
 _SEEN_MAX = 64
 
@@ -62,22 +68,38 @@ def _probe(a):
     return _hash(_bytes(flat[idx]), _bytes(flat[np.arange(64)]), _bytes(flat[np.arange(n - 64, n)]))
 
 
+def _frozen(a):
+    """True when nothing can write to the buffer through NumPy: the array and every array it
+    is a view of are read-only (a read-only view of a writeable array is not frozen)."""
+    while isinstance(a, np.ndarray):
+        if a.flags.writeable:
+            return False
+        a = a.base
+    return a is None or isinstance(a, bytes)
+
+
 def _content_key(a):
     """(shape, content digest) of a caller's array, cheap for a buffer seen before.
 
     The reference re-reads its inputs on every call; a device cache must notice when they
-    change.  Hashing them in full on every layer call cost 8.5 ms per call at C2 (`own` alone
-    is 144 MB).  Now: a buffer is identified by (address, shape, strides, dtype); the first
+    change.  Hashing everything in full on every layer call cost 8.5 ms per call at C2 (`own`
+    alone is 144 MB).  Now: arrays of up to 32 MiB -- every line-list array up to 4e6 lines --
+    are hashed in full every time (an edit of a few gf values must be seen).
+    A larger buffer is identified by (address, shape, strides, dtype, writeable); the first
     time it is hashed in full, afterwards only a 64-KiB strided probe of it is -- when the
     probe differs (an in-place edit, or another array at a recycled address) the full hash is
-    taken again.  Arrays of up to 64 KiB are hashed in full every time.  An in-place edit
-    that misses every probed element is not seen: call invalidate() after such an edit."""
+    taken again; a read-only buffer (no writeable array anywhere in its base chain) is
+    trusted by identity alone.  An in-place edit of such a huge WRITEABLE array (`own`, the
+    Voigt table) that misses every probed element is not seen: call invalidate() after it."""
     a = np.asarray(a)
     if a.nbytes <= _SMALL_BYTES:
         return a.shape, _hash(_bytes(a))
-    ident = (a.__array_interface__['data'][0], a.shape, a.strides, a.dtype.str)
-    probe = _probe(a)
+    frozen = _frozen(a)
+    ident = (a.__array_interface__['data'][0], a.shape, a.strides, a.dtype.str, frozen)
     ent = _seen.get(ident)
+    if frozen and ent is not None:
+        return a.shape, ent[0]
+    probe = _probe(a)
     if ent is not None and ent[1] == probe:
         return a.shape, ent[0]
     digest = _digest(a)

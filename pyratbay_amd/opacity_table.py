@@ -108,20 +108,30 @@ def _wn_mask(wn, wn_min, wn_max, tol=1.0e-8):
 
 
 def _brackets(x_table, x_new):
-    """Lower node and weight of the upper node of every x_new in the ascending x_table; values
-    beyond the table take its end node with weight 0 (constant extrapolation, the reference's
-    fill_value)."""
+    """(perm, lo, a): the permutation that sorts x_table ascending, and for every x_new the lower
+    node IN THE SORTED TABLE and the weight of the node above it.  The reference resamples with
+    scipy's interp1d(assume_sorted=False, fill_value=(y[first], y[last])) (tools.py:1086-1104):
+    a descending or unsorted tabulated axis is sorted first, and a value beyond the table takes
+    the table's FIRST entry in FILE order when below the smallest node and its LAST entry in
+    file order when above the largest one (the end nodes themselves for an ascending file)."""
     x_table, x_new = np.asarray(x_table, float), np.asarray(x_new, float)
-    if np.any(np.diff(x_table) <= 0):
-        raise ValueError('tabulated grid must be strictly ascending')
-    lo = np.clip(np.searchsorted(x_table, x_new, side='right') - 1, 0, len(x_table) - 1)
-    lo = np.where(x_new >= x_table[-1], len(x_table) - 1, lo)
-    hi = np.minimum(lo + 1, len(x_table) - 1)
-    span = x_table[hi] - x_table[lo]
+    perm = np.argsort(x_table, kind='stable')
+    xs = x_table[perm]
+    if np.any(np.diff(xs) <= 0):
+        raise ValueError('tabulated grid holds a value twice')
+    n = len(xs)
+    inv = np.empty(n, np.intp)
+    inv[perm] = np.arange(n)                          # sorted position of every file entry
+    lo = np.clip(np.searchsorted(xs, x_new, side='right') - 1, 0, n - 1)
+    lo = np.where(x_new >= xs[-1], n - 1, lo)
+    hi = np.minimum(lo + 1, n - 1)
+    span = xs[hi] - xs[lo]
     with np.errstate(divide='ignore', invalid='ignore'):
-        a = np.where(span > 0, (x_new - x_table[lo]) / span, 0.0)
-    a = np.where((x_new <= x_table[0]) | (x_new >= x_table[-1]), 0.0, a)
-    return lo.astype(np.int32), a
+        a = np.where(span > 0, (x_new - xs[lo]) / span, 0.0)
+    a = np.where((x_new <= xs[0]) | (x_new >= xs[-1]), 0.0, a)
+    lo = np.where(x_new < xs[0], inv[0], lo)          # fill_value[0] = the file's first entry
+    lo = np.where(x_new > xs[-1], inv[n - 1], lo)     # fill_value[1] = the file's last entry
+    return perm, lo.astype(np.int32), a
 
 
 class CrossSections:
@@ -187,10 +197,15 @@ def load_cross_sections(cs_files, temperature=None, pressure=None, min_wn=None, 
         resample_t = len(ttab) != len(temp) or np.any(np.abs(1.0 - ttab / temp) > 0.01)
         resample = bool(resample_p or resample_t)
         if resample:
-            plo, pa = _brackets(np.log(ptab), np.log(press)) if resample_p else (
-                np.arange(len(press), dtype=np.int32), np.zeros(len(press)))
-            tlo, ta = _brackets(ttab, temp) if resample_t else (
-                np.arange(len(temp), dtype=np.int32), np.zeros(len(temp)))
+            pperm, plo, pa = _brackets(np.log(ptab), np.log(press)) if resample_p else (
+                None, np.arange(len(press), dtype=np.int32), np.zeros(len(press)))
+            tperm, tlo, ta = _brackets(ttab, temp) if resample_t else (
+                None, np.arange(len(temp), dtype=np.int32), np.zeros(len(temp)))
+            # a descending / unsorted tabulated axis: the brackets index the SORTED table
+            if pperm is not None and np.any(np.diff(pperm) != 1):
+                cs = cs[:, pperm]
+            if tperm is not None and np.any(np.diff(tperm) != 1):
+                cs = cs[tperm]
         else:
             plo, pa = np.arange(len(press), dtype=np.int32), np.zeros(len(press))
             tlo, ta = np.arange(len(temp), dtype=np.int32), np.zeros(len(temp))

@@ -164,3 +164,38 @@ def read_tli(path, wn_low=-np.inf, wn_high=np.inf, strict=False):
     meta = dict(wn_min=file_wn_min, wn_max=file_wn_max, version=ver, n_lines=n_lines,
                 lines_per_isotope=per_iso, iso_global=iso_global)
     return databases, wn, gf, elow, iso_id, meta
+
+
+def _slinear(ttab, pf, temperature):
+    """scipy.interpolate.interp1d(ttab, pf, kind='slinear')(temperature) restated: the
+    first-order B-spline as SciPy's de Boor recurrence evaluates it (w = 1/(t_hi - t_lo), basis
+    w (t_hi - T) and w (T - t_lo), interval t_lo <= T < t_hi with the last one closed) -- bit
+    for bit -- and interp1d's error for a temperature outside the table."""
+    ttab = np.asarray(ttab, float)
+    pf = np.atleast_2d(np.asarray(pf, float))
+    x = np.asarray(temperature, float)
+    if ttab.size < 2:
+        raise ValueError('a partition-function table needs at least two temperatures')
+    if np.any(x < ttab[0]):
+        raise ValueError("A value in the temperature profile is below the partition-function "
+                         f"table's minimum temperature ({ttab[0]} K)")
+    if np.any(x > ttab[-1]):
+        raise ValueError("A value in the temperature profile is above the partition-function "
+                         f"table's maximum temperature ({ttab[-1]} K)")
+    lo = np.clip(np.searchsorted(ttab, x, 'right') - 1, 0, ttab.size - 2)
+    xa, xb = ttab[lo], ttab[lo + 1]
+    w = 1.0 / (xb - xa)
+    return pf[:, lo] * (w * (xb - x)) + pf[:, lo + 1] * (w * (x - xa))
+
+
+def iso_partition(databases, temperature):
+    """Partition function of every isotope of the file (concatenated over its databases, the
+    order of read_tli's iso_id) at the layer temperatures: [niso_total, nlayers].
+
+    Reference: Line_By_Line.__init__ builds scipy.interpolate.interp1d(db.temp, db.iso_pf[j],
+    kind='slinear') per isotope (pyratbay/pyrat/line_by_line.py:156-158) and
+    calc_extinction_coefficient evaluates them at the temperature profile on EVERY call
+    (:219-222) -- an LBL retrieval changes T each time.  Piecewise linear in T per isotope;
+    a temperature outside a database's table raises ValueError like interp1d does."""
+    return np.concatenate([_slinear(db['temperatures'], db['partition'], temperature)
+                           for db in databases], axis=0)

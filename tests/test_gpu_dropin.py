@@ -229,6 +229,9 @@ def test_extinction_cache_sees_in_place_edits(hip, monkeypatch):
     buffer must not be re-hashed, and a different array of equal content must hit the cache."""
     mod = hip._extcoeff
     mod.invalidate()
+    # (the probe mechanics are exercised on this small case by lowering the size from which
+    # buffers are probed instead of hashed in full; the default is 32 MiB)
+    monkeypatch.setattr(mod, '_SMALL_BYTES', 64 << 10)
     case, profile, psize, pindex = _dropin_case()
     full = []
     real_digest = mod._digest
@@ -258,6 +261,44 @@ def test_extinction_cache_sees_in_place_edits(hip, monkeypatch):
     np.testing.assert_allclose(tripled[nz], 6.0 * base[nz], rtol=1e-12)
     mod.invalidate()
     assert not mod._seen and not mod._cache
+
+
+def test_extinction_cache_sees_a_single_edited_line(hip):
+    """with the default thresholds the line-list arrays are hashed in full on
+    every call, so an in-place edit of ONE element that no strided probe would visit (here
+    element 12 345 of gf, then two swapped lines) changes the result like in the reference,
+    which re-reads its inputs on every call.  A read-only huge buffer is trusted by identity."""
+    mod = hip._extcoeff
+    mod.invalidate()
+    case, profile, psize, pindex = _dropin_case()
+    ln = case['lines']
+    probed = set(np.linspace(0, ln['gf'].size - 1, mod._PROBE_ELEMS).astype(int)[1:-1])
+    i = next(j for j in range(12345, 13000) if j not in probed)
+    base = _dropin_call(hip, case, profile, psize, pindex, 1)
+    ln['gf'][i] *= 1e6                                    # one line, in place
+    edited = _dropin_call(hip, case, profile, psize, pindex, 1)
+    assert not np.array_equal(edited, base)
+    ln['gf'][i] /= 1e6
+    assert np.array_equal(_dropin_call(hip, case, profile, psize, pindex, 1), base)
+    j = i + 1                                             # swap the strengths of two lines
+    ln['gf'][[i, j]] = ln['gf'][[j, i]]
+    ln['elow'][[i, j]] = ln['elow'][[j, i]]
+    swapped = _dropin_call(hip, case, profile, psize, pindex, 1)
+    assert not np.array_equal(swapped, base)
+    # frozen buffers: identity is enough (no probe, no re-hash)
+    big = np.arange(5 << 20, dtype=float)                 # 40 MiB > 32 MiB
+    big.setflags(write=False)
+    view = big[:]
+    assert mod._frozen(view) and not mod._frozen(np.arange(4.0)[:2])
+    k1 = mod._content_key(view)
+    calls = []
+    real = mod._probe
+    mod._probe = lambda a: (calls.append(1), real(a))[1]
+    try:
+        assert mod._content_key(view) == k1 and not calls
+    finally:
+        mod._probe = real
+    mod.invalidate()
 
 
 def test_extinction_cache_without_xxhash(hip, monkeypatch):

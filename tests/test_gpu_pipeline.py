@@ -399,6 +399,36 @@ def test_stage_timestamps_like_the_reference(eng, case, rt_path):
     assert list(model.timestamps) == ['extinction', 'odepth', 'spectrum']
 
 
+def test_finished_timer_ignores_later_calls_and_captures(eng, case):
+    """a fused transit call marks its internal 'odepth' boundary on the timer
+    the calling thread started last.  A run that has FINISHED must not collect the boundaries of
+    later calls (a timestamps=False model, a direct engine.transit_spectrum): its values stay
+    what they were.  And a run captured into a HIP graph records no timer events at all -- the
+    timestamps of the last eager run remain readable after capture() and replay()."""
+    import torch
+    model = eng.LBLSpectrum(case, rt_path='transit')
+    model.run()
+    model.run()
+    before = dict(model.timestamps)
+    assert list(before) == ['extinction', 'odepth', 'spectrum']
+    other = eng.LBLSpectrum(case, rt_path='transit', voigt=model.voigt, lines=model.lines,
+                            timestamps=False)
+    for _ in range(3):
+        other.run()
+    eng.transit_spectrum(model.ec.view(model.nlayers, model.wcount), model.raypath, model.radius,
+                         model.rstar, model.itop, model.nlayers, model.maxdepth)
+    torch.cuda.synchronize()
+    assert dict(model.timestamps) == before
+    replay = model.capture()                    # one eager run, one warm-up, one captured run
+    eager = dict(model.timestamps)
+    assert list(eager) == ['extinction', 'odepth', 'spectrum'] and all(v > 0 for v in eager.values())
+    want = model.spectrum.clone()
+    out = replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out, want)
+    assert dict(model.timestamps) == eager
+
+
 def test_stage_timer_api(eng):
     """The C-ABI timer on its own: stages in order, duplicates summed, errors for a timer that
     was not started or is full."""

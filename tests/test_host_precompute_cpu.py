@@ -34,3 +34,39 @@ def test_default_quadrature_is_the_reference_raygrid():
     assert np.array_equal(mu, np.cos(raygrid))
     assert np.array_equal(w, np.pi * (np.sin(bounds[1:])**2 - np.sin(bounds[:-1])**2))
     np.testing.assert_allclose(w.sum(), np.pi, rtol=1e-15)
+
+
+def test_partition_function_from_the_tli_table_equals_the_reference_run(golden):
+    """a11, the piece missing until round 4: Z_i(T_layer) from the TLI file's table
+    (line_by_line.py:156-158 interp1d(kind='slinear'), :219-222 evaluated per extinction call).
+    The reference-written mock H2O file's table at G6's layer temperatures must give G6's
+    `iso_pf` -- what the reference's own run handed to _extcoeff.extinction -- bit for bit."""
+    import os
+    import pytest
+    from pyratbay_amd import tli
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+    dbs = tli.read_tli(os.path.join(here, 'g13_mock_h2o.tli'))[0]
+    for rt in ('transit', 'emission'):
+        g = golden(f'g6_e2e_{rt}')
+        z = tli.iso_partition(dbs, g['temp'])
+        assert z.shape == g['iso_pf'].shape
+        np.testing.assert_allclose(z, g['iso_pf'], rtol=1e-15, atol=0)
+        assert np.array_equal(z, g['iso_pf'])
+    # on the nodes and at both ends of the table: the node values themselves (to an ulp: the
+    # de Boor weights are w*(t_hi - t_lo), not exactly 1)
+    t = dbs[0]['temperatures']
+    z = tli.iso_partition(dbs, t)
+    np.testing.assert_allclose(z, dbs[0]['partition'], rtol=4e-16)
+    # SciPy itself, where importable (it is in this image): same bits on random temperatures
+    sip = pytest.importorskip('scipy.interpolate')
+    x = np.random.default_rng(5).uniform(t[0], t[-1], 4000)
+    want = np.array([sip.interp1d(t, row, kind='slinear')(x) for row in dbs[0]['partition']])
+    assert np.array_equal(tli.iso_partition(dbs, x), want)
+    # outside the table interp1d raises ValueError: so does the restatement
+    for bad in (t[0] - 1e-9, t[-1] + 1e-9):
+        with pytest.raises(ValueError):
+            tli.iso_partition(dbs, [500.0, bad])
+    # two databases with their own temperature grids: isotopes concatenated in file order
+    dbs2 = tli.read_tli(os.path.join(here, 'g13_two_db.tli'))[0]
+    z2 = tli.iso_partition(dbs2, [300.0, 1234.5])
+    assert z2.shape[0] == sum(len(d['isotopes']) for d in dbs2)
