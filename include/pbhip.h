@@ -142,7 +142,12 @@ int pb_lbl_set_ethresh(pb_lbl *p, double ethresh);
  *       the resident-profile kernel; the others run the LDS-staged kernel when several lines
  *       share a phase row of a tile, else the global gather;
  *   1 = global gather only, 2 = LDS-staged only (falls back to 1 when a phase row does not
- *       fit in LDS), 3 = resident-profile kernel where it applies + global gather.
+ *       fit in LDS), 3 = resident-profile kernel where it applies + global gather,
+ *   7 = the LDS-staged kernel + the wave-autonomous kernel (pb_wave.hip) for the layers whose
+ *       phase rows are at most 384 samples long (the Doppler-core layers of an atmosphere):
+ *       wavefronts split a tile's phase rows between them instead of its samples, no workgroup
+ *       barrier per row.  Opt-in: at BASELINE config 2 the pair is slower than the staged kernel
+ *       alone (1.20 against 1.05 ms per extinction, profiles/r04_gather_wave.md).
  * All sum the same terms; only the order differs (global, resident: isotope, position;
  * staged: isotope, phase, position).  In mode 0 the choice depends on the size of the launch
  * (layers x samples); with a fixed mode every tiling and sharding adds the same terms in the
@@ -161,7 +166,7 @@ int pb_lbl_set_ethresh(pb_lbl *p, double ethresh);
  * Two-phase shard calls of such a plan use the direct gather.
  * last_gather_mode reports what the last call ran: 1 global, 2 staged, 3 resolution mode (direct
  * gather), 6 resolution mode through dynamic grids, plus 8 when the resident-profile kernel ran
- * as well. */
+ * as well, plus 16 when the wave-autonomous kernel took the short-row layers. */
 int pb_lbl_set_gather_mode(pb_lbl *p, int mode);
 int pb_lbl_last_gather_mode(const pb_lbl *p, int *mode);
 /* Hint: the caller keeps n independent calls in flight on n streams (the reference's callers
@@ -198,6 +203,10 @@ int pb_lbl_last_state(pb_lbl *p, int32_t *ofactor_h, double *kmax_h, int nlayers
  * profile block each layer can select (block_h[nlayers]).  Synchronises the stream. */
 int pb_lbl_last_layer_kinds(pb_lbl *p, int32_t *resident_h, int32_t *block_h, int nlayers,
                             void *stream);
+/* Which layers of the last call the wave-autonomous kernel computed (wave_h[nlayers], 0/1: the
+ * layers whose longest phase row is at most 384 samples; all 0 when that kernel was off).
+ * Synchronises the stream. */
+int pb_lbl_last_wave_layers(pb_lbl *p, int32_t *wave_h, int nlayers, void *stream);
 /* The same call in two halves, for wavenumber shards on several GPUs.  _begin derives the layer
  * state and the records of the groups within reach of the shard, with the per-row maxima
  * (_extcoeff.c:203-226) over THOSE groups only -- 1/N of the exp() work; the caller then

@@ -15,6 +15,11 @@ constexpr int kStagePad = 256;       // zero samples on either side of a staged 
 constexpr int kStageSpan = 256;      // samples per wavefront and sub-tile (4 chunks of 64)
 constexpr int kStageRowMax = 1024;   // longest phase row the staged kernels keep in one piece
 
+// wave-autonomous gather (pb_wave.hip): output samples per workgroup (every wavefront keeps all
+// of them) and the longest phase row / window it stages (three LDS-DMA pieces of 128 samples)
+constexpr int kWvTile = 2048;
+constexpr int kWvRowMax = 384;
+
 struct VRec;
 struct VSeg;
 struct UnitHdr;
@@ -90,6 +95,10 @@ struct LblArgs {
     int32_t *ls_resident;
     int32_t *ls_block;                // largest phase-major profile block of the layer (doubles)
     int res_cap;
+    // wave-autonomous kernel (pb_wave.hip): layers whose longest phase row is at most wave_cap
+    // samples are its (ls_wave, decided by k_layer_state; 0 = kernel off) and skipped by the staged one
+    int32_t *ls_wave;
+    int wave_cap;
     const int32_t *gs_start;          // [niso][nwave+1]
     // scatter kernel: one 32-byte record per (layer, position-sorted group)
     struct Rec32 *rec32;
@@ -170,6 +179,8 @@ struct LblArgs {
 size_t rounds_prep_lds(const LblArgs &a);
 void rounds_geometry(int geom, int *tile, int *rbuf);
 int rounds_launch(const LblArgs &a, int geom, hipStream_t s);
+size_t wave_lds(const LblArgs &a);
+int wave_launch(LblArgs a, int nunits, hipStream_t s);
 
 
 // first index in [lo,hi) with a[idx] >= v

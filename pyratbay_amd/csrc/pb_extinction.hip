@@ -70,6 +70,7 @@ __global__ __launch_bounds__(64) void k_layer_state(LblArgs a)
 {
     __shared__ unsigned long long s_minwidth;
     __shared__ int s_block;          // largest phase-major profile block any isotope can use
+    __shared__ int s_rowmax;         // longest phase row any isotope can select
     // the width grids and the divisors are searched serially by one or a few lanes: one
     // parallel copy into LDS first turns ~40 dependent global loads into LDS reads (the
     // kernel is on the critical path of every spectrum)
@@ -89,6 +90,7 @@ __global__ __launch_bounds__(64) void k_layer_state(LblArgs a)
     if (threadIdx.x == 0) {
         s_minwidth = __double_as_longlong(1e5);
         s_block = 0;
+        s_rowmax = 0;
     }
     for (int r = threadIdx.x; r < a.nrows; r += 64)
         a.kmax_bits[(int64_t)layer * a.nrows + r] = 0ull;
@@ -123,6 +125,7 @@ __global__ __launch_bounds__(64) void k_layer_state(LblArgs a)
                 hhi = max(hhi, a.psize[ilor * a.ndop + d]);
             }
             atomicMax(&s_block, used * a.osamp);
+            atomicMax(&s_rowmax, used);
             a.li_rowmax[(int64_t)layer * a.niso + i] = used;
             a.li_hlo[(int64_t)layer * a.niso + i] = hlo;
             a.li_hhi[(int64_t)layer * a.niso + i] = hhi;
@@ -151,6 +154,9 @@ __global__ __launch_bounds__(64) void k_layer_state(LblArgs a)
         a.ls_scale[layer] = (int)round(a.wnstep / a.ownstep / ofactor);
         a.ls_resident[layer] = a.res_cap > 0 && s_block <= a.res_cap;
         a.ls_block[layer] = s_block;
+        // (a resident layer stays the resident kernel's)
+        a.ls_wave[layer] = a.wave_cap > 0 && !(a.res_cap > 0 && s_block <= a.res_cap) &&
+                           s_rowmax <= a.wave_cap;
     }
 }
 
@@ -796,7 +802,7 @@ __global__ __launch_bounds__(NW * 64, 8) void k_ext_staged(LblArgs a)
             zsplit = unit % a.nsplit;
         }
     }
-    if (layer < 0 || (a.res_cap > 0 && a.ls_resident[layer]))
+    if (layer < 0 || (a.res_cap > 0 && a.ls_resident[layer]) || (a.wave_cap > 0 && a.ls_wave[layer]))
         return;
     const int nsp = a.lsplit ? a.lsplit[layer] : a.nsplit;    // pieces of this layer's tiles
     const int row = blockIdx.y;
@@ -2100,6 +2106,7 @@ struct pb_lbl {
     int rowcap = 0;
     int32_t *ls_resident = nullptr;   // [max_layers]
     int32_t *ls_block = nullptr;      // [max_layers]
+    int32_t *ls_wave = nullptr;       // [max_layers] layers of the wave-autonomous kernel
     Rec32 *rec32 = nullptr;           // [max_layers][ngroups], scatter kernel
     Rec16 *rec16 = nullptr;           // [layers of the largest call][ngroups][nch_max], staged kernel
     size_t rec16_alloc = 0;
@@ -2471,6 +2478,7 @@ int pb_lbl_create(pb_lbl **out, pb_voigt *voigt, pb_lines *lines, const double *
     alloc((void **)&p->kmax_bits, L * (size_t)rows * 8);
     alloc((void **)&p->ls_resident, L * 4);
     alloc((void **)&p->ls_block, L * 4);
+    alloc((void **)&p->ls_wave, L * 4);
     // the whole buffer is what a multi-GPU run all-reduces (pb_lbl_kmax_buffer): slots beyond the
     // rows of a call must not hold whatever the allocation did
     if (rc == PB_OK && hipMemset(p->kmax_bits, 0, L * (size_t)rows * 8) != hipSuccess)
@@ -2626,7 +2634,7 @@ int pb_lbl_set_isoiext(pb_lbl *p, const int32_t *isoiext_h)
 
 int pb_lbl_set_gather_mode(pb_lbl *p, int mode)
 {
-    PB_REQUIRE(p && mode >= 0 && mode <= 6, "pb_lbl_set_gather_mode: mode must be 0..6");
+    PB_REQUIRE(p && mode >= 0 && mode <= 7, "pb_lbl_set_gather_mode: mode must be 0..7");
     PB_REQUIRE(mode != 6 || p->resolution,
                "pb_lbl_set_gather_mode: mode 6 (per-layer dynamic grids) is for `resolution` plans");
     p->gather_mode = mode;
@@ -2737,6 +2745,8 @@ static int lbl_extinction(pb_lbl *p, double *ext_d, int64_t wbegin, int64_t wcou
     a.g_lead = p->g_lead;
     a.ls_resident = p->ls_resident;
     a.ls_block = p->ls_block;
+    a.ls_wave = p->ls_wave;
+    a.wave_cap = 0;
     a.gs_start = p->gs_start;
     a.giso = l->d_giso;
     a.ngroups = l->ngroups;
@@ -2906,7 +2916,7 @@ static int lbl_extinction(pb_lbl *p, double *ext_d, int64_t wbegin, int64_t wcou
                                    (shared_chip ? p->concurrency : 1) >= 750;
     // round-staged kernel (pb_rounds.hip): rows of one piece (<= 1024 samples), packed records
     const bool rounds = can_stage && a.nch_max == 1 && packable && p->gather_mode == 5;
-    const bool staged = can_stage && (p->gather_mode == 2 || rounds ||
+    const bool staged = can_stage && (p->gather_mode == 2 || p->gather_mode == 7 || rounds ||
                                       (p->gather_mode == 0 && enough_blocks &&
                                        per_phase >= p->stage_threshold));
     const bool use_records = !p->resolution && l->ngroups > 0;
@@ -2997,6 +3007,23 @@ static int lbl_extinction(pb_lbl *p, double *ext_d, int64_t wbegin, int64_t wcou
                                                         nullptr, 0, nullptr, nullptr, 0);
         }
         a.rec16 = p->rec16;
+    }
+    // Layers of short phase rows (<= kWvRowMax samples: the Doppler-core layers) go to the
+    // wave-autonomous kernel (pb_wave.hip), decided per layer on the device by k_layer_state; the
+    // staged kernel computes the others.  Mode 7 selects the pair; modes 0 and 2 keep to the staged
+    // kernel alone.  Chunked line lists continue running sums in the staged kernel's order and
+    // keep to it.
+    {
+        // (measured at C2, round 4: the pair takes 1.20 ms per extinction against 1.05 ms for the
+        // staged kernel alone -- profiles/r04_gather_wave.md -- so mode 0 does not use it unless
+        // PB_WAVE=1 asks for it)
+        bool wave_on = staged && !rounds && !scatter && !chunked && a.rec16 != nullptr &&
+                       p->gather_mode == 7;
+        if (const char *e = getenv("PB_WAVE"))
+            wave_on = staged && !rounds && !scatter && !chunked && a.rec16 != nullptr &&
+                      (p->gather_mode == 0 || p->gather_mode == 7) && atoi(e) != 0;
+        if (wave_on && wave_lds(a) <= 160 * 1024)
+            a.wave_cap = kWvRowMax;
     }
     a.nsplit = 1;
     a.part = nullptr;
@@ -3234,7 +3261,9 @@ static int lbl_extinction(pb_lbl *p, double *ext_d, int64_t wbegin, int64_t wcou
     const bool timed = p->ev_used + 2 <= (int)p->ev.size();
     if (timed)
         PB_HIP(hipEventRecord(p->ev[p->ev_used], s));
-    p->last_gather = scatter ? 4 : (p->resolution ? 3 : rounds ? 5 : staged ? 2 : 1) + (resident ? 8 : 0);
+    p->last_gather = scatter ? 4
+                             : (p->resolution ? 3 : rounds ? 5 : staged ? 2 : 1) +
+                                   (resident ? 8 : 0) + (a.wave_cap > 0 ? 16 : 0);
     if (scatter) {
         int T = 512;
         if (const char *e = getenv("PB_SCATTER_T"))
@@ -3477,6 +3506,12 @@ static int lbl_extinction(pb_lbl *p, double *ext_d, int64_t wbegin, int64_t wcou
         if (lds > 64 * 1024)
             PB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        if (a.wave_cap > 0) {
+            // the short-row layers first: many short workgroups, then the staged kernel's long ones
+            const int rc = wave_launch(a, nunits, s);
+            if (rc != PB_OK)
+                return rc;
+        }
         kern<<<grid, kStagedThreads, lds, s>>>(a);
         if (deep > 0) {
             PB_LAUNCH_CHECK();
@@ -3847,6 +3882,18 @@ int pb_lbl_last_layer_kinds(pb_lbl *p, int32_t *resident_h, int32_t *block_h, in
     return PB_OK;
 }
 
+int pb_lbl_last_wave_layers(pb_lbl *p, int32_t *wave_h, int nlayers, void *stream)
+{
+    PB_REQUIRE(p && wave_h, "pb_lbl_last_wave_layers: null pointer");
+    PB_REQUIRE(nlayers >= 1 && nlayers <= p->max_layers, "pb_lbl_last_wave_layers: bad sizes");
+    PB_HIP(hipStreamSynchronize(pb::as_stream(stream)));
+    if (p->last_args.wave_cap > 0)
+        PB_HIP(hipMemcpy(wave_h, p->ls_wave, (size_t)nlayers * 4, hipMemcpyDeviceToHost));
+    else
+        memset(wave_h, 0, (size_t)nlayers * 4);
+    return PB_OK;
+}
+
 int pb_lbl_last_work(pb_lbl *p, int64_t work[3], void *stream)
 {
     PB_REQUIRE(p && work, "pb_lbl_last_work: null pointer");
@@ -3923,6 +3970,7 @@ void pb_lbl_destroy(pb_lbl *p)
     (void)hipFree(p->ls_scale);
     (void)hipFree(p->ls_resident);
     (void)hipFree(p->ls_block);
+    (void)hipFree(p->ls_wave);
     (void)hipFree(p->rec32);
     (void)hipFree(p->rec16);
     (void)hipFree(p->part);

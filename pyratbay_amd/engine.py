@@ -322,11 +322,13 @@ class LBL:
         call('pb_lbl_set_ethresh', self._h, float(ethresh))
 
     GATHER = {'auto': 0, 'global': 1, 'staged': 2, 'resident': 3, 'scatter': 4, 'rounds': 5,
-              'dynamic': 6}
+              'dynamic': 6, 'wave': 7}
 
     def set_gather_mode(self, mode):
-        """'auto' | 'global' | 'staged' | 'resident'; 'dynamic' (`resolution` plans: the layers'
-        dynamic grids through constant-step sub-plans).  See pbhip.h: pb_lbl_set_gather_mode."""
+        """'auto' | 'global' | 'staged' | 'resident' | 'wave' (the staged kernel + the
+        wave-autonomous kernel for the layers of short phase rows); 'dynamic' (`resolution`
+        plans: the layers' dynamic grids through constant-step sub-plans).  See pbhip.h:
+        pb_lbl_set_gather_mode."""
         call('pb_lbl_set_gather_mode', self._h, self.GATHER[mode])
         self.gather_mode = mode
 
@@ -351,6 +353,8 @@ class LBL:
         call('pb_lbl_last_gather_mode', self._h, C.byref(m))
         base = {0: None, 1: 'k_ext_resample', 2: 'k_ext_staged', 3: 'k_ext_linterp',
                 4: 'k_ext_scatter', 5: 'k_ext_rounds', 6: 'dynamic grids'}[m.value & 7]
+        if m.value & 16:
+            base = 'k_ext_wave+' + base
         return 'k_ext_resident+' + base if m.value & 8 else base
 
     def extinction(self, temp, dens, isoz, add=True, out=None, wbegin=0, wcount=None):
@@ -442,6 +446,12 @@ class LBL:
         block = np.zeros(nlayers, np.int32)
         call('pb_lbl_last_layer_kinds', self._h, hptr(resident), hptr(block), nlayers, _stream())
         return resident, block
+
+    def last_wave_layers(self, nlayers):
+        """wave[L] 0/1: the layers of the last call the wave-autonomous kernel computed."""
+        wave = np.zeros(nlayers, np.int32)
+        call('pb_lbl_last_wave_layers', self._h, hptr(wave), nlayers, _stream())
+        return wave
 
     def close(self):
         if self._h:
