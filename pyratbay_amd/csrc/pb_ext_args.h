@@ -149,6 +149,8 @@ struct LblArgs {
     int64_t *ls_dnwn;
     double *ls_dwnstep;
     double *ls_cutsteps, *ls_inv_ofactor, *ls_inv_scale;   // per-layer quotients for k_records
+    double *ls_inv_temp;              // 1 / temperature of the layer
+    double *li_invz;                  // 1 / partition function of the (layer, isotope)
     double *li_alphad, *li_dens, *li_z;
     int32_t *li_ilor, *li_hmax;
     int32_t *li_rowmax;               // longest phase row the (layer, isotope) can select

@@ -55,12 +55,26 @@ constexpr int kRecs = 4;                         // records in flight per wavefr
 static_assert(kTile <= kPmPad, "table padding must cover one tile");
 static_assert(kTile < 65536, "window coordinates are packed in 16 bits");
 
-// Line strength divided by the abundance (_extcoeff.c:219-224), same operation order.
-__device__ inline double line_strength(double ratio, double gf, double elow, double wavn,
-                                       double temp, double z)
+// x / d with inv = RN(1 / d) prepared once per layer (k_layer_state): the closing steps of the
+// division the compiler would emit -- product, exact residual, one correction -- without its
+// reciprocal refinement (3 instructions instead of ~12).  The correctly rounded quotient except
+// for divisors whose significand is all ones (Markstein): otherwise the same bits as x / d.
+__device__ __forceinline__ double quot(double x, double d, double inv)
 {
-    return pb::kSigCte * ratio * gf * exp(-pb::kExpCte * elow / temp) *
-           (1 - exp(-pb::kExpCte * wavn / temp)) / z;
+    const double q = x * inv;
+    return fma(fma(-q, d, x), inv, q);
+}
+
+// Line strength divided by the abundance (_extcoeff.c:219-224), same operation order; the three
+// divisions by per-layer values through quot(), the exponentials through pb::exp_s (the device
+// library's exp arithmetic with its coefficients in scalar registers: same bits).  k_records
+// evaluates this once per (layer, line): 2 exp + 3 divisions were 0.11 ms of every C2 spectrum.
+__device__ inline double line_strength(double ratio, double gf, double elow, double wavn,
+                                       double temp, double inv_temp, double z, double inv_z)
+{
+    return quot(pb::kSigCte * ratio * gf * pb::exp_s(quot(-pb::kExpCte * elow, temp, inv_temp)) *
+                    (1 - pb::exp_s(quot(-pb::kExpCte * wavn, temp, inv_temp))),
+                z, inv_z);
 }
 
 // ---------------------------------------------------------------------------
@@ -136,6 +150,7 @@ __global__ __launch_bounds__(64) void k_layer_state(LblArgs a)
         a.li_hmax[k] = hmax;
         a.li_dens[k] = dens[imol];
         a.li_z[k] = a.isoz[i * a.z_iso_stride + layer * a.z_layer_stride];
+        a.li_invz[k] = 1.0 / a.li_z[k];
     }
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -149,6 +164,7 @@ __global__ __launch_bounds__(64) void k_layer_state(LblArgs a)
         a.ls_dwnstep[layer] = a.ownstep * ofactor;
         a.ls_cutsteps[layer] = a.cutoff / (a.ownstep * ofactor);
         a.ls_inv_ofactor[layer] = 1.0 / (double)ofactor;
+        a.ls_inv_temp[layer] = 1.0 / temp;
         a.ls_inv_scale[layer] = 1.0 / (double)(int)round(a.wnstep / a.ownstep / ofactor);
         a.ls_dnwn[layer] = 1 + (a.onwn - 1) / ofactor;
         a.ls_scale[layer] = (int)round(a.wnstep / a.ownstep / ofactor);
@@ -170,7 +186,7 @@ __global__ __launch_bounds__(kBlock) void k_kmax(LblArgs a, int lines_per_block)
     for (int r = threadIdx.x; r < a.nrows; r += kBlock)
         s_max[r] = 0ull;
     __syncthreads();
-    const double temp = a.temp[layer];
+    const double temp = a.temp[layer], inv_temp = a.ls_inv_temp[layer];
     const int64_t begin = (int64_t)blockIdx.x * lines_per_block;
     const int64_t end = min(begin + lines_per_block, a.nlines);
     int cur_row = -1;
@@ -186,8 +202,8 @@ __global__ __launch_bounds__(kBlock) void k_kmax(LblArgs a, int lines_per_block)
         if (v < a.own0 || v > a.own_last)
             continue;
         const int64_t li = (int64_t)layer * a.niso + i;
-        const double k = line_strength(a.isoratio[i], a.gf[ln], a.elow[ln], v, temp,
-                                       a.li_z[li]);
+        const double k = line_strength(a.isoratio[i], a.gf[ln], a.elow[ln], v, temp, inv_temp,
+                                       a.li_z[li], a.li_invz[li]);
         if (row != cur_row) {
             if (cur_row >= 0)
                 atomicMax(&s_max[cur_row], (unsigned long long)__double_as_longlong(cur_max));
@@ -267,12 +283,13 @@ __device__ inline Window group_window(const LblArgs &a, double wavn, int iown, i
 
 // Co-added strength of a group (left-to-right sum of its members, _extcoeff.c:248-262)
 __device__ inline double group_strength(const LblArgs &a, int first, int count, double ratio,
-                                        double temp, double z)
+                                        double temp, double inv_temp, double z, double inv_z)
 {
-    double k = line_strength(ratio, a.gf[first], a.elow[first], a.lwn[first], temp, z);
+    double k = line_strength(ratio, a.gf[first], a.elow[first], a.lwn[first], temp, inv_temp, z,
+                             inv_z);
     for (int m = 1; m < count; m++)
         k += line_strength(ratio, a.gf[first + m], a.elow[first + m], a.lwn[first + m],
-                           temp, z);
+                           temp, inv_temp, z, inv_z);
     return k;
 }
 
@@ -540,7 +557,8 @@ __global__ __launch_bounds__(kBlock) void k_records(LblArgs a)
     // it were ~12 same-address global loads per layer in a dependent chain
     double *s_alphad = s_dop + a.ndop;                            // [kRecLayers][niso]
     double *s_z = s_alphad + kRecLayers * a.niso;
-    double *s_ratio = s_z + kRecLayers * a.niso;                  // [niso]
+    double *s_invz = s_z + kRecLayers * a.niso;
+    double *s_ratio = s_invz + kRecLayers * a.niso;               // [niso]
     int *s_ilor = reinterpret_cast<int *>(s_ratio + a.niso);      // [kRecLayers][niso]
     int *s_iext = s_ilor + kRecLayers * a.niso;                   // [niso]
     for (int e = threadIdx.x; e < kRecLayers * a.niso; e += kBlock) {
@@ -549,6 +567,7 @@ __global__ __launch_bounds__(kBlock) void k_records(LblArgs a)
             const int64_t li = (int64_t)layer * a.niso + e % a.niso;
             s_alphad[e] = a.li_alphad[li];
             s_z[e] = a.li_z[li];
+            s_invz[e] = a.li_invz[li];
             s_ilor[e] = a.li_ilor[li];
         }
     }
@@ -618,14 +637,15 @@ __global__ __launch_bounds__(kBlock) void k_records(LblArgs a)
                 if (row >= 0) {
                     const int e = i * a.niso + iso;
                     const double temp = uniform_load(a.temp, layer);
+                    const double inv_temp = uniform_load(a.ls_inv_temp, layer);
                     const double ratio = s_ratio[iso];
-                    const double z = s_z[e];
-                    k = line_strength(ratio, gf, elow, wavn, temp, z);
+                    const double z = s_z[e], inv_z = s_invz[e];
+                    k = line_strength(ratio, gf, elow, wavn, temp, inv_temp, z, inv_z);
                     lmax = k;
                     for (int m = 1; m < count; m++) {
                         const double kp = line_strength(ratio, a.gf[first + m],
                                                         a.elow[first + m], a.lwn[first + m],
-                                                        temp, z);
+                                                        temp, inv_temp, z, inv_z);
                         k += kp;
                         lmax = fmax(lmax, kp);
                     }
@@ -1901,7 +1921,8 @@ __global__ __launch_bounds__(kBlock) void k_ext_linterp(LblArgs a)
         const int ilor = a.li_ilor[li];
         const double alphad = a.li_alphad[li];
         const double ratio = a.isoratio[iso];
-        const double z = a.li_z[li];
+        const double z = a.li_z[li], inv_z = a.li_invz[li];
+        const double inv_temp = a.ls_inv_temp[layer];
         const double dens = a.li_dens[li];
         int64_t reach = a.li_hmax[li];
         if (a.cutoff > 0.0)
@@ -1922,7 +1943,7 @@ __global__ __launch_bounds__(kBlock) void k_ext_linterp(LblArgs a)
                 if (g < g1) {
                     const int first = a.gfirst[g];
                     const int iown = a.giown[g];
-                    k = group_strength(a, first, a.gcount[g], ratio, temp, z);
+                    k = group_strength(a, first, a.gcount[g], ratio, temp, inv_temp, z, inv_z);
                     if (!(k < kthresh)) {
                         if (a.add)
                             k *= dens;
@@ -2090,7 +2111,8 @@ struct pb_lbl {
     int32_t *li_rowmax = nullptr, *li_hlo = nullptr, *li_hhi = nullptr;
     int64_t *ls_dnwn = nullptr;
     double *ls_dwnstep = nullptr, *li_alphad = nullptr, *li_dens = nullptr, *li_z = nullptr;
-    double *ls_quot = nullptr;        // [3][max_layers]: cutsteps, 1/ofactor, 1/scale
+    double *ls_quot = nullptr;        // [4][max_layers]: cutsteps, 1/ofactor, 1/scale, 1/temp
+    double *li_invz = nullptr;        // [max_layers][niso] 1 / partition function
     unsigned long long *kmax_bits = nullptr;
     int kmax_rows = 0;
     // phase-sorted copy of the groups for the LDS-staged kernel
@@ -2124,6 +2146,16 @@ struct pb_lbl {
     int64_t wm_total0 = 0, wm_total1 = 0;
     int32_t *gs_start = nullptr;      // [niso][nwave+1]
     int res_cap = 0;                  // LDS doubles of one resident profile block (0 = none fits)
+    // Which layers are resident is decided on the device, per call; a plan none of whose layers
+    // ever qualifies (C2: the smallest block a layer selects is 53 820 doubles) still paid an
+    // empty launch of the resident kernel on every spectrum (7.5 us).  The host looks at the
+    // decision of the first automatic call and of every 256th one (one small synchronous copy
+    // each): while no layer qualified the resident kernel is left out (res_cap = 0 for the whole
+    // call: the staged / global kernel computes every layer).
+    int res_seen = -1;                // -1 not looked yet, 0 no resident layer, 1 some
+    uint64_t res_calls = 0;
+    bool res_on_pending = false;      // decision of a two-phase call's first half
+    bool res_look_pending = false;
     // packed (layer, group) records above this many bytes are produced and consumed in chunks of
     // the line list (pb_lbl_set_record_budget; PB_RECORD_BUDGET overrides)
     size_t record_budget = (size_t)96 << 30;
@@ -2466,7 +2498,8 @@ int pb_lbl_create(pb_lbl **out, pb_voigt *voigt, pb_lines *lines, const double *
     alloc((void **)&p->ls_scale, L * 4);
     alloc((void **)&p->ls_dnwn, L * 8);
     alloc((void **)&p->ls_dwnstep, L * 8);
-    alloc((void **)&p->ls_quot, 3 * L * 8);
+    alloc((void **)&p->ls_quot, 4 * L * 8);
+    alloc((void **)&p->li_invz, LI * 8);
     alloc((void **)&p->li_alphad, LI * 8);
     alloc((void **)&p->li_dens, LI * 8);
     alloc((void **)&p->li_z, LI * 8);
@@ -2773,6 +2806,8 @@ static int lbl_extinction(pb_lbl *p, double *ext_d, int64_t wbegin, int64_t wcou
     a.ls_cutsteps = p->ls_quot;
     a.ls_inv_ofactor = p->ls_quot + p->max_layers;
     a.ls_inv_scale = p->ls_quot + 2 * (size_t)p->max_layers;
+    a.ls_inv_temp = p->ls_quot + 3 * (size_t)p->max_layers;
+    a.li_invz = p->li_invz;
     a.li_alphad = p->li_alphad;
     a.li_dens = p->li_dens;
     a.li_z = p->li_z;
@@ -2923,8 +2958,25 @@ static int lbl_extinction(pb_lbl *p, double *ext_d, int64_t wbegin, int64_t wcou
     // layers with narrow profiles go to the resident-profile kernel (decided per layer on
     // the device, from the layer alone); the kernel chosen above computes the others
     const bool scatter = use_records && p->gs_start && p->gather_mode == 4;
-    const bool resident = use_records && !scatter && p->res_cap > 0 && p->gs_start &&
-                          (p->gather_mode == 0 || p->gather_mode == 3);
+    bool resident = use_records && !scatter && p->res_cap > 0 && p->gs_start &&
+                    (p->gather_mode == 0 || p->gather_mode == 3);
+    bool res_look = false;            // read the layers' decision back after this call
+    if (resident && p->gather_mode == 0) {
+        if (phase == 2) {
+            resident = p->res_on_pending;
+            res_look = p->res_look_pending;
+        } else {
+            hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+            const bool capturing = hipStreamIsCapturing(s, &cs) == hipSuccess &&
+                                   cs != hipStreamCaptureStatusNone;
+            const bool probe = !capturing && (p->res_seen < 0 || (p->res_calls++ & 255) == 255);
+            if (!probe && p->res_seen == 0)
+                resident = false;
+            res_look = probe && resident;
+            p->res_on_pending = resident;
+            p->res_look_pending = res_look;
+        }
+    }
     a.res_cap = resident ? p->res_cap : 0;
     a.rec32 = nullptr;
     a.rec16 = nullptr;
@@ -3113,7 +3165,7 @@ static int lbl_extinction(pb_lbl *p, double *ext_d, int64_t wbegin, int64_t wcou
             PB_HIP(hipEventRecord(p->ev[p->ev_used], s));
         const int per = kRecLayers;
         const size_t rlds = (size_t)per * a.nrows * 8 + (size_t)a.ndop * 8 +
-                            (size_t)per * a.niso * (8 + 8 + 4) + (size_t)a.niso * (8 + 4) + 16 + 8;
+                            (size_t)per * a.niso * (8 + 8 + 8 + 4) + (size_t)a.niso * (8 + 4) + 16 + 8;
         PB_REQUIRE(rlds <= 64 * 1024, "pb_lbl_extinction: %zu B of LDS for the record kernel", rlds);
         a.wm_lds = 0;
         a.nsplit = 1;
@@ -3228,7 +3280,7 @@ static int lbl_extinction(pb_lbl *p, double *ext_d, int64_t wbegin, int64_t wcou
         // in 48 KiB (niso * osamp + 1 words: the reference's default wnosamp of 2160 with 8
         // isotopes is already 69 KiB); larger maps are bisected in global memory
         const size_t rlds0 = (size_t)per * a.nrows * 8 + (size_t)a.ndop * 8 +
-                             (size_t)per * a.niso * (8 + 8 + 4) + (size_t)a.niso * (8 + 4) + 16;
+                             (size_t)per * a.niso * (8 + 8 + 8 + 4) + (size_t)a.niso * (8 + 4) + 16;
         const size_t wm_bytes = ((size_t)a.wm_n[0] + 2) * 4;
         size_t wm_cap_lds = 48 * 1024;
         if (const char *e = getenv("PB_WM_LDS_CAP"))
@@ -3549,6 +3601,12 @@ static int lbl_extinction(pb_lbl *p, double *ext_d, int64_t wbegin, int64_t wcou
             k_ext_resample<1, 4><<<grid, kBlock, 0, s>>>(a);
     }
     PB_LAUNCH_CHECK();
+    if (res_look) {
+        std::vector<int32_t> h((size_t)nlayers);
+        PB_HIP(hipMemcpyAsync(h.data(), p->ls_resident, (size_t)nlayers * 4, hipMemcpyDeviceToHost, s));
+        PB_HIP(hipStreamSynchronize(s));
+        p->res_seen = std::any_of(h.begin(), h.end(), [](int32_t v) { return v != 0; }) ? 1 : 0;
+    }
     p->last_args = a;
     // (chunked records are counted only in the one-row form with every isotope kept: the entries
     // of a skipped isotope are never written)
@@ -3984,6 +4042,7 @@ void pb_lbl_destroy(pb_lbl *p)
     (void)hipFree(p->li_alphad);
     (void)hipFree(p->li_dens);
     (void)hipFree(p->li_z);
+    (void)hipFree(p->li_invz);
     (void)hipFree(p->li_ilor);
     (void)hipFree(p->li_hmax);
     (void)hipFree(p->li_rowmax);

@@ -49,7 +49,10 @@ def test_g6_spectra_from_the_tli_file_and_the_atmosphere_alone(golden, rt):
     assert np.array_equal(c['iso']['isomass'], g['iso_mass'])
     assert np.array_equal(c['iso']['isoratio'], g['iso_ratio'])
     assert np.array_equal(c['iso']['isoz'], g['iso_pf'])
-    assert np.array_equal(c['voigt']['size'] > 0, g['size_out'] > 0)
+    # (the reference's `size_out` is vprofile.grid's OUTPUT: aliased cells filled in; the input
+    # marks them 0)
+    computed = c['voigt']['size'] > 0
+    assert np.array_equal(c['voigt']['size'][computed], g['size_out'][computed])
     spec = m.run().cpu().numpy()
     ec = m.ec.view(m.nlayers, m.wcount).cpu().numpy()
     assert np.array_equal(ec == 0, g['ec'] == 0)
@@ -106,5 +109,9 @@ def test_partition_table_for_a_batch_of_walkers(golden):
     with pytest.raises(ValueError):
         pt.evaluate(engine.dev(temps))
     z = pt.evaluate(engine.dev(temps), check=False).cpu().numpy()
-    assert np.isnan(z[:, 5, 7]).all() and np.isnan(z).sum() == pt.niso
+    # (NaN for the isotopes of the databases whose table ends below that temperature)
+    outside = np.concatenate([np.full(len(d['isotopes']), d['temperatures'][-1] < hi + 1.0)
+                              for d in dbs])
+    assert outside.any()
+    assert np.array_equal(np.isnan(z[:, 5, 7]), outside) and np.isnan(z).sum() == outside.sum()
     torch.cuda.synchronize()
