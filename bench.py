@@ -65,6 +65,30 @@ LDS_PEAK_TBS = 150.0      # MI355X_MICROARCH.md: ds_read_b64/b128 aggregate, eve
 NORTH_STAR = 'c2-1e6'     # north_star's >= 50x target configuration
 
 
+class stdout_to_stderr:
+    """File descriptor 1 -> 2 for the duration: RCCL prints a version banner to the process's
+    stdout when a communicator is created, and stdout carries exactly ONE JSON line."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self.saved = os.dup(1)
+        os.dup2(2, 1)
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        os.dup2(self.saved, 1)
+        os.close(self.saved)
+
+
+def metric_name(nwave, nlayers, w):
+    """BASELINE.json's metric with the workload's own shape: 'spectra/sec (1e5 wavenumbers x 80
+    layers)' for the headline configuration, '(1e6 wavenumbers x 120 layers)' for c4, ..."""
+    e = int(round(np.log10(max(nwave - 1, 1))))
+    n = f'1e{e}' if abs((nwave - 1) / 10.0**e - 1.0) < 0.02 else f'{nwave}'
+    grid = f", R = {w['resolution']:.0f}" if w.get('resolution') else ''
+    return f'spectra/sec ({n} wavenumbers x {nlayers} layers{grid})'
+
+
 def make_case(w):
     from pyratbay_amd import synth
     kw = {k: w[k] for k in ('species', 'vmr', 'line_species', 'resolution') if k in w}
@@ -408,6 +432,9 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-north-star', action='store_true',
                     help='skip the 1e6-line leg of the default c2 run')
+    ap.add_argument('--no-rank-projection', action='store_true',
+                    help='skip the per-rank times of the wavenumber decomposition (one-rank RCCL '
+                         'group) of the default c2 run')
     ap.add_argument('--shard', default='wavenumber', choices=['layers', 'wavenumber'],
                     help='multi-GPU decomposition `value` is taken from (pyratbay_amd/dist.py): '
                          "wavenumber = north_star's (shards + RCCL all-gather); the other one is "
@@ -415,6 +442,7 @@ def main():
     ap.add_argument('--cpu-layers', type=int, default=None,
                     help='layers of the one-core CPU leg (default: all at c2, 16 otherwise)')
     ap.add_argument('--cpu-worker', action='store_true', help=argparse.SUPPRESS)
+    ap.add_argument('--rank-worker', action='store_true', help=argparse.SUPPRESS)
     ap.add_argument('--selftest-launch', default=None, choices=['ok', 'fail'],
                     help=argparse.SUPPRESS)
     ap.add_argument('--sustain-seconds', type=float, default=3.0,
@@ -422,6 +450,8 @@ def main():
     args = ap.parse_args()
     if args.cpu_worker:
         return cpu_worker()
+    if args.rank_worker:
+        return rank_worker()
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         # plain `python bench.py --gpus N`: start the ranks ourselves (before any GPU call)
         sys.exit(self_launch(sys.argv[1:], args.gpus))
@@ -447,6 +477,12 @@ def main():
     want_cpu = world == 1 and not args.no_cpu_baseline
     if want_cpu:
         pool = CpuPool(max(1, min(host_cores() - 1, w['nlayers'])))
+    rank_proc = None
+    if world == 1 and args.workload == 'c2' and not args.no_rank_projection:
+        # (idle until this process has finished its GPU work; see rank_worker)
+        rank_proc = subprocess.Popen([sys.executable, os.path.abspath(__file__), '--rank-worker'],
+                                     stdin=subprocess.PIPE, stdout=subprocess.PIPE, text=True,
+                                     cwd=ROOT)
 
     import torch
     import torch.distributed as dist
@@ -466,9 +502,16 @@ def main():
         if rehearse:
             dist.init_process_group('gloo', rank=rank, world_size=world)
         else:
-            dist.init_process_group('nccl', rank=rank, world_size=world,
-                                    device_id=torch.device('cuda', local_rank))
+            with stdout_to_stderr():
+                dist.init_process_group('nccl', rank=rank, world_size=world,
+                                        device_id=torch.device('cuda', local_rank))
+                # (the communicator itself is created by the first collective)
+                dist.barrier()
 
+    # the process-wide side streams are made first, in one go: HIP deals streams to hardware queues
+    # in creation order, and a side stream created later (after RCCL's own streams) can land on
+    # the queue of an earlier one -- two "concurrent" spectra then run one after the other
+    engine.side_streams(4)
     case = make_case(w)
     nwave, nlayers = case['grid']['nwave'], case['atm']['nlayers']
     rt_path = w.get('rt_path', 'transit')
@@ -687,15 +730,17 @@ def main():
                 runs.pop()
     if not runs:
         raise SystemExit(f'every decomposition failed: {failed}')
-    # `value` = the faster decomposition of this run (both end in the wavenumber-sharded RT and
-    # the RCCL all-gather north_star names; they differ in how the extinction is cut); the other
-    # one is listed beside it in config.decompositions.  PB_BENCH_PRIMARY=first: the --shard one.
+    # `value` = the --shard decomposition (default: north_star's wavenumber shards + RCCL
+    # all-gather), at every N: one curve.  The other one (the extinction cut by layers) and the
+    # replicas are listed beside it in config.decompositions, never `value` -- unless
+    # PB_BENCH_PRIMARY=fastest asks for the faster sharded one (round 3's default).  A --shard
+    # decomposition that failed leaves the other one as `value` (config.value_from says which).
     primary = runs[0]
     sharded = [r_ for r_ in runs if r_['kind'] != 'replicas']
     if not sharded:
         raise SystemExit(f'every sharded decomposition failed: {failed}')
     primary = sharded[0]
-    if len(sharded) > 1 and os.environ.get('PB_BENCH_PRIMARY') != 'first':
+    if len(sharded) > 1 and os.environ.get('PB_BENCH_PRIMARY') == 'fastest':
         primary = max(sharded, key=lambda r_: r_['value'])
     model, elapsed = primary['model'], primary['elapsed']
     gather_ms, launches = primary['gather_ms'], primary['launches']
@@ -757,7 +802,7 @@ def main():
                    'all-gather' + (f", {primary['streams']} spectra in flight per rank"
                                    if pipelined else ''))
         out = {
-            'metric': 'spectra/sec (1e5 wavenumbers x 80 layers)',
+            'metric': metric_name(nwave, nlayers, w),
             'value': value, 'unit': 'spectra/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': ms_per_step, 'higher_is_better': True,
             'scaling': 'strong', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
@@ -786,19 +831,46 @@ def main():
                                    'unpipelined_ms_per_spectrum', 'parity_vs_single_gpu',
                                    'init_seconds') if k in r}
                 for r in runs] + failed
+        # GPU work of this process ends here: the north_star spectrum, then the host copies the CPU
+        # legs compare with; the rank-projection child gets the chip while the CPU legs run
+        ns = None
+        if want_cpu and args.workload == 'c2' and not args.no_north_star:
+            ns = north_star_gpu(model)
+        gpu_ec = model.ec.cpu().numpy()[:, 0] if want_cpu else None
+        gpu_spectrum = (model.spectrum.cpu().numpy()
+                        if want_cpu and rt_path == 'transit' else None)
+        torch.cuda.synchronize()
+        if rank_proc is not None:
+            rank_proc.stdin.write('go\n')
+            rank_proc.stdin.flush()
         if want_cpu:
             budget = args.cpu_layers or (nlayers if args.workload in ('c2', 'small') else 16)
-            one, many = cpu_legs(
-                case, model.voigt, pool, budget, gpu_ec=model.ec.cpu().numpy()[:, 0],
-                gpu_spectrum=model.spectrum.cpu().numpy() if rt_path == 'transit' else None,
-                rt_path=rt_path)
+            one, many = cpu_legs(case, model.voigt, pool, budget, gpu_ec=gpu_ec,
+                                 gpu_spectrum=gpu_spectrum, rt_path=rt_path)
             out['cpu_baseline'] = one
             if many:
                 out['cpu_baseline_allcores'] = many
             # north_star's target: >= 50x over the reference CPU _extcoeff + optical-depth
             # path on a 1e6-line / 1e5-wavenumber / 80-layer transmission spectrum at 1 GPU
-            if args.workload == 'c2' and not args.no_north_star:
-                out['north_star_target'] = north_star_leg(model, pool, args)
+            if ns is not None:
+                out['north_star_target'] = north_star_leg(ns, pool)
+        if rank_proc is not None:
+            try:
+                line, _ = rank_proc.communicate(timeout=300)
+                proj = json.loads(line.strip().splitlines()[-1])
+            except Exception as e:                               # noqa: BLE001
+                rank_proc.kill()
+                proj = {'error': f'{type(e).__name__}: {e}'[:300], 'ranks': {}}
+            single = {'c2': ms_per_step,
+                      NORTH_STAR: out.get('north_star_target', {}).get('gpu_ms_per_spectrum')}
+            for name, rows in proj.get('ranks', {}).items():
+                for row in rows.values():
+                    if single.get(name):
+                        # the single-GPU step (C2: two spectra in flight; 1e6 lines: one at a
+                        # time) over this rank's step: the scaling available BEFORE any byte
+                        # crosses xGMI
+                        row['speedup_before_collectives'] = single[name] / row['ms_per_spectrum']
+            out['config']['rank_projection'] = proj
         print(json.dumps(out), flush=True)
     if pool is not None:
         pool.close()
@@ -807,9 +879,48 @@ def main():
         dist.destroy_process_group()
 
 
-def north_star_leg(c2_model, pool, args):
-    """The 1e6-line x 1e5-wavenumber x 80-layer transit spectrum: GPU step time, and the
-    reference on the same box (one core on 16 sampled layers, all cores on every layer)."""
+def rank_worker():
+    """Child process of the default c2 run (started before the parent touches the GPU, idle until
+    the parent's GPU work is over): what ONE rank of an N-GPU wavenumber-sharded run costs per
+    spectrum on this one GPU -- the middle shard of N = 2, 4, 8 for C2 and for north_star's
+    1e6-line list, three spectra in flight as dist.ShardPipeline runs them, both collectives issued
+    through a one-rank RCCL group (the host-side cost and the stream structure of the real ones;
+    no byte crosses xGMI).  A process of its own: measured inside the parent, after its pipelines,
+    the same rank step took 0.23-0.26 ms instead of 0.16 (profiles/r04_summary.md)."""
+    if not sys.stdin.readline().strip():
+        return                                           # the parent went away
+    proj = {'note': 'per-rank compute + collectives through a ONE-rank RCCL group on one GPU; '
+                    'no inter-GPU traffic is measured', 'ranks': {}}
+    with stdout_to_stderr():
+        try:
+            import torch
+            import torch.distributed as dist
+            from tools import bench_rank_rccl as brr
+            torch.cuda.set_device(0)
+            os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+            os.environ['MASTER_PORT'] = str(free_port())
+            dist.init_process_group('nccl', rank=0, world_size=1,
+                                    device_id=torch.device('cuda', 0))
+            from pyratbay_amd import engine
+            voigt = None
+            for name in ('c2', NORTH_STAR):
+                rows = {}
+                for world in (2, 4, 8):
+                    r = brr.measure(world, name, 3, 200, voigt=voigt, collectives=(True,),
+                                    keep=True)
+                    ms, host = r['collectives through RCCL (one rank)']
+                    voigt = r['voigt']                   # same grid: one table for all of them
+                    rows[f'N={world}'] = {'ms_per_spectrum': ms, 'host_submission_ms': host}
+                proj['ranks'][name] = rows
+            dist.destroy_process_group()
+        except Exception as e:                           # noqa: BLE001
+            proj['error'] = f'{type(e).__name__}: {e}'[:300]
+    print(json.dumps(proj), flush=True)
+
+
+def north_star_gpu(c2_model):
+    """GPU half of the north_star leg: the 1e6-line x 1e5-wavenumber x 80-layer transit spectrum,
+    step time of one spectrum at a time."""
     import torch
     from pyratbay_amd import engine
     w = WORKLOADS[NORTH_STAR]
@@ -827,11 +938,19 @@ def north_star_leg(c2_model, pool, args):
     torch.cuda.synchronize()
     gpu_s = (time.perf_counter() - t0) / steps
     gather_ms, launches = model.lbl.timing_end()
-    one, many = cpu_legs(case, model.voigt, pool, 16, gpu_ec=model.ec.cpu().numpy()[:, 0],
-                         gpu_spectrum=model.spectrum.cpu().numpy(), rt_path='transit')
+    return dict(w=w, case=case, model=model, gpu_s=gpu_s, gather_ms=gather_ms, launches=launches,
+                ec=model.ec.cpu().numpy()[:, 0], spectrum=model.spectrum.cpu().numpy())
+
+
+def north_star_leg(ns, pool):
+    """CPU half: the reference on the same box (one core on 16 sampled layers, all cores on
+    every layer) and the comparison."""
+    w, case, model, gpu_s = ns['w'], ns['case'], ns['model'], ns['gpu_s']
+    one, many = cpu_legs(case, model.voigt, pool, 16, gpu_ec=ns['ec'],
+                         gpu_spectrum=ns['spectrum'], rt_path='transit')
     leg = {'workload': w['label'], 'gpu_ms_per_spectrum': 1e3 * gpu_s,
            'gpu_spectra_per_s': 1.0 / gpu_s, 'kernel': model.lbl.last_gather_kernel,
-           'kernel_ms': gather_ms / max(launches, 1),
+           'kernel_ms': ns['gather_ms'] / max(ns['launches'], 1),
            'cpu_baseline': one, 'cpu_baseline_allcores': many,
            'speedup_vs_1core': one['seconds_per_spectrum'] / gpu_s,
            'target_speedup': 50.0}

@@ -42,22 +42,23 @@ class OneRankGather(pbdist.SpectrumGather):
         return self.full
 
 
-def main():
-    world = int(sys.argv[1])
-    name = sys.argv[2] if len(sys.argv) > 2 else 'c2'
-    streams = int(sys.argv[3]) if len(sys.argv) > 3 else 3
-    steps = int(os.environ.get('PB_WSHARD_STEPS', '200'))
-    torch.cuda.set_device(0)
-    dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))
+def measure(world, name='c2', streams=3, steps=200, voigt=None, lines=None, collectives=(True, False),
+            log=None, prime_seconds=0.3, keep=False):
+    """ms per spectrum (and host submission ms) of rank world // 2 of `world`, `streams` spectra in
+    flight, with the collectives through the (already initialised, one-rank) RCCL group and/or
+    without them.  Returns {label: (ms_per_spectrum, host_ms_per_spectrum)}."""
     case = bench.make_case(bench.WORKLOADS[name])
     nwave = case['grid']['nwave']
     r = world // 2
-    pipe = pbdist.ShardPipeline(case, world, r, depth=streams, kmax_exchange=True,
+    pipe = pbdist.ShardPipeline(case, world, r, depth=streams, kmax_exchange=True, voigt=voigt,
+                                lines=lines,
                                 timestamps=os.environ.get('PB_TIMESTAMPS', '0') == '1')
     pipe.gathers = [OneRankGather(nwave, world, r, 'cuda', uniform=True) for _ in range(streams)]
     for m, g in zip(pipe.models, pipe.gathers):
         m.spectrum_out = g.slot if g.uniform else None
-    for label, coll in (('collectives through RCCL (one rank)', True), ('no collectives', False)):
+    out = {}
+    for coll in collectives:
+        label = 'collectives through RCCL (one rank)' if coll else 'no collectives'
         for i, m in enumerate(pipe.models):
             m.kmax_exchange = pbdist.kmax_allreduce() if coll else (lambda t: None)
         if not coll:
@@ -66,10 +67,16 @@ def main():
             pipe.gathers = [pbdist.SpectrumGather(nwave, 1, 0, 'cuda') for _ in range(streams)]
             for g, m in zip(pipe.gathers, pipe.models):   # (world 1: returns the local shard)
                 g.bounds = np.array([0, m.wcount])
-        for _ in range(4 * streams):
-            pipe.submit()
-        pipe.flush()
-        torch.cuda.synchronize()
+        # warm-up: every context's workspaces exist and the chip is at its working clocks (after an
+        # idle period the first few hundred spectra run at lower clocks)
+        tw = time.perf_counter()
+        while True:
+            for _ in range(4 * streams):
+                pipe.submit()
+            pipe.flush()
+            torch.cuda.synchronize()
+            if time.perf_counter() - tw >= prime_seconds:
+                break
         t0 = time.perf_counter()
         for _ in range(steps):
             pipe.submit()
@@ -77,9 +84,24 @@ def main():
         pipe.flush()
         torch.cuda.synchronize()
         t_all = time.perf_counter() - t0
-        print(f'{name} rank {r}/{world}, {streams} in flight, {label}: '
-              f'{1e3 * t_all / steps:.3f} ms/spectrum, host submission {1e3 * t_submit / steps:.3f} '
-              f'ms/spectrum', flush=True)
+        out[label] = (1e3 * t_all / steps, 1e3 * t_submit / steps)
+        if log:
+            log(f'{name} rank {r}/{world}, {streams} in flight, {label}: '
+                f'{1e3 * t_all / steps:.3f} ms/spectrum, host submission '
+                f'{1e3 * t_submit / steps:.3f} ms/spectrum')
+    if keep:
+        out['voigt'] = pipe.models[0].voigt
+    return out
+
+
+def main():
+    world = int(sys.argv[1])
+    name = sys.argv[2] if len(sys.argv) > 2 else 'c2'
+    streams = int(sys.argv[3]) if len(sys.argv) > 3 else 3
+    steps = int(os.environ.get('PB_WSHARD_STEPS', '200'))
+    torch.cuda.set_device(0)
+    dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))
+    measure(world, name, streams, steps, log=lambda s: print(s, flush=True))
     dist.destroy_process_group()
 
 
