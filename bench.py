@@ -428,7 +428,7 @@ def main():
     ap.add_argument('--steps', type=int, default=None,
                     help='timed steps (default 50; c5: 157 batches of 64 walkers = 1e4 evals)')
     ap.add_argument('--warmup', type=int, default=4)
-    ap.add_argument('--workload', default='c2', choices=sorted(WORKLOADS) + ['c5'])
+    ap.add_argument('--workload', default='c2', choices=sorted(WORKLOADS) + ['c5', 'c5-emission'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-north-star', action='store_true',
                     help='skip the 1e6-line leg of the default c2 run')
@@ -459,7 +459,7 @@ def main():
         if int(os.environ.get('WORLD_SIZE', '1')) != args.gpus:
             raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={os.environ.get("WORLD_SIZE")}')
         return launch_selftest(args.selftest_launch)
-    if args.workload == 'c5':
+    if args.workload in ('c5', 'c5-emission'):
         from tools import bench_c5
         return bench_c5.main(args)
     if args.steps is None:

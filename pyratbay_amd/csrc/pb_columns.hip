@@ -357,9 +357,31 @@ __device__ inline double planck_factor(double wn)
 {
     return 2 * pb::kH * pb::kLS * pb::kLS * pow(wn, 3.0);
 }
+// kt = kKB * temp and its rounded reciprocal: the same for every sample of a layer, so the
+// column kernels prepare them once per (workgroup, layer) in LDS (planck_terms) and the exponent's
+// division is pb::quot's three instructions; every kernel forms B this way (same bits)
+__device__ inline double planck_q(double factor, double wn, double kt, double inv_kt)
+{
+    return factor / (pb::exp_s(pb::quot(pb::kH * pb::kLS * wn, kt, inv_kt)) - 1.0);
+}
 __device__ inline double planck(double factor, double wn, double temp)
 {
-    return factor / (pb::exp_s(pb::kH * pb::kLS * wn / (pb::kKB * temp)) - 1.0);
+    const double kt = pb::kKB * temp;
+    return planck_q(factor, wn, kt, 1.0 / kt);
+}
+// s_kt[0 .. 2 nlayers): kKB * temp[k] and 1 / (kKB * temp[k]) of one temperature profile, then
+// 1 / mu[m] for the nmu quadrature angles (the angles themselves stay scalar loads)
+__device__ inline void planck_terms(double *s_kt, const double *temp, int nlayers,
+                                    const double *mu = nullptr, int nmu = 0)
+{
+    for (int k = threadIdx.x; k < nlayers; k += blockDim.x) {
+        const double kt = pb::kKB * temp[k];
+        s_kt[k] = kt;
+        s_kt[nlayers + k] = 1.0 / kt;
+    }
+    for (int m = threadIdx.x; m < nmu; m += blockDim.x)
+        s_kt[2 * nlayers + m] = 1.0 / mu[m];
+    __syncthreads();
 }
 
 __global__ void k_blackbody2d(double *B, const double *wn, int nwave, const double *temp,
@@ -400,7 +422,7 @@ __global__ void k_intensity(double *out, const double *tau, const int32_t *ideep
     int last = ideep[j];
     if (last > nlayers - 1)
         last = nlayers - 1;
-    const double m = mu[k];
+    const double m = mu[k], im = 1.0 / m;
     double blast = bbody[(int64_t)last * nwave + j];
     double result;
     if (last - rtop == 1) {
@@ -408,17 +430,17 @@ __global__ void k_intensity(double *out, const double *tau, const int32_t *ideep
     } else {
         double acc = 0.0;
         if (last > rtop) {
-            double eprev = pb::exp_s(-tau[(int64_t)rtop * nwave + j] / m);
+            double eprev = pb::exp_s(pb::quot(-tau[(int64_t)rtop * nwave + j], m, im));
             double bprev = bbody[(int64_t)rtop * nwave + j];
             for (int i = rtop; i < last; i++) {
-                double enext = pb::exp_s(-tau[(int64_t)(i + 1) * nwave + j] / m);
+                double enext = pb::exp_s(pb::quot(-tau[(int64_t)(i + 1) * nwave + j], m, im));
                 double bnext = bbody[(int64_t)(i + 1) * nwave + j];
                 acc += (enext - eprev) * (bnext + bprev);
                 eprev = enext;
                 bprev = bnext;
             }
         }
-        result = blast * pb::exp_s(-tau[(int64_t)last * nwave + j] / m) - 0.5 * acc;
+        result = blast * pb::exp_s(pb::quot(-tau[(int64_t)last * nwave + j], m, im)) - 0.5 * acc;
     }
     out[(int64_t)k * nwave + j] = result;
 }
@@ -428,12 +450,16 @@ __global__ void k_intensity(double *out, const double *tau, const int32_t *ideep
 // (pyrat/spectrum.py:366-377).  One thread per column, layers outermost so that
 // tau is read once; the nmu running sums live in registers.
 // ---------------------------------------------------------------------------
+template <int MU>
 __global__ void k_emission_flux(double *flux, double *intensity, const double *tau,
                                 const int32_t *ideep, const double *wn,
                                 const double *temp, const double *mu,
                                 const double *weights, int nmu, int rtop, int nlayers,
                                 int nwave, int ideep_max)
 {
+    extern __shared__ double s_kt[];        // [2][nlayers]: kKB T and its reciprocal
+    planck_terms(s_kt, temp, nlayers, mu, nmu);
+    const double *s_imu = s_kt + 2 * nlayers;
     int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= nwave)
         return;
@@ -442,23 +468,23 @@ __global__ void k_emission_flux(double *flux, double *intensity, const double *t
         last = nlayers - 1;
     const double w = wn[j];
     const double factor = planck_factor(w);
-    double acc[kMaxMu], eprev[kMaxMu];
+    double acc[MU], eprev[MU];
     double t0 = tau[(int64_t)rtop * nwave + j];
 #pragma unroll
-    for (int k = 0; k < kMaxMu; k++) {
+    for (int k = 0; k < MU; k++) {
         acc[k] = 0.0;
-        eprev[k] = k < nmu ? pb::exp_s(-t0 / mu[k]) : 0.0;
+        eprev[k] = k < nmu ? pb::exp_s(pb::quot(-t0, mu[k], s_imu[k])) : 0.0;
     }
-    double bprev = planck(factor, w, temp[rtop]);
+    double bprev = planck_q(factor, w, s_kt[rtop], s_kt[nlayers + rtop]);
     double tlast = t0;
     for (int i = rtop; i < last; i++) {
         double t = tau[(int64_t)(i + 1) * nwave + j];
-        double bnext = planck(factor, w, temp[i + 1]);
+        double bnext = planck_q(factor, w, s_kt[i + 1], s_kt[nlayers + i + 1]);
         double bsum = bnext + bprev;
 #pragma unroll
-        for (int k = 0; k < kMaxMu; k++) {
+        for (int k = 0; k < MU; k++) {
             if (k < nmu) {
-                double enext = pb::exp_s(-t / mu[k]);
+                double enext = pb::exp_s(pb::quot(-t, mu[k], s_imu[k]));
                 acc[k] += (enext - eprev[k]) * bsum;
                 eprev[k] = enext;
             }
@@ -466,18 +492,18 @@ __global__ void k_emission_flux(double *flux, double *intensity, const double *t
         bprev = bnext;
         tlast = t;
     }
-    double blast = (last > rtop) ? bprev : planck(factor, w, temp[last]);
+    double blast = (last > rtop) ? bprev : planck_q(factor, w, s_kt[last], s_kt[nlayers + last]);
     if (last <= rtop)
         tlast = tau[(int64_t)last * nwave + j];
     double total = 0.0;
 #pragma unroll
-    for (int k = 0; k < kMaxMu; k++) {
+    for (int k = 0; k < MU; k++) {
         if (k < nmu) {
             double val;
             if (last - rtop == 1)
                 val = blast;
             else
-                val = blast * pb::exp_s(-tlast / mu[k]) - 0.5 * acc[k];
+                val = blast * pb::exp_s(pb::quot(-tlast, mu[k], s_imu[k])) - 0.5 * acc[k];
             if (intensity)
                 intensity[(int64_t)k * nwave + j] = val;
             total += val * weights[k];
@@ -494,28 +520,31 @@ __global__ void k_emission_flux(double *flux, double *intensity, const double *t
 // operations in the same order as the two kernels run one after the other.
 // grid (columns, walkers); ec[nw][L][W], intervals[nw][L-1], temp[nw][L] -> flux[nw][W].
 // ---------------------------------------------------------------------------
+template <int MU>
 __global__ void k_emission_fused(double *flux, const double *ec, const double *intervals,
                                  const double *wn, const double *temp, const double *mu,
                                  const double *weights, int nmu, double maxdepth, int itop,
                                  int ibottom, int nlayers, int nwave)
 {
+    extern __shared__ double s_kt[];        // [2][nlayers]: kKB T of this walker and its reciprocal
+    const int wk = blockIdx.y;
+    planck_terms(s_kt, temp + (int64_t)wk * nlayers, nlayers, mu, nmu);
+    const double *s_imu = s_kt + 2 * nlayers;
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= nwave)
         return;
-    const int wk = blockIdx.y;
     ec += (int64_t)wk * nlayers * nwave;
     const double *h = intervals + (int64_t)wk * (nlayers - 1);
-    const double *tp = temp + (int64_t)wk * nlayers;
     const double w = wn[j];
     const double factor = planck_factor(w);
     const int rtop = itop;
-    double acc[kMaxMu], eprev[kMaxMu];
+    double acc[MU], eprev[MU];
 #pragma unroll
-    for (int k = 0; k < kMaxMu; k++) {
+    for (int k = 0; k < MU; k++) {
         acc[k] = 0.0;
-        eprev[k] = k < nmu ? pb::exp_s(-0.0 / mu[k]) : 0.0;        // depth[rtop] = 0
+        eprev[k] = k < nmu ? pb::exp_s(pb::quot(-0.0, mu[k], s_imu[k])) : 0.0;   // depth[rtop] = 0
     }
-    double bprev = planck(factor, w, tp[rtop]);
+    double bprev = planck_q(factor, w, s_kt[rtop], s_kt[nlayers + rtop]);
     double depth = 0.0, tlast = 0.0;
     double prev = ec[(int64_t)itop * nwave + j];
     int last = rtop;                                          // deepest layer seen so far
@@ -524,12 +553,12 @@ __global__ void k_emission_fused(double *flux, const double *ec, const double *i
         depth += 0.5 * h[k - 1] * (cur + prev);
         prev = cur;
         // intensity terms of the interval (k-1, k)
-        const double bnext = planck(factor, w, tp[k]);
+        const double bnext = planck_q(factor, w, s_kt[k], s_kt[nlayers + k]);
         const double bsum = bnext + bprev;
 #pragma unroll
-        for (int m = 0; m < kMaxMu; m++) {
+        for (int m = 0; m < MU; m++) {
             if (m < nmu) {
-                const double enext = pb::exp_s(-depth / mu[m]);
+                const double enext = pb::exp_s(pb::quot(-depth, mu[m], s_imu[m]));
                 acc[m] += (enext - eprev[m]) * bsum;
                 eprev[m] = enext;
             }
@@ -541,16 +570,17 @@ __global__ void k_emission_fused(double *flux, const double *ec, const double *i
             break;
     }
     // (itop == nlayers-1: no interval; the reference's loop then leaves ideep = nlayers, clipped)
-    const double blast = (last > rtop) ? bprev : planck(factor, w, tp[last]);
+    const double blast =
+        (last > rtop) ? bprev : planck_q(factor, w, s_kt[last], s_kt[nlayers + last]);
     double total = 0.0;
 #pragma unroll
-    for (int m = 0; m < kMaxMu; m++) {
+    for (int m = 0; m < MU; m++) {
         if (m < nmu) {
             double val;
             if (last - rtop == 1)
                 val = blast;
             else
-                val = blast * pb::exp_s(-tlast / mu[m]) - 0.5 * acc[m];
+                val = blast * pb::exp_s(pb::quot(-tlast, mu[m], s_imu[m])) - 0.5 * acc[m];
             total += val * weights[m];
         }
     }
@@ -1049,7 +1079,12 @@ int pb_emission_flux_deck(double *flux_d, double *intensity_d, const double *tau
         return PB_OK;
     PB_REQUIRE(flux_d && tau_d && ideep_d && wn_d && temp_d && mu_d && weights_d,
                "pb_emission_flux: null pointer");
-    k_emission_flux<<<pb::div_up(nwave, kBlock), kBlock, 0, pb::as_stream(stream)>>>(
+    if (nmu <= 8)
+        k_emission_flux<8><<<pb::div_up(nwave, kBlock), kBlock, ((size_t)2 * nlayers + kMaxMu) * 8, pb::as_stream(stream)>>>(
+        flux_d, intensity_d, tau_d, ideep_d, wn_d, temp_d, mu_d, weights_d, nmu, rtop,
+        nlayers, nwave, cloud_itop >= 0 ? cloud_itop : nlayers - 1);
+    else
+        k_emission_flux<kMaxMu><<<pb::div_up(nwave, kBlock), kBlock, ((size_t)2 * nlayers + kMaxMu) * 8, pb::as_stream(stream)>>>(
         flux_d, intensity_d, tau_d, ideep_d, wn_d, temp_d, mu_d, weights_d, nmu, rtop,
         nlayers, nwave, cloud_itop >= 0 ? cloud_itop : nlayers - 1);
     PB_LAUNCH_CHECK();
@@ -1117,7 +1152,14 @@ int pb_emission_flux_batch(double *flux_d, const double *ec_d, const double *int
                    (nlayers == 1 || intervals_d),
                "pb_emission_flux_batch: null pointer");
     dim3 grid(pb::div_up(nwave, kBlock), nwalkers);
-    k_emission_fused<<<grid, kBlock, 0, pb::as_stream(stream)>>>(
+    // (quadratures of up to 8 angles -- the default raygrid has 5 -- keep 2 x 8 running values per
+    // lane instead of 2 x 16: half the registers, twice the wavefronts per SIMD)
+    if (nmu <= 8)
+        k_emission_fused<8><<<grid, kBlock, ((size_t)2 * nlayers + kMaxMu) * 8, pb::as_stream(stream)>>>(
+        flux_d, ec_d, intervals_d, wn_d, temp_d, mu_d, weights_d, nmu, maxdepth, itop, ibottom,
+        nlayers, nwave);
+    else
+        k_emission_fused<kMaxMu><<<grid, kBlock, ((size_t)2 * nlayers + kMaxMu) * 8, pb::as_stream(stream)>>>(
         flux_d, ec_d, intervals_d, wn_d, temp_d, mu_d, weights_d, nmu, maxdepth, itop, ibottom,
         nlayers, nwave);
     PB_LAUNCH_CHECK();

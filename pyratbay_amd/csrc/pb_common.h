@@ -98,6 +98,16 @@ __host__ __device__ inline int64_t ceil_div(int64_t a, int64_t b)
     return -floor_div(-a, b);
 }
 
+// x / d with inv = RN(1 / d) prepared once for many numerators: the closing steps of the division
+// the compiler would emit -- product, exact residual, one correction -- without its reciprocal
+// refinement (3 instructions instead of ~12).  The correctly rounded quotient except for divisors
+// whose significand is all ones (Markstein): otherwise the same bits as x / d.
+__device__ __forceinline__ double quot(double x, double d, double inv)
+{
+    const double q = x * inv;
+    return fma(fma(-q, d, x), inv, q);
+}
+
 // exp() with its constants in SGPRs.  The arithmetic is the device library's (range reduction by
 // ln2 in two parts, degree-11 polynomial, ldexp, the same overflow/underflow selects), so the
 // result is the same bit pattern; what changes is that the polynomial coefficients sit in scalar

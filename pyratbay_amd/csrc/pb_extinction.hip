@@ -55,26 +55,17 @@ constexpr int kRecs = 4;                         // records in flight per wavefr
 static_assert(kTile <= kPmPad, "table padding must cover one tile");
 static_assert(kTile < 65536, "window coordinates are packed in 16 bits");
 
-// x / d with inv = RN(1 / d) prepared once per layer (k_layer_state): the closing steps of the
-// division the compiler would emit -- product, exact residual, one correction -- without its
-// reciprocal refinement (3 instructions instead of ~12).  The correctly rounded quotient except
-// for divisors whose significand is all ones (Markstein): otherwise the same bits as x / d.
-__device__ __forceinline__ double quot(double x, double d, double inv)
-{
-    const double q = x * inv;
-    return fma(fma(-q, d, x), inv, q);
-}
-
 // Line strength divided by the abundance (_extcoeff.c:219-224), same operation order; the three
-// divisions by per-layer values through quot(), the exponentials through pb::exp_s (the device
+// divisions by per-layer values through pb::quot(), the exponentials through pb::exp_s (the device
 // library's exp arithmetic with its coefficients in scalar registers: same bits).  k_records
 // evaluates this once per (layer, line): 2 exp + 3 divisions were 0.11 ms of every C2 spectrum.
 __device__ inline double line_strength(double ratio, double gf, double elow, double wavn,
                                        double temp, double inv_temp, double z, double inv_z)
 {
-    return quot(pb::kSigCte * ratio * gf * pb::exp_s(quot(-pb::kExpCte * elow, temp, inv_temp)) *
-                    (1 - pb::exp_s(quot(-pb::kExpCte * wavn, temp, inv_temp))),
-                z, inv_z);
+    return pb::quot(pb::kSigCte * ratio * gf *
+                        pb::exp_s(pb::quot(-pb::kExpCte * elow, temp, inv_temp)) *
+                        (1 - pb::exp_s(pb::quot(-pb::kExpCte * wavn, temp, inv_temp))),
+                    z, inv_z);
 }
 
 // ---------------------------------------------------------------------------

@@ -67,10 +67,36 @@ def walkers(inp, n, seed):
 
 
 # ------------------------------------------------------------------ CPU reference legs
-def cpu_eval(arr, temps, dens, radius, rstar, bands, wn):
+def cpu_eval(arr, temps, dens, radius, rstar, bands, wn, rt='transit'):
     from oracle import oracle as orc, ref
     L, W = temps.shape[0], wn.shape[0]
     ec = np.zeros((L, W))
+    if rt == 'emission':
+        # interp_ec + plane_parallel_optical_depth + blackbody_wn_2D + intensity + the quadrature
+        # sum (pyrat/spectrum.py:366-377, spectrum/radiative_transfer.py:76-138), default raygrid
+        from pyratbay_amd import engine
+        mu, weights = engine.default_quadrature()
+        depth = np.zeros((L, W))
+        ideep = np.full(W, L - 1, np.intc)
+        if ref.available():
+            kind = 'reference'
+            ref.module('_extcoeff').interp_ec(ec, arr['etable'], arr['ttable'], temps, dens, 0, L)
+            t = ref.module('_trapezoid')
+            ideep64 = np.full(W, L - 1, int)
+            t.plane_parallel_optical_depth(depth, ideep64, ec, -np.ediff1d(radius), 10.0, 0, L)
+            B = np.zeros((L, W))
+            ref.module('_blackbody').blackbody_wn_2D(np.ascontiguousarray(wn), temps, B, ideep64)
+            inten = t.intensity(depth, ideep64, B, mu, 0)
+        else:
+            kind = 'port'
+            orc.interp_ec(ec, arr['etable'], arr['ttable'], temps, dens, 0, L)
+            orc.plane_parallel_optical_depth(depth, ideep, ec, -orc.ediff(radius), 10.0, 0, L)
+            B = orc.blackbody_wn_2D(np.ascontiguousarray(wn), temps)
+            inten = orc.intensity(depth, ideep, B, mu, 0)
+        spec = np.sum(inten * weights[:, None], axis=0)
+        flux = np.array([np.trapezoid(spec[s:s + len(r)] * r, wn[s:s + len(r)]) * h
+                         for s, r, h in bands])
+        return kind, flux
     if ref.available():
         kind = 'reference'
         ref.module('_extcoeff').interp_ec(ec, arr['etable'], arr['ttable'], temps, dens, 0, L)
@@ -107,7 +133,8 @@ def cpu_worker():
         out = []
         for w in job['walkers']:
             kind, flux = cpu_eval(arr, np.array(arr['temps'][w]), np.array(arr['dens'][w]),
-                                  np.array(arr['radius'][w]), job['rstar'], bands, arr['wn'])
+                                  np.array(arr['radius'][w]), job['rstar'], bands, arr['wn'],
+                                  job.get('rt', 'transit'))
             out.append(flux.tolist())
         print(json.dumps({'kind': kind, 'wall': time.perf_counter() - t0, 'flux': out}),
               flush=True)
@@ -150,8 +177,9 @@ def main(args):
     g, atm = inp['grid'], inp['atm']
     nwave, nlayers = g['nwave'], atm['nlayers']
     t0 = time.perf_counter()
+    rt = 'emission' if getattr(args, 'workload', 'c5') == 'c5-emission' else 'transit'
     model = engine.TableSpectrum(inp['etable'], inp['ttable'], g['wn'], atm['radius'],
-                                 atm['rstar'])
+                                 atm['rstar'], rt_path=rt)
     pb = engine.PassBands(g['wn'], inp['bands'])
     steps = args.steps if args.steps not in (None, 20) else 157   # default: 1e4 evals in batches of 64
     nbatch_distinct = 4
@@ -189,7 +217,7 @@ def main(args):
     # transmission in one kernel, ec never stored; two walkers per wavefront where the batch allows)
     # -- reported beside `value`, which stays the default path's
     one_pass = None
-    if world == 1:
+    if world == 1 and rt == 'transit':
         default_flux = out.clone()
         model.one_pass = True
         n1p = max(8, min(steps, 40))
@@ -228,9 +256,14 @@ def main(args):
 
         interp_ms = timed(lambda: engine.interp_ec_batch(model.etable, model.ttable, temps, dens))
         ec = engine.interp_ec_batch(model.etable, model.ttable, temps, dens)
-        path = engine.transit_path_device(radius, 0)
-        transit_ms = timed(lambda: engine.transit_spectrum_batch(
-            ec, path, radius, atm['rstar'], 0, nlayers, 10.0))
+        if rt == 'emission':
+            intervals = (radius[:, :-1] - radius[:, 1:]).contiguous()
+            transit_ms = timed(lambda: engine.emission_flux_batch(
+                ec, intervals, model.wn, temps, model.mu, model.weights, 0, nlayers, 10.0))
+        else:
+            path = engine.transit_path_device(radius, 0)
+            transit_ms = timed(lambda: engine.transit_spectrum_batch(
+                ec, path, radius, atm['rstar'], 0, nlayers, 10.0))
         # compulsory bytes of ONE batched launch.  interp: every table slice (species x layer x
         # temperature node) that some walker of the batch brackets is read once -- walkers in the
         # same bracket share it -- and every walker's ec is written; transit: every walker's ec
@@ -245,7 +278,13 @@ def main(args):
         # matrix-core form: per 32 columns 2 x 60 v_mfma_f64_16x16x4_f64 (the blocks of the
         # 80 x 80 ray-path matrix on or below its diagonal) = 7680 flop per column
         transit_flops = 2.0 * 60 * 2048 / 32 * nwave * nloc
+        nmu = len(model.mu) if rt == 'emission' else 0
         kernels = [
+            {'kernel': 'k_emission_fused', 'kernel_ms': transit_ms, 'kernel_bytes': transit_bytes,
+             'bound_by': (f'FP64 vector ALU: per (walker, column, layer) one Planck exp + {nmu} '
+                          'exp(-depth / mu) (plane_parallel_optical_depth + blackbody + intensity '
+                          'in one pass, depth and B never stored); ec read once')}
+            if rt == 'emission' else
             {'kernel': 'k_transit_mfma<5,4>' if mfma else 'k_transit_pair<16>',
              'kernel_ms': transit_ms, 'kernel_bytes': transit_bytes,
              'bound_by': ('FP64 matrix pipe (120 v_mfma_f64_16x16x4_f64 per 32 columns = '
@@ -261,13 +300,16 @@ def main(args):
         dom = kernels[0]
         path_bytes = (16.0 * NSPEC + 32.0) * nlayers * nwave + 8.0 * nwave
         out_json = {
-            'metric': 'pyrat.eval() calls/sec (1e5 wavenumbers x 80 layers, sampled cross sections)',
+            'metric': 'pyrat.eval() calls/sec (1e5 wavenumbers x 80 layers, sampled cross sections'
+                      + (', emission geometry)' if rt == 'emission' else ')'),
             'value': value, 'unit': 'evals/s', 'n_gpus': world, 'steps': steps,
             'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / steps,
             'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None, 'dtype': 'f64',
             'data': 'synthetic',
             'config': {'workload': f'MCMC retrieval inner loop: {evals} eval() calls at 1e5 '
-                                   'wavenumbers x 80 layers, batched walkers',
+                                   'wavenumbers x 80 layers, batched walkers'
+                                   + (', emission geometry (plane-parallel RT, 5-angle quadrature)'
+                                      if rt == 'emission' else ''),
                        'batch': BATCH, 'nspec': NSPEC, 'ntemp': NTEMP, 'nbands': len(inp['bands']),
                        'table_bytes': int(model.etable.numel() * 8),
                        'parallelism': 'single GPU' if world == 1 else
@@ -283,7 +325,7 @@ def main(args):
                          'path_bytes_per_eval_unshared': path_bytes},
         }
         if want_cpu:
-            out_json.update(cpu_legs(inp, procs, step(0).cpu().numpy()))
+            out_json.update(cpu_legs(inp, procs, step(0).cpu().numpy(), rt))
         print(json.dumps(out_json), flush=True)
     for p in procs:
         try:
@@ -297,7 +339,7 @@ def main(args):
         dist.destroy_process_group()
 
 
-def cpu_legs(inp, procs, gpu_flux_last):
+def cpu_legs(inp, procs, gpu_flux_last, rt='transit'):
     g, atm = inp['grid'], inp['atm']
     n1 = 8
     nall = max(len(procs), 1) * 2
@@ -306,12 +348,13 @@ def cpu_legs(inp, procs, gpu_flux_last):
     t0 = time.perf_counter()
     flux1 = []
     for w in range(n1):
-        kind, f = cpu_eval(arr, temps[w], dens[w], radius[w], atm['rstar'], inp['bands'], g['wn'])
+        kind, f = cpu_eval(arr, temps[w], dens[w], radius[w], atm['rstar'], inp['bands'], g['wn'],
+                           rt)
         flux1.append(f)
     s1 = (time.perf_counter() - t0) / n1
     res = {'cpu_baseline': dict(value=1.0 / s1, unit='evals/s', cores=1, kind=kind,
                                 seconds_per_eval=s1,
-                                sample=f'{n1} eval() calls: interp_ec + optdepth loop + '
+                                sample=f'{n1} eval() calls ({rt}): interp_ec + optical depth + '
                                        'trapezoid2D + band trapezoids, one core')}
     # parity of the GPU batch with the CPU path on the same walkers (the first batch)
     res['cpu_baseline']['parity'] = {
@@ -327,7 +370,7 @@ def cpu_legs(inp, procs, gpu_flux_last):
         shares = [list(range(i, nall, len(procs))) for i in range(len(procs))]
         t0 = time.perf_counter()
         for p, ws in zip(procs, shares):
-            p.stdin.write(json.dumps({'dir': d, 'walkers': ws, 'bands': bands,
+            p.stdin.write(json.dumps({'dir': d, 'walkers': ws, 'bands': bands, 'rt': rt,
                                       'rstar': float(atm['rstar'])}) + '\n')
             p.stdin.flush()
         replies = [json.loads(p.stdout.readline()) for p in procs]
