@@ -54,6 +54,16 @@ WORKLOADS = {
     'c3': dict(nwave=1000001, nlayers=80, nlines=1000000, wnstep=0.005, niso=4,
                rt_path='emission',
                label='1e6 wavenumbers x 80 layers, 1e6-line 4-isotope list, emission'),
+    # c3 / c2 with a band-structured line list (synth.band_positions: 8 band heads per isotope,
+    # peak line density 300 x the background's, duplicated positions): what tile dealing, segment
+    # lengths and the staged / global choice see on a real molecular list
+    'c3-bands': dict(nwave=1000001, nlayers=80, nlines=1000000, wnstep=0.005, niso=4,
+                     rt_path='emission', bands=True,
+                     label='1e6 wavenumbers x 80 layers, 1e6-line 4-isotope list with band heads '
+                           '(300 x density contrast), emission'),
+    'c2-bands': dict(nwave=100001, nlayers=80, nlines=100000, wnstep=0.05, niso=1, bands=True,
+                     label='1e5 wavenumbers x 80 layers, 1e5 synthetic lines with band heads '
+                           '(300 x density contrast), transit'),
     # BASELINE.json configs[3]; on one GPU this is its single-GPU form, with --gpus N the
     # wavenumber-sharded form the config names
     'c4': dict(nwave=1000001, nlayers=120, nlines=1000000, wnstep=0.005, niso=4,
@@ -91,7 +101,7 @@ def metric_name(nwave, nlayers, w):
 
 def make_case(w):
     from pyratbay_amd import synth
-    kw = {k: w[k] for k in ('species', 'vmr', 'line_species', 'resolution') if k in w}
+    kw = {k: w[k] for k in ('species', 'vmr', 'line_species', 'resolution', 'bands') if k in w}
     return synth.lbl_case(w['nwave'], w['nlayers'], w['nlines'], wnstep=w['wnstep'],
                           niso=w['niso'], seed=42, **kw)
 

@@ -128,6 +128,18 @@ struct LblArgs {
     const int32_t *unit_tab;
     const int32_t *lsplit;
     int nunits;
+    // per-tile phase split of the staged kernel (null: off): tile t of every layer is computed by
+    // tsplit[t] <= nsplit workgroups; the (tile, split) workgroups beyond it end at once.  For line
+    // lists of uneven density (band heads): the tiles under a head hold 10-100 x the records of
+    // the others and would end the launch alone.
+    const int32_t *tsplit;
+    // tsplit[t] == 0: the tile is too sparse for the staged kernel (a few records per phase row:
+    // its time is its ~300 barrier steps whatever they hold) and is computed by the global gather,
+    // launched beside it over the tiles so marked; ts_tile = samples per tile of that table;
+    // pos2ph[g] = index of position-sorted group g in the phase-sorted list (the packed records'
+    // order), for the global gather's record fetch
+    int ts_tile;
+    const int32_t *pos2ph;
     // per (layer, phase-sorted group) records written by k_records [nlayers][ngroups]
     double *rec_k;                    // co-added strength (before threshold / density)
     int32_t *rec_ulo, *rec_uhi;       // window on the global output grid

@@ -330,6 +330,9 @@ __global__ __launch_bounds__(NW * 64) void k_ext_resample(LblArgs a)
     decode_block(a, tile, layer);
     if (layer < 0 || (a.res_cap > 0 && a.ls_resident[layer]))
         return;
+    // launched beside the staged kernel (uneven line density): only the tiles it leaves out
+    if (a.tsplit && a.tsplit[((int64_t)tile * kTileRS) / a.ts_tile] != 0)
+        return;
     const int row = blockIdx.y;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -388,19 +391,36 @@ __global__ __launch_bounds__(NW * 64) void k_ext_resample(LblArgs a)
                 double k = 0.0;
                 unsigned off = 0, win = 0;
                 if (g < g1) {
-                    const int64_t idx = recbase + g;
-                    k = a.rec_k[idx];
-                    const int64_t lo = max((int64_t)a.rec_ulo[idx], t0);
-                    const int64_t hi = min((int64_t)a.rec_uhi[idx], tend);
+                    int ulo, uhi, cell, phi, q;
+                    if (a.tsplit) {
+                        // the staged kernel's packed records (phase order): window end, row
+                        // offset and phase follow from the cell's half-width and the position
+                        const Rec16 r = a.rec16[(int64_t)layer * a.rec_pitch + a.pos2ph[g]];
+                        k = r.k;
+                        ulo = r.ulo;
+                        uhi = ulo + (int)(r.lc & 0xfffu);
+                        cell = (int)(r.lc >> 12);
+                        const int d = a.psize[cell] - a.giown[g];          // half - iown
+                        q = floor_div_inv(d, a.inv_osamp);
+                        phi = d - q * osamp;
+                    } else {
+                        const int64_t idx = recbase + g;
+                        k = a.rec_k[idx];
+                        ulo = a.rec_ulo[idx];
+                        uhi = a.rec_uhi[idx];
+                        cell = a.rec_cell[idx];
+                        phi = a.rec_phi[idx];
+                        q = a.rec_q[idx];
+                    }
+                    const int64_t lo = max((int64_t)ulo, t0);
+                    const int64_t hi = min((int64_t)uhi, tend);
                     if (!(k < kthresh) && lo < hi) {
                         if (a.add)
                             k *= dens;
-                        const int cell = a.rec_cell[idx];
                         win = (unsigned)(lo - t0) | ((unsigned)(hi - t0) << 16);
                         // tile sample j reads base[off + j]
-                        off = (unsigned)(a.pm_base[cell] +
-                                         (int64_t)a.rec_phi[idx] * a.pm_stride[cell] +
-                                         a.rec_q[idx] + t0 - base_idx);
+                        off = (unsigned)(a.pm_base[cell] + (int64_t)phi * a.pm_stride[cell] + q +
+                                         t0 - base_idx);
                         if (a.experiment == 1)
                             off = (unsigned)(kTile + (lo - t0));
                     } else {
@@ -815,7 +835,10 @@ __global__ __launch_bounds__(NW * 64, 8) void k_ext_staged(LblArgs a)
     }
     if (layer < 0 || (a.res_cap > 0 && a.ls_resident[layer]) || (a.wave_cap > 0 && a.ls_wave[layer]))
         return;
-    const int nsp = a.lsplit ? a.lsplit[layer] : a.nsplit;    // pieces of this layer's tiles
+    // pieces of this tile: per layer, per tile (uneven line density) or one number for the launch
+    const int nsp = a.tsplit ? a.tsplit[tile] : a.lsplit ? a.lsplit[layer] : a.nsplit;
+    if (zsplit >= nsp)
+        return;
     const int row = blockIdx.y;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -1841,6 +1864,24 @@ __global__ __launch_bounds__(kBlock) void k_combine_parts(double *ext, const dou
     ext[i] = v;
 }
 
+// the same with a per-tile number of pieces (LblArgs::tsplit): sample w of a row belongs to tile
+// w / tile and has tsplit[tile] - 1 partial planes
+__global__ __launch_bounds__(kBlock) void k_combine_tile_parts(double *ext, const double *part,
+                                                              const int32_t *tsplit, int tile,
+                                                              int64_t wcount, int64_t n)
+{
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n)
+        return;
+    const int np = tsplit[(i % wcount) / tile] - 1;
+    if (np <= 0)
+        return;
+    double v = ext[i];
+    for (int p = 0; p < np; p++)
+        v += part[(int64_t)p * n + i];
+    ext[i] = v;
+}
+
 // the same with a per-layer number of pieces: grid.y = layer, layers in one piece are skipped
 __global__ __launch_bounds__(kBlock) void k_combine_layer_parts(double *ext, const double *part,
                                                                const int32_t *lsplit,
@@ -2153,6 +2194,12 @@ struct pb_lbl {
     int last_chunks = 0;     // chunks of the last call (0 = records of every group at once)
     // per-layer phase split of the staged kernel: device tables and the configuration they hold
     int32_t *d_unit_tab = nullptr, *d_lsplit = nullptr;
+    // per-tile phase split (uneven line density): device table and what it was made for
+    int32_t *d_tsplit = nullptr;
+    int32_t *pos2ph = nullptr;                        // [ngroups] (LblArgs::pos2ph)
+    bool ts_sparse = false;                           // some tile of the table is the global gather's
+    int64_t ts_key[4] = {-1, -1, -1, -1};            // wbegin, wcount, tile, base split
+    int ts_max = 0, ts_tiles = 0;
     int ut_key[4] = {-1, -1, -1, -1};                 // nlayers, base split, deep layers, deep split
     int ut_units = 0;
     int concurrency = 1;     // independent calls the caller keeps in flight beside this plan's
@@ -2542,6 +2589,12 @@ int pb_lbl_create(pb_lbl **out, pb_voigt *voigt, pb_lines *lines, const double *
             f[k] = lines->h_gfirst[order[k]];
             c[k] = lines->h_gcount[order[k]];
             w[k] = lines->h_giown[order[k]];
+        }
+        {
+            std::vector<int32_t> inv(ng);                 // position-sorted group -> phase-sorted slot
+            for (size_t k = 0; k < ng; k++)
+                inv[(size_t)order[k]] = (int32_t)k;
+            if (rc == PB_OK) rc = upload(&p->pos2ph, inv.data(), ng);
         }
         if (rc == PB_OK) rc = upload(&p->ph_first, f.data(), ng);
         if (rc == PB_OK) rc = upload(&p->ph_count, c.data(), ng);
@@ -3486,6 +3539,98 @@ static int lbl_extinction(pb_lbl *p, double *ext_d, int64_t wbegin, int64_t wcou
         a.unit_tab = nullptr;
         a.lsplit = nullptr;
         a.nunits = 0;
+        a.tsplit = nullptr;
+        // Per-tile split.  A uniform line list gives every tile the same number of records; a
+        // real one has band heads (10^2-10^3 x the line density of the gaps): the few tiles under
+        // a head run 10 x as long as the others and end the launch alone (the C2 grid with 8 band
+        // heads per isotope at 300 x contrast: gather 1.90 ms unsplit, 1.34 ms with every tile in
+        // four pieces -- profiles/r04_bands.md).  From the groups within reach of every tile (host
+        // copy of the group positions, cached per tiling) the tiles above 1.5 x the median count
+        // get more pieces, up to 8; the others keep the launch's.  Automatic mode only: a forced
+        // mode adds the terms of a sample in one order whatever the tiling (pbhip.h).
+        if (deep == 0 && a.nch_max == 1 && p->gather_mode == 0 && a.wave_cap == 0 &&
+            !getenv("PB_STAGE_SPLIT") && !(getenv("PB_TILE_SPLIT") && atoi(getenv("PB_TILE_SPLIT")) == 0) &&
+            !l->h_giown.empty()) {
+            const int tile = S * (int)sub;
+            const int nt = pb::div_up(wcount, tile);
+            if (p->ts_key[0] != wbegin || p->ts_key[1] != wcount || p->ts_key[2] != tile ||
+                p->ts_key[3] != nsplit) {
+                int64_t hmax_all = 0;
+                for (int32_t h : v->psize)
+                    hmax_all = std::max<int64_t>(hmax_all, h);
+                int64_t reach = hmax_all;
+                if (a.cutoff > 0.0)
+                    reach = std::min(reach, (int64_t)(a.cutoff / a.ownstep) + 2 * (int64_t)v->osamp + 2);
+                std::vector<int64_t> cnt((size_t)nt, 0);
+                for (int t = 0; t < nt; t++) {
+                    const int64_t t0 = wbegin + (int64_t)t * tile;
+                    const int64_t tend = std::min<int64_t>(t0 + tile, wbegin + wcount);
+                    const int64_t flo = t0 * v->osamp - reach, fhi = (tend - 1) * v->osamp + reach;
+                    for (int i = 0; i < p->niso; i++) {
+                        const int32_t *b = l->h_giown.data() + l->iso_gstart[(size_t)i];
+                        const int32_t *e = l->h_giown.data() + l->iso_gstart[(size_t)i + 1];
+                        cnt[(size_t)t] += std::upper_bound(b, e, (int32_t)std::min<int64_t>(fhi, INT_MAX)) -
+                                          std::lower_bound(b, e, (int32_t)std::max<int64_t>(flo, INT_MIN));
+                    }
+                }
+                std::vector<int64_t> sorted(cnt);
+                std::nth_element(sorted.begin(), sorted.begin() + nt / 2, sorted.end());
+                const double median = (double)std::max<int64_t>(1, sorted[(size_t)nt / 2]);
+                std::vector<int32_t> ts((size_t)nt);
+                int tmax = nsplit;
+                const int tmin = getenv("PB_TILE_MIN") ? atoi(getenv("PB_TILE_MIN")) : 1;
+                if (getenv("PB_TILE_DEBUG")) {
+                    fprintf(stderr, "tile counts (median %.0f):", median);
+                    for (int t = 0; t < nt; t++)
+                        fprintf(stderr, " %lld", (long long)cnt[(size_t)t]);
+                    fprintf(stderr, "\n");
+                }
+                // groups per (2048 samples, phase row) of a tile against the threshold that sends a
+                // whole launch to the global gather: a tile below it is visit-starved in the staged
+                // kernel (~300 barrier steps of one or two records: as long as a full tile) -- once
+                // SOME tile is dense enough to be split, the sparse ones go to the global gather
+                bool sparse = false, dense = false;
+                for (int t = 0; t < nt; t++) {
+                    const int k = std::max(tmin, (int)std::ceil((double)cnt[(size_t)t] / (1.5 * median)));
+                    ts[(size_t)t] = std::max(nsplit, std::min(8, nsplit * std::max(1, k)));
+                    tmax = std::max(tmax, ts[(size_t)t]);
+                    dense = dense || ts[(size_t)t] > nsplit;
+                }
+                if (dense && packable && p->pos2ph &&
+                    !(getenv("PB_TILE_GLOBAL") && atoi(getenv("PB_TILE_GLOBAL")) == 0))
+                    for (int t = 0; t < nt; t++) {
+                        const double per =
+                            (double)cnt[(size_t)t] * 2048.0 / (double)tile / (double)v->osamp;
+                        if (per < p->stage_threshold) {
+                            ts[(size_t)t] = 0;
+                            sparse = true;
+                        }
+                    }
+                p->ts_sparse = sparse;
+                PB_HIP(hipStreamSynchronize(s));       // an earlier call may still read the table
+                if (nt > p->ts_tiles) {
+                    (void)hipFree(p->d_tsplit);
+                    p->d_tsplit = nullptr;
+                    PB_HIP(hipMalloc(&p->d_tsplit, (size_t)nt * 4));
+                    p->ts_tiles = nt;
+                }
+                PB_HIP(hipMemcpy(p->d_tsplit, ts.data(), (size_t)nt * 4, hipMemcpyHostToDevice));
+                p->ts_key[0] = wbegin;
+                p->ts_key[1] = wcount;
+                p->ts_key[2] = tile;
+                p->ts_key[3] = nsplit;
+                p->ts_max = tmax;
+            }
+            if (p->ts_max > nsplit) {
+                const int64_t plane = (int64_t)nlayers * a.nrows * wcount * 8;
+                if ((int64_t)(p->ts_max - 1) * plane <= ((int64_t)1 << 30)) {
+                    a.tsplit = p->d_tsplit;
+                    a.ts_tile = tile;
+                    a.pos2ph = p->pos2ph;
+                    nsplit = deep_split = p->ts_max;
+                }
+            }
+        }
         if (deep > 0) {
             if (p->ut_key[0] != nlayers || p->ut_key[1] != nsplit || p->ut_key[2] != deep ||
                 p->ut_key[3] != deep_split) {
@@ -3562,6 +3707,20 @@ static int lbl_extinction(pb_lbl *p, double *ext_d, int64_t wbegin, int64_t wcou
             dim3 cgrid((unsigned)pb::div_up(per_layer, kBlock), nlayers);
             k_combine_layer_parts<<<cgrid, kBlock, 0, s>>>(ext_d, p->part, p->d_lsplit, per_layer,
                                                           (int64_t)nlayers * per_layer);
+        } else if (a.tsplit) {
+            PB_LAUNCH_CHECK();
+            if (p->ts_sparse) {
+                // the sparse tiles through the global gather (RS = 1: its own 1024-sample tiles;
+                // the tiles of the staged kernel end at once there, and the other way round)
+                LblArgs g = a;
+                g.ntiles = pb::div_up(wcount, kTile);
+                dim3 ggrid((unsigned)(8 * g.ntiles * layer_groups), a.nrows);
+                k_ext_resample<1, 4><<<ggrid, kBlock, 0, s>>>(g);
+                PB_LAUNCH_CHECK();
+            }
+            const int64_t n = (int64_t)nlayers * a.nrows * wcount;
+            k_combine_tile_parts<<<(unsigned)pb::div_up(n, kBlock), kBlock, 0, s>>>(
+                ext_d, p->part, a.tsplit, S * (int)sub, wcount, n);
         } else if (nsplit > 1) {
             PB_LAUNCH_CHECK();
             const int64_t n = (int64_t)nlayers * a.nrows * wcount;
@@ -4020,6 +4179,8 @@ void pb_lbl_destroy(pb_lbl *p)
     (void)hipFree(p->ls_resident);
     (void)hipFree(p->ls_block);
     (void)hipFree(p->ls_wave);
+    (void)hipFree(p->d_tsplit);
+    (void)hipFree(p->pos2ph);
     (void)hipFree(p->rec32);
     (void)hipFree(p->rec16);
     (void)hipFree(p->part);

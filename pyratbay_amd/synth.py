@@ -111,9 +111,37 @@ def voigt_sizes(lorentz, doppler, extent, cutoff, ownstep, onwave, dlratio=0.1):
     return size
 
 
+def band_positions(rng, n, wnlow, wnhigh, nbands=8, contrast=300.0, in_bands=0.9,
+                   duplicates=0.02):
+    """n line positions with BAND STRUCTURE instead of a uniform density: a uniform background
+    holding (1 - in_bands) of the lines plus `nbands` Gaussian band heads (random centres, equal
+    shares) whose peak line density is `contrast` times the background's -- real molecular lists
+    (the reference's LBL tests run on HITRAN, tests/configs/spectrum_transmission_test.cfg) have
+    10^2-10^3 x density contrasts between band heads and the gaps -- and a fraction `duplicates`
+    of the band lines at EXACTLY the wavenumber of another line (blended lines at a head: the
+    co-adding of _extcoeff.c:248-262 and equal sort keys).  Sorted."""
+    span = wnhigh - wnlow
+    nbg = int(round(n * (1.0 - in_bands)))
+    nb = n - nbg
+    sigma = in_bands * span / (nbands * np.sqrt(2 * np.pi) * max(contrast - 1.0, 1e-9)
+                               * max(1.0 - in_bands, 1e-9))
+    centres = rng.uniform(wnlow + 3 * sigma, wnhigh - 3 * sigma, nbands)
+    which = rng.integers(0, nbands, nb)
+    pos = centres[which] + sigma * rng.standard_normal(nb)
+    bad = (pos < wnlow) | (pos > wnhigh)
+    pos[bad] = rng.uniform(wnlow, wnhigh, int(bad.sum()))          # (tails beyond the grid)
+    ndup = int(duplicates * nb)
+    if ndup and nb > 1:
+        dst = rng.choice(nb, ndup, replace=False)
+        pos[dst] = pos[rng.integers(0, nb, ndup)]
+    return np.sort(np.concatenate([pos, rng.uniform(wnlow, wnhigh, nbg)]))
+
+
 def synthetic_lines(nlines, wnlow, wnhigh, niso=1, seed=42,
-                    ratios=(0.997, 2e-3, 4e-4, 3e-4)):
-    """Line list sorted by isotope then wavenumber, as the TLI reader returns it."""
+                    ratios=(0.997, 2e-3, 4e-4, 3e-4), bands=None):
+    """Line list sorted by isotope then wavenumber, as the TLI reader returns it.  bands: None =
+    uniform positions; a dict of band_positions' keywords (or True for its
+    defaults) = band heads with a 10^2-10^3 x density contrast and duplicated positions."""
     rng = np.random.default_rng(seed)
     frac = np.asarray(ratios[:niso], float)
     frac = frac / frac.sum()
@@ -128,7 +156,11 @@ def synthetic_lines(nlines, wnlow, wnhigh, niso=1, seed=42,
     counts[0] += nlines - counts.sum()
     lwn, lid = [], []
     for i, c in enumerate(counts):
-        lwn.append(np.sort(rng.uniform(wnlow, wnhigh, c)))
+        if bands:
+            kw = bands if isinstance(bands, dict) else {}
+            lwn.append(band_positions(rng, int(c), wnlow, wnhigh, **kw))
+        else:
+            lwn.append(np.sort(rng.uniform(wnlow, wnhigh, c)))
         lid.append(np.full(c, i, np.int32))
     lwn = np.concatenate(lwn)
     lid = np.concatenate(lid)
@@ -171,7 +203,7 @@ def lbl_case(nwave_target, nlayers, nlines, *, wnlow=4000.0, wnstep=0.05, wnosam
              niso=1, nlor=100, ndop=50, extent=300.0, cutoff=25.0, dlratio=0.1,
              seed=42, species=('H2', 'He', 'H2O'), vmr=(0.85, 0.149, 4e-4),
              line_species_index=2, iso_masses=None, ptop=1e-6, pbottom=1e2,
-             line_species=None, resolution=None):
+             line_species=None, resolution=None, bands=None):
     """Everything the LBL hot path needs for one synthetic spectrum.
 
     The line-carrying species is species[line_species_index]; its `niso` isotopes
@@ -200,7 +232,7 @@ def lbl_case(nwave_target, nlayers, nlines, *, wnlow=4000.0, wnstep=0.05, wnosam
     base_ratios = np.array((0.997, 2e-3, 4e-4, 3e-4)[:niso]) if niso > 1 else np.array([1.0])
     parts, isoimol, isomass, isoratio, isoiext = [], [], [], [], []
     for k, imol in enumerate(carriers):
-        ln = synthetic_lines(nlines, grid['wn'][0], grid['wn'][-1], niso, seed + k)
+        ln = synthetic_lines(nlines, grid['wn'][0], grid['wn'][-1], niso, seed + k, bands=bands)
         ln['lid'] = ln['lid'] + np.int32(k * niso)
         parts.append(ln)
         m0 = atm['mol_mass'][imol]

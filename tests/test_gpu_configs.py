@@ -141,6 +141,11 @@ FULL = {
     'c2-1e6': dict(args=(100001, 80, 1000000), kw=dict(wnstep=0.05, niso=1), layers=(41,)),
     # configs[2]: 1e6 wavenumbers, 1e6-line 4-isotope list
     'c3': dict(args=(1000001, 80, 1000000), kw=dict(wnstep=0.005, niso=4), layers=(3, 76)),
+    # C3 with a band-structured list (synth.band_positions: band heads at 300 x the background's
+    # line density, duplicated positions): the reference's own LBL tests run on HITRAN, whose
+    # density contrasts the uniform lists above do not have
+    'c3-bands': dict(args=(1000001, 80, 1000000), kw=dict(wnstep=0.005, niso=4, bands=True),
+                     layers=(3, 76)),
     # configs[3]: 1e6 wavenumbers x 120 layers, 4 species x 1e6 lines (single-GPU form)
     'c4': dict(args=(1000001, 120, 1000000),
                kw=dict(wnstep=0.005, niso=4, species=C4_SPECIES, vmr=C4_VMR,
@@ -148,7 +153,7 @@ FULL = {
 }
 
 
-@pytest.mark.parametrize('name', ['c2', 'c2-1e6', 'c3', 'c4'])
+@pytest.mark.parametrize('name', ['c2', 'c2-1e6', 'c3', 'c3-bands', 'c4'])
 def test_full_size_config(eng, orc, name, monkeypatch):
     import torch
     from pyratbay_amd import synth

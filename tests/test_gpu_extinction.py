@@ -1083,3 +1083,49 @@ def test_wave_kernel_vs_oracle(eng, orc, monkeypatch, wnosamp, cutoff, extent, n
     parts = [host(lbl.extinction(t, d, z, wbegin=a, wcount=b - a))
              for a, b in zip(bounds[:-1], bounds[1:])]
     assert np.array_equal(np.concatenate(parts, axis=2), split)
+
+
+@pytest.mark.parametrize('gather', ['auto', 'global', 'staged', 'rounds', 'wave'])
+def test_band_structured_list_vs_oracle(eng, orc, gather):
+    """A line list with band heads (synth.band_positions: peak line density 300 x the
+    background's, 2 % of the band lines at exactly another line's wavenumber) instead of uniform
+    positions: dense tiles next to nearly empty ones, long co-add groups, equal sort keys.  Every
+    layer against the oracle; shards cut through a band head concatenate bit for bit."""
+    from pyratbay_amd import synth
+    case = synth.lbl_case(12001, 6, 60000, wnosamp=24, nlor=18, ndop=9, extent=80.0, cutoff=3.0,
+                          niso=2, seed=91, bands=dict(nbands=3, contrast=300.0))
+    g, atm, ln, iso, vg = (case[k] for k in ('grid', 'atm', 'lines', 'iso', 'voigt'))
+    w = ln['lwn'][ln['lid'] == 0]
+    hist, _ = np.histogram(w, bins=200)
+    assert hist.max() > 50 * max(np.median(hist), 1) and np.sum(np.diff(w) == 0) > 100
+    vt = eng.VoigtTable.build(vg['lorentz'], vg['doppler'], vg['size'], g['ownstep'], 24)
+    ll = eng.LineList(ln['lwn'], ln['elow'], ln['gf'], ln['lid'], 2, g['own'])
+    assert ll.nadd > 1000                                  # co-added lines at the heads
+    lbl = eng.LBL(vt, ll, g['wn'], g['divisors'], atm['mol_radius'], atm['mol_mass'],
+                  iso['isoimol'], iso['isomass'], iso['isoratio'], iso['isoiext'],
+                  vg['cutoff'], 1e-30, max_layers=6)
+    lbl.set_gather_mode(gather)
+    t, d, z = eng.dev(atm['temp']), eng.dev(atm['dens']), eng.dev(iso['isoz'])
+    ext = host(lbl.extinction(t, d, z, add=True))
+    profile = vt.flat()
+    worst = 0.0
+    for layer in range(6):
+        want = np.zeros((1, g['nwave']))
+        orc.extinction(want, profile, vt.size, vt.index, vg['lorentz'], vg['doppler'],
+                       g['wn'], g['own'], g['divisors'], atm['dens'][layer],
+                       atm['mol_radius'], atm['mol_mass'], iso['isoimol'], iso['isomass'],
+                       iso['isoratio'], iso['isoz'][:, layer].copy(), iso['isoiext'],
+                       ln['lwn'], ln['elow'], ln['gf'], ln['lid'], vg['cutoff'], 1e-30,
+                       atm['temp'][layer], 0, 1, 0)
+        got = ext[layer]
+        assert np.array_equal(got == 0, want == 0), layer
+        nz = want != 0
+        worst = max(worst, np.max(np.abs(got[nz] / want[nz] - 1)))
+        np.testing.assert_allclose(got, want, rtol=RTOL)
+    print(f'band heads {gather}: max rel err vs oracle = {worst:.2e}, co-added {ll.nadd}')
+    if gather != 'auto':
+        head = int(np.argmax(np.histogram(w, bins=g['nwave'], range=(g['wn'][0], g['wn'][-1]))[0]))
+        bounds = sorted({0, max(1, head - 3), min(g['nwave'] - 1, head + 700), g['nwave']})
+        parts = [host(lbl.extinction(t, d, z, wbegin=a, wcount=b - a))
+                 for a, b in zip(bounds[:-1], bounds[1:])]
+        assert np.array_equal(np.concatenate(parts, axis=2), ext)
