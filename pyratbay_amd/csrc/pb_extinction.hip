@@ -1851,12 +1851,20 @@ __global__ __launch_bounds__(64) void k_ext_scatter(LblArgs a)
         out[i] = s_tile[i];
 }
 
-// ext += part[0] + part[1] + ... in that order (the phase splits of a small staged launch)
+// ext += part[0] + part[1] + ... in that order (the phase splits of a small staged launch).
+// skip[layer] != 0: a layer another kernel computed whole (the resident-profile kernel): the
+// staged kernel wrote NO partial sums for it, its planes hold whatever an earlier call left there
+// (found by tools/fuzz_r4.py: a plan used in `staged` mode and then in automatic mode with resident
+// layers added the earlier call's pieces to the resident kernel's result; on a fresh plan the
+// planes are fresh zero pages, which is why no test saw it).
 __global__ __launch_bounds__(kBlock) void k_combine_parts(double *ext, const double *part,
-                                                         int nparts, int64_t n)
+                                                         int nparts, int64_t n,
+                                                         const int32_t *skip, int64_t per_layer)
 {
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (i >= n)
+        return;
+    if (skip && skip[i / per_layer])
         return;
     double v = ext[i];
     for (int p = 0; p < nparts; p++)
@@ -1868,13 +1876,14 @@ __global__ __launch_bounds__(kBlock) void k_combine_parts(double *ext, const dou
 // w / tile and has tsplit[tile] - 1 partial planes
 __global__ __launch_bounds__(kBlock) void k_combine_tile_parts(double *ext, const double *part,
                                                               const int32_t *tsplit, int tile,
-                                                              int64_t wcount, int64_t n)
+                                                              int64_t wcount, int64_t n,
+                                                              const int32_t *skip, int64_t per_layer)
 {
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (i >= n)
         return;
     const int np = tsplit[(i % wcount) / tile] - 1;
-    if (np <= 0)
+    if (np <= 0 || (skip && skip[i / per_layer]))
         return;
     double v = ext[i];
     for (int p = 0; p < np; p++)
@@ -1885,11 +1894,12 @@ __global__ __launch_bounds__(kBlock) void k_combine_tile_parts(double *ext, cons
 // the same with a per-layer number of pieces: grid.y = layer, layers in one piece are skipped
 __global__ __launch_bounds__(kBlock) void k_combine_layer_parts(double *ext, const double *part,
                                                                const int32_t *lsplit,
-                                                               int64_t per_layer, int64_t n)
+                                                               int64_t per_layer, int64_t n,
+                                                               const int32_t *skip)
 {
     const int layer = blockIdx.y;
     const int nparts = lsplit[layer] - 1;
-    if (nparts <= 0)
+    if (nparts <= 0 || (skip && skip[layer]))
         return;
     const int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (j >= per_layer)
@@ -3504,8 +3514,8 @@ static int lbl_extinction(pb_lbl *p, double *ext_d, int64_t wbegin, int64_t wcou
             return rc;
         if (rsplit > 1) {
             const int64_t n = (int64_t)nlayers * a.nrows * wcount;
-            k_combine_parts<<<(unsigned)pb::div_up(n, kBlock), kBlock, 0, s>>>(ext_d, p->part,
-                                                                             rsplit - 1, n);
+            k_combine_parts<<<(unsigned)pb::div_up(n, kBlock), kBlock, 0, s>>>(
+                ext_d, p->part, rsplit - 1, n, nullptr, (int64_t)a.nrows * wcount);
         }
     } else if (staged) {
         // Per-layer split.  A launch ends when its slowest workgroup does, and the slowest are the
@@ -3706,7 +3716,8 @@ static int lbl_extinction(pb_lbl *p, double *ext_d, int64_t wbegin, int64_t wcou
             const int64_t per_layer = (int64_t)a.nrows * wcount;
             dim3 cgrid((unsigned)pb::div_up(per_layer, kBlock), nlayers);
             k_combine_layer_parts<<<cgrid, kBlock, 0, s>>>(ext_d, p->part, p->d_lsplit, per_layer,
-                                                          (int64_t)nlayers * per_layer);
+                                                          (int64_t)nlayers * per_layer,
+                                                          a.res_cap > 0 ? a.ls_resident : nullptr);
         } else if (a.tsplit) {
             PB_LAUNCH_CHECK();
             if (p->ts_sparse) {
@@ -3720,12 +3731,14 @@ static int lbl_extinction(pb_lbl *p, double *ext_d, int64_t wbegin, int64_t wcou
             }
             const int64_t n = (int64_t)nlayers * a.nrows * wcount;
             k_combine_tile_parts<<<(unsigned)pb::div_up(n, kBlock), kBlock, 0, s>>>(
-                ext_d, p->part, a.tsplit, S * (int)sub, wcount, n);
+                ext_d, p->part, a.tsplit, S * (int)sub, wcount, n,
+                a.res_cap > 0 ? a.ls_resident : nullptr, (int64_t)a.nrows * wcount);
         } else if (nsplit > 1) {
             PB_LAUNCH_CHECK();
             const int64_t n = (int64_t)nlayers * a.nrows * wcount;
-            k_combine_parts<<<(unsigned)pb::div_up(n, kBlock), kBlock, 0, s>>>(ext_d, p->part,
-                                                                             nsplit - 1, n);
+            k_combine_parts<<<(unsigned)pb::div_up(n, kBlock), kBlock, 0, s>>>(
+                ext_d, p->part, nsplit - 1, n, a.res_cap > 0 ? a.ls_resident : nullptr,
+                (int64_t)a.nrows * wcount);
         }
     } else {
         // record splitting when the launch would not fill the chip

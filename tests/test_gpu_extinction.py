@@ -1129,3 +1129,46 @@ def test_band_structured_list_vs_oracle(eng, orc, gather):
         parts = [host(lbl.extinction(t, d, z, wbegin=a, wcount=b - a))
                  for a, b in zip(bounds[:-1], bounds[1:])]
         assert np.array_equal(np.concatenate(parts, axis=2), ext)
+
+
+def test_mode_switch_on_one_plan_with_resident_layers(eng, orc):
+    """Found by tools/fuzz_r4.py (round 4; the bug was in the round-3 library too): a plan used with
+    the staged kernel (phase split > 1: partial-sum planes written) and THEN in automatic mode,
+    where the resident-profile kernel computes layers the staged kernel skips, had the combine
+    pass add the earlier call's planes to the resident kernel's result -- up to 2 x the truth on
+    a used plan, correct on a fresh one (fresh zero pages).  The combine passes now leave the
+    layers of another kernel alone."""
+    from pyratbay_amd import synth
+    case = synth.lbl_case(40001, 12, 150000, wnstep=0.02, wnosamp=60, nlor=12, ndop=6,
+                          extent=60.0, cutoff=0.768, niso=3, seed=41013,
+                          bands=dict(nbands=5, contrast=450.0, in_bands=0.84))
+    g, atm, ln, iso, vg = (case[k] for k in ('grid', 'atm', 'lines', 'iso', 'voigt'))
+    vt = eng.VoigtTable.build(vg['lorentz'], vg['doppler'], vg['size'], g['ownstep'], 60)
+    ll = eng.LineList(ln['lwn'], ln['elow'], ln['gf'], ln['lid'], 3, g['own'])
+    t, d, z = eng.dev(atm['temp']), eng.dev(atm['dens']), eng.dev(iso['isoz'])
+
+    def plan():
+        return eng.LBL(vt, ll, g['wn'], g['divisors'], atm['mol_radius'], atm['mol_mass'],
+                       iso['isoimol'], iso['isomass'], iso['isoratio'], iso['isoiext'],
+                       vg['cutoff'], 1e-6, max_layers=12)
+    fresh = plan()
+    want = host(fresh.extinction(t, d, z))
+    assert fresh.last_gather_kernel == 'k_ext_resident+k_ext_staged'
+    assert fresh.last_layer_kinds(12)[0].sum() >= 1            # some layers resident
+    used = plan()
+    for mode in ('staged', 'auto', 'wave', 'auto', 'global', 'auto'):
+        used.set_gather_mode(mode)
+        got = host(used.extinction(t, d, z))
+        assert np.array_equal(got == 0, want == 0), mode
+        np.testing.assert_allclose(got, want, rtol=1e-12, err_msg=mode)
+        if mode == 'auto':
+            assert np.array_equal(got, want), 'automatic mode on a used plan != a fresh plan'
+    profile = vt.flat()
+    for layer in (0, 11):
+        ref = np.zeros((1, g['nwave']))
+        orc.extinction(ref, profile, vt.size, vt.index, vg['lorentz'], vg['doppler'], g['wn'],
+                       g['own'], g['divisors'], atm['dens'][layer], atm['mol_radius'],
+                       atm['mol_mass'], iso['isoimol'], iso['isomass'], iso['isoratio'],
+                       iso['isoz'][:, layer].copy(), iso['isoiext'], ln['lwn'], ln['elow'],
+                       ln['gf'], ln['lid'], vg['cutoff'], 1e-6, atm['temp'][layer], 0, 1, 0)
+        np.testing.assert_allclose(want[layer], ref, rtol=RTOL)

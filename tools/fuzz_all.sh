@@ -15,3 +15,4 @@ run tools/fuzz_dropin.py $((8000 * s))
 run tools/fuzz_opacity.py $((2000 * s))
 run tools/fuzz_r3.py $((3000 * s))
 run tools/fuzz_resdyn.py $((3000 * s))
+run tools/fuzz_r4.py $((400 * s))
