@@ -298,6 +298,20 @@ def main(args):
             k['frac'] = k['achieved'] / HBM_PEAK_GBS
         kernels.sort(key=lambda k: -k['kernel_ms'])
         dom = kernels[0]
+        # HBM traffic of the dominant kernel from the PMC passes (tools/pmc_traffic.py), accepted
+        # only for THIS build of the library
+        traffic = None
+        try:
+            import hashlib
+            rec = json.load(open(os.path.join(ROOT, 'profiles', 'pmc_traffic.json')))
+            so = os.path.join(ROOT, 'pyratbay_amd', 'libpbhip.so')
+            if rec.get('libpbhip_sha256') == hashlib.sha256(open(so, 'rb').read()).hexdigest():
+                wl = 'c5-emission' if rt == 'emission' else 'c5'
+                for name, e in rec.get(wl, {}).get('kernels', {}).items():
+                    if dom['kernel'].split('<')[0] in name:
+                        traffic = e['hbm_bytes_per_launch']
+        except Exception:                                       # noqa: BLE001
+            traffic = None
         path_bytes = (16.0 * NSPEC + 32.0) * nlayers * nwave + 8.0 * nwave
         out_json = {
             'metric': 'pyrat.eval() calls/sec (1e5 wavenumbers x 80 layers, sampled cross sections'
@@ -317,7 +331,7 @@ def main(args):
                        'init_seconds': round(t_init, 3), 'one_pass': one_pass},
             'roofline': {'bound': 'hbm', 'kernel': dom['kernel'], 'achieved': dom['achieved'],
                          'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': dom['frac'],
-                         'traffic': None, 'kernel_ms': dom['kernel_ms'],
+                         'traffic': traffic, 'kernel_ms': dom['kernel_ms'],
                          'kernel_bytes': dom['kernel_bytes'], 'binding': dom['bound_by'],
                          'other_kernels': kernels[1:],
                          'note': 'bytes = what one launch of 64 walkers must move: table slices '

@@ -17,6 +17,8 @@ b = shard_bounds(case['grid']['nwave'], nshard)
 r = nshard // 2
 model = engine.LBLSpectrum(case, rt_path=w.get('rt_path', 'transit'), wbegin=int(b[r]),
                            wcount=int(b[r + 1] - b[r]))
+if os.environ.get('PB_BENCH_GATHER'):
+    model.lbl.set_gather_mode(os.environ['PB_BENCH_GATHER'])
 for _ in range(2):
     model.run()
 torch.cuda.synchronize()
@@ -30,7 +32,7 @@ for _ in range(steps):
     torch.cuda.synchronize()
     for i in range(3):
         tot[i] += ev[i].elapsed_time(ev[i + 1])
-print(f'{name} shard 1/{nshard}: extinction {tot[0]/steps:.3f} ms  odepth {tot[1]/steps:.3f} ms  '
+print(f'{name} shard 1/{nshard} [{model.lbl.last_gather_kernel}]: extinction {tot[0]/steps:.3f} ms  odepth {tot[1]/steps:.3f} ms  '
       f'spectrum {tot[2]/steps:.3f} ms  total {sum(tot)/steps:.3f} ms '
       f'({steps/sum(tot)*1e3:.1f} spectra/s)')
 

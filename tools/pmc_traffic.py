@@ -21,8 +21,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def counter_pass(counter, workload, out):
     env = dict(os.environ, TMPDIR='/tmp')
-    subprocess.run(['rocprofv3', '--pmc', counter, '--output-format', 'csv', '-d', out, '--',
-                    sys.executable, os.path.join(ROOT, 'tools', 'bench_stages.py'), workload, '3'],
+    if workload.startswith('c5'):
+        cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--workload', workload, '--steps', '4',
+               '--warmup', '1', '--no-cpu-baseline']
+    else:
+        cmd = [sys.executable, os.path.join(ROOT, 'tools', 'bench_stages.py'), workload, '3']
+    subprocess.run(['rocprofv3', '--pmc', counter, '--output-format', 'csv', '-d', out, '--'] + cmd,
                    check=True, cwd=ROOT, env=env, stdout=subprocess.DEVNULL,
                    stderr=subprocess.DEVNULL)
     acc = {}
@@ -35,6 +39,13 @@ def counter_pass(counter, workload, out):
     return {k: sum(v) / len(v) for k, v in acc.items()}
 
 
+def entry(kern, fetch, write):
+    f_kib, w_kib = fetch.get(kern, 0.0), write.get(kern, 0.0)
+    return {'kernel': kern, 'FETCH_SIZE_KiB': f_kib, 'WRITE_SIZE_KiB': w_kib,
+            'hbm_bytes_per_launch': (2 * f_kib + w_kib) * 1024.0,
+            'raw_fetch_plus_write_bytes': (f_kib + w_kib) * 1024.0}
+
+
 def main():
     workloads = sys.argv[1:] or ['c2']
     so = os.path.join(ROOT, 'pyratbay_amd', 'libpbhip.so')
@@ -43,12 +54,19 @@ def main():
         base = os.path.join(ROOT, 'gpurun_out', f'pmc_traffic_{wl}')
         fetch = counter_pass('FETCH_SIZE', wl, base + '_f')
         write = counter_pass('WRITE_SIZE', wl, base + '_w')
+        if wl.startswith('c5'):
+            # the retrieval batch: every big kernel of a 64-walker launch (bench_c5 picks its
+            # dominant one); WRITE_SIZE of 8-byte-per-lane stores is tallied double on gfx950
+            # (tools/write_size_probe.hip), FETCH_SIZE of 16-byte-per-lane loads at half
+            keep = [k for k in fetch if any(t in k for t in ('k_transit_mfma', 'k_interp_ec_batch',
+                                                              'k_emission_fused', 'k_table_transit'))]
+            res[wl] = {'kernels': {k: entry(k, fetch, write) for k in keep}}
+            for k in keep:
+                print(wl, res[wl]['kernels'][k])
+            continue
         kern = max((k for k in fetch if 'k_ext_' in k and 'resident' not in k),
                    key=lambda k: fetch[k])
-        f_kib, w_kib = fetch[kern], write.get(kern, 0.0)
-        res[wl] = {'kernel': kern, 'FETCH_SIZE_KiB': f_kib, 'WRITE_SIZE_KiB': w_kib,
-                   'hbm_bytes_per_launch': (2 * f_kib + w_kib) * 1024.0,
-                   'raw_fetch_plus_write_bytes': (f_kib + w_kib) * 1024.0}
+        res[wl] = entry(kern, fetch, write)
         print(wl, res[wl])
     res['note'] = ('rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, mean over the '
                    'dispatches of the dominant gather kernel; hbm_bytes_per_launch = 2*FETCH_SIZE + '
