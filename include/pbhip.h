@@ -464,6 +464,19 @@ int pb_transit_spectrum_batch(double *spectrum_d, double *depth_d, int32_t *idee
                               const double *radius_d, double rstar, int itop, int ibottom,
                               double maxdepth, int nlayers, int nwave, int nwalkers,
                               void *work_d, void *stream);
+/* The same batch with its columns in an order of the caller's choosing (retrieval batches:
+ * columns sorted by the row at which a typical model crosses maxdepth).  ec_d[nwalkers,nlayers,
+ * nwave] holds the columns IN THAT ORDER; column_d[nwave] gives the grid index of each, and
+ * spectrum_d[nwalkers,nwave] is written in grid order.  The optical depths are formed row tile by
+ * row tile and a wavefront stops at the tile in which its 32 columns have all crossed maxdepth --
+ * the reference's per-column exit (_trapezoid.c:259-273) at tile granularity: neither the
+ * remaining products nor the deeper layers of ec are touched.  Per column the arithmetic does not
+ * depend on the order: spectra equal those of pb_transit_spectrum_batch bit for bit.  2 ... 128
+ * impact parameters, nwave >= 2, no cloud deck; work_d as above (required). */
+int pb_transit_spectrum_ordered(double *spectrum_d, const double *ec_d, const double *raypath_d,
+                                const double *radius_d, const int32_t *column_d, double rstar,
+                                int itop, int ibottom, double maxdepth, int nlayers, int nwave,
+                                int nwalkers, void *work_d, void *stream);
 /* interp_ec + optical depth + transmission of a batch in ONE pass (the retrieval inner loop,
  * pyrat_obj.py:225-385: opacity/line_sampling.py:394-463 -> _extcoeff.c:367-418, then
  * opacity/optic_depth.py:103-112 and spectrum/radiative_transfer.py:57-71, no cloud deck):

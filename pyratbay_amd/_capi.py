@@ -78,6 +78,7 @@ _PROTOS = {
     'pb_interp_ec_batch': [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp],
     'pb_transit_work_doubles': [i32, i32, i32, i32, i32],
     'pb_transit_spectrum_batch': [vp, vp, vp, vp, vp, vp, f64, i32, i32, f64, i32, i32, i32, vp, vp],
+    'pb_transit_spectrum_ordered': [vp, vp, vp, vp, vp, f64, i32, i32, f64, i32, i32, i32, vp, vp],
     'pb_table_transit_supported': [i32, i32, i32, i32, i32, i32],
     'pb_table_transit_work_doubles': [i32, i32, i32, i32, i32],
     'pb_table_transit_batch': [vp, vp, vp, vp, vp, vp, vp, f64, i32, i32, f64, i32, i32, i32, i32,

@@ -17,6 +17,7 @@
 #include <algorithm>
 #include <climits>
 #include <cstdlib>
+#include <type_traits>
 
 #include "pb_common.h"
 
@@ -748,6 +749,127 @@ __global__ __launch_bounds__(TB, WPS) void k_transit_mfma(
                               maxdepth, rstar);
 }
 
+// The same products ROW TILE BY ROW TILE, with the reference's early exit at tile granularity
+// (_trapezoid.c:259-273: a column is finished at the first row whose optical depth exceeds
+// maxdepth).  Row tile m needs the layers 0 .. 16m + 15 only, so the B operands stay in registers
+// (2 doubles per K-step and lane: 80 registers at 80 layers) while ONE row tile's accumulators are
+// live; its rows go through the epilogue at once (carry, sums and first crossing kept across
+// tiles), and when every column of the wavefront has crossed, the remaining tiles -- their products
+// AND the loads of their layers, which are issued one tile ahead -- are skipped.  Per column the
+// products, their order and the epilogue's arithmetic are those of k_transit_mfma: same bits.
+// Columns that cross at similar rows must sit together for the exit to happen: the caller orders
+// the columns (TableSpectrum.column_order) and passes `scatter`, the grid index of each column.
+template <int MT, int WPS, int TB>
+__global__ __launch_bounds__(TB, WPS) void k_transit_mfma_rows(
+    double *spectrum, const double *ec, const double *qblk, const double *radius, int nblk,
+    double rstar, int itop, int ibottom, double maxdepth, int nlayers, int nwave,
+    const int32_t *scatter)
+{
+    extern __shared__ __align__(16) double s_q[];         // [nblk][64] | rad[16 MT]
+    const int w = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nimpact = min(ibottom, nlayers) - itop;
+    double *s_rad = s_q + (size_t)nblk * 64;
+    {
+        stage_qblocks<MT, TB>(s_q, qblk + (int64_t)w * nblk * 64, tid);
+        for (int r = tid; r < 16 * MT; r += TB)
+            s_rad[r] = r < nimpact ? radius[(int64_t)w * nlayers + itop + r] : 0.0;
+    }
+    __syncthreads();
+    const int c0 = (blockIdx.x * (TB / 64) + wave) * 32;
+    if (c0 >= nwave)
+        return;                                           // (after the only barrier)
+    const int kq = lane >> 4, n = lane & 15;
+    const int col0 = c0 + 2 * n;
+    const bool ok[2] = {col0 < nwave, col0 + 1 < nwave};
+    const int cpair = max(min(col0, nwave - 2), 0);
+    const bool second = col0 != cpair;
+    const double *src = ec + ((int64_t)w * nlayers + itop) * nwave + cpair;
+    const int KS = (nimpact + 3) / 4;
+    double b[4 * MT][2];
+    auto loadb = [&](auto mbc) {
+        constexpr int mb = decltype(mbc)::value;
+#pragma unroll
+        for (int kk = 0; kk < 4; kk++) {
+            const int j = min(4 * (4 * mb + kk) + kq, nimpact - 1);
+            const d2u v = *reinterpret_cast<const d2u *>(src + (int64_t)j * nwave);
+            b[4 * mb + kk][0] = second ? v.y : v.x;
+            b[4 * mb + kk][1] = v.y;
+        }
+    };
+    const double rtop = s_rad[0];
+    const double *srad = s_rad + kq;
+    const int src_lane = (lane + 48) & 63;                // the lane one row above (16 below)
+    int first[2] = {ok[0] ? INT_MAX : -1, ok[1] ? INT_MAX : -1};   // (-1: nothing to wait for)
+    double acc[2] = {0.0, 0.0}, carry[2] = {0.0, 0.0};
+    const double *sq = s_q + lane;
+    bool done = false;
+    loadb(std::integral_constant<int, 0>{});
+    auto tile = [&](auto mc) {
+        constexpr int m = decltype(mc)::value;
+        if (done || 4 * m >= KS)                          // uniform
+            return;
+        // the next tile's layers are requested before this tile's products (two tiles ahead:
+        // measured slower, 1.27 against 1.16 ms at C5's shape -- the loads an exit wastes)
+        if constexpr (m + 1 < MT)                         // (clamped rows: harmless past the end)
+            loadb(std::integral_constant<int, m + 1>{});
+        v4d C[2] = {v4d{0.0, 0.0, 0.0, 0.0}, v4d{0.0, 0.0, 0.0, 0.0}};
+#pragma unroll
+        for (int ks = 0; ks < 4 * m + 4; ks++) {
+            const double a = sq[(qblocks(m) + ks) * 64];
+            C[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b[ks][0], C[0], 0, 0, 0);
+            C[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b[ks][1], C[1], 0, 0, 0);
+        }
+#pragma unroll
+        for (int t = 0; t < 2; t++) {
+            int f = INT_MAX;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int r = 16 * m + 4 * j + kq;
+                if (r < nimpact && C[t][j] > maxdepth)
+                    f = min(f, r);
+            }
+            f = min(f, __shfl_xor(f, 16));
+            f = min(f, __shfl_xor(f, 32));
+            // (an earlier tile's crossing is below every row of this one)
+            const int fst = first[t] == INT_MAX ? f : first[t];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int r = 16 * m + 4 * j + kq;
+                const bool in = r < nimpact && r <= fst;
+                const double rr = srad[16 * m + 4 * j];
+                const double fv = in ? pb::exp_s(-C[t][j]) * rr : 0.0;
+                const double up = __shfl(fv, src_lane);   // q > 0: row r - 1; q = 0: row r + 3
+                const double fprev = kq > 0 ? up : carry[t];
+                carry[t] = up;
+                if (in && r >= 1)
+                    acc[t] += (rr - srad[16 * m + 4 * j - 1]) * (fprev + fv);
+            }
+            first[t] = fst;
+        }
+        done = __all(first[0] != INT_MAX && first[1] != INT_MAX);
+    };
+    static_assert(MT <= 8, "row tiles");
+    tile(std::integral_constant<int, 0>{});
+    if constexpr (MT > 1) tile(std::integral_constant<int, 1>{});
+    if constexpr (MT > 2) tile(std::integral_constant<int, 2>{});
+    if constexpr (MT > 3) tile(std::integral_constant<int, 3>{});
+    if constexpr (MT > 4) tile(std::integral_constant<int, 4>{});
+    if constexpr (MT > 5) tile(std::integral_constant<int, 5>{});
+    if constexpr (MT > 6) tile(std::integral_constant<int, 6>{});
+    if constexpr (MT > 7) tile(std::integral_constant<int, 7>{});
+#pragma unroll
+    for (int t = 0; t < 2; t++) {
+        double a = acc[t];
+        a += __shfl_xor(a, 16);
+        a += __shfl_xor(a, 32);
+        if (kq == 0 && ok[t]) {
+            const int64_t dst = scatter ? scatter[col0 + t] : col0 + t;
+            spectrum[(int64_t)w * nwave + dst] = (rtop * rtop + 2 * (a * 0.5)) / (rstar * rstar);
+        }
+    }
+}
+
 // a wave-uniform flag written by an earlier kernel, by a scalar load
 __device__ __forceinline__ int uniform_flag(const int32_t *p)
 {
@@ -1448,7 +1570,7 @@ int pb_transit_fused_launch(double *depth_d, int32_t *ideep_d, double *spectrum_
                             const double *ec_d, const double *raypath_d, const double *radius_d,
                             int64_t npath, double rstar, int itop, int ibottom, double maxdepth,
                             int nlayers, int nwave, int nwalkers, int deck_row, double rsurf,
-                            hipStream_t s, double *work_d)
+                            hipStream_t s, double *work_d, const int32_t *scatter_d)
 {
     const int nrow = nlayers - itop;
     const int nimpact = std::min(ibottom, nlayers) - itop;
@@ -1477,8 +1599,12 @@ int pb_transit_fused_launch(double *depth_d, int32_t *ideep_d, double *spectrum_
     {
         // (read per call: the tests switch it inside one process)
         const char *mode = getenv("PB_TRANSIT_MFMA");
-        const bool no_mfma = mode && atoi(mode) == 0;
+        const bool no_mfma = mode && atoi(mode) == 0 && !scatter_d;   // (ordered: this form only)
         const int mt = pb::div_up(std::max(nimpact, 1), 16);
+        PB_REQUIRE(!scatter_d || (work_d && spectrum_d && !depth_d && !ideep_d && deck_row < 0 &&
+                                  nimpact > 1 && mt <= 8 && nwave >= 2),
+                   "pb_transit_spectrum_ordered: 2 ... 128 impact parameters and at least 2 "
+                   "columns (got %d, %d)", nimpact, nwave);
         if (!no_mfma && work_d && spectrum_d && !depth_d && !ideep_d && deck_row < 0 &&
             nimpact > 1 && mt <= 8 && nwave >= 2 && nwalkers >= 1) {
             const int nblk = qblocks(mt);
@@ -1499,6 +1625,44 @@ int pb_transit_fused_launch(double *depth_d, int32_t *ideep_d, double *spectrum_
             // threads per workgroup: a workgroup stages its walker's Q blocks (30 KB at 80
             // layers) once for TB / 64 x 32 columns
             const int tb = getenv("PB_MFMA_TB") ? atoi(getenv("PB_MFMA_TB")) : 512;
+            // row tile by row tile with the early exit (the default: 1.48 against 1.59 ms per 64
+            // walkers at C5's shape with the columns in grid order, 1.16 with ordered columns);
+            // PB_TRANSIT_MFMA=4: the layers-outer kernel it replaced, for A/B
+            if (scatter_d || !(mode && atoi(mode) == 4)) {
+#define PB_MFMA_ROWS(M, W, T)                                                                    \
+    do {                                                                                         \
+        if (lds > 64 * 1024)                                                                     \
+            PB_HIP(hipFuncSetAttribute(                                                          \
+                reinterpret_cast<const void *>(k_transit_mfma_rows<M, W, T>),                    \
+                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                          \
+        dim3 mgrid(pb::div_up(nwave, (T / 64) * 32), nwalkers);                                  \
+        k_transit_mfma_rows<M, W, T><<<mgrid, T, lds, s>>>(spectrum_d, ec_d, work_d, radius_d,   \
+                                                          nblk, rstar, itop, ibottom, maxdepth,  \
+                                                          nlayers, nwave, scatter_d);            \
+    } while (0)
+                switch (mt) {
+                case 1: PB_MFMA_ROWS(1, 4, 256); break;
+                case 2: PB_MFMA_ROWS(2, 4, 256); break;
+                case 3: PB_MFMA_ROWS(3, 4, 256); break;
+                case 4: PB_MFMA_ROWS(4, 4, 256); break;
+                case 5:
+                    if (tb >= 1024)
+                        PB_MFMA_ROWS(5, 4, 1024);
+                    else if (tb >= 512)
+                        PB_MFMA_ROWS(5, 4, 512);
+                    else if (tb >= 256)
+                        PB_MFMA_ROWS(5, 4, 256);
+                    else
+                        PB_MFMA_ROWS(5, 4, 128);
+                    break;
+                case 6: PB_MFMA_ROWS(6, 2, 256); break;
+                case 7: PB_MFMA_ROWS(7, 2, 256); break;
+                default: PB_MFMA_ROWS(8, 2, 256); break;
+                }
+#undef PB_MFMA_ROWS
+                PB_LAUNCH_CHECK();
+                return PB_OK;
+            }
             switch (mt) {
             case 1: PB_MFMA(1, 4, 256); break;
             case 2: PB_MFMA(2, 4, 256); break;
@@ -1744,7 +1908,28 @@ int pb_transit_spectrum_batch(double *spectrum_d, double *depth_d, int32_t *idee
     const int64_t npath = ((int64_t)nrow * (nrow - 1)) / 2;
     return pb_transit_fused_launch(depth_d, ideep_d, spectrum_d, ec_d, raypath_d, radius_d, npath,
                                    rstar, itop, ibottom, maxdepth, nlayers, nwave, nwalkers, -1,
-                                   0.0, pb::as_stream(stream), reinterpret_cast<double *>(work_d));
+                                   0.0, pb::as_stream(stream), reinterpret_cast<double *>(work_d),
+                                   nullptr);
+}
+
+int pb_transit_spectrum_ordered(double *spectrum_d, const double *ec_d, const double *raypath_d,
+                                const double *radius_d, const int32_t *column_d, double rstar,
+                                int itop, int ibottom, double maxdepth, int nlayers, int nwave,
+                                int nwalkers, void *work_d, void *stream)
+{
+    PB_REQUIRE(nlayers > 0 && nwave >= 0 && nwalkers >= 0, "pb_transit_spectrum_ordered: bad shape");
+    PB_REQUIRE(itop >= 0 && itop < nlayers, "pb_transit_spectrum_ordered: itop out of range");
+    PB_REQUIRE(ibottom <= nlayers, "pb_transit_spectrum_ordered: ibottom > nlayers");
+    if (nwave == 0 || nwalkers == 0)
+        return PB_OK;
+    const int nrow = nlayers - itop;
+    PB_REQUIRE(spectrum_d && ec_d && radius_d && raypath_d && column_d && work_d,
+               "pb_transit_spectrum_ordered: null pointer");
+    const int64_t npath = ((int64_t)nrow * (nrow - 1)) / 2;
+    return pb_transit_fused_launch(nullptr, nullptr, spectrum_d, ec_d, raypath_d, radius_d, npath,
+                                   rstar, itop, ibottom, maxdepth, nlayers, nwave, nwalkers, -1,
+                                   0.0, pb::as_stream(stream), reinterpret_cast<double *>(work_d),
+                                   column_d);
 }
 
 int pb_table_transit_supported(int nmol, int ntemp, int nlayers, int itop, int ibottom, int nwave)

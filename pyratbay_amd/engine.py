@@ -534,6 +534,20 @@ def transit_spectrum_batch(ec, raypath, radius, rstar, itop, ibottom, maxdepth,
     return (spectrum, depth, ideep) if want_depth else spectrum
 
 
+def transit_spectrum_ordered(ec, raypath, radius, column, rstar, itop, ibottom, maxdepth):
+    """transit_spectrum_batch for ec[nw, L, W] whose columns are in the order `column` (int32[W]:
+    grid index of each column): spectrum[nw, W] in GRID order.  Wavefronts stop at the row tile in
+    which their 32 columns have all crossed maxdepth (pb_transit_spectrum_ordered)."""
+    nw, nlayers, nwave = ec.shape
+    spectrum = torch.empty((nw, nwave), dtype=torch.float64, device=ec.device)
+    nwork = _capi.lib().pb_transit_work_doubles(nlayers, int(itop), int(ibottom), nwave, nw)
+    work = torch.empty(nwork, dtype=torch.float64, device=ec.device)
+    call('pb_transit_spectrum_ordered', _ptr(spectrum), _ptr(ec), _ptr(raypath), _ptr(radius),
+         _ptr(column), float(rstar), int(itop), int(ibottom), float(maxdepth), nlayers, nwave, nw,
+         _ptr(work), _stream())
+    return spectrum
+
+
 def table_transit_supported(nmol, ntemp, nlayers, itop, ibottom, nwave):
     """Whether the one-pass form (table_transit_batch) exists for this shape."""
     return bool(_capi.lib().pb_table_transit_supported(int(nmol), int(ntemp), int(nlayers),
@@ -1173,9 +1187,23 @@ class TableSpectrum:
 
     def __init__(self, etable, ttable, wn, radius, rstar, rt_path='transit', itop=0,
                  maxdepth=10.0, quadrature_mu=None, quadrature_weights=None, continuum=None,
-                 timestamps=True):
+                 timestamps=True, column_order='auto'):
         require_gpu()
         self._timer = StageTimer() if timestamps else None
+        # eval_bands, transit geometry: the order the columns are worked in (see order_columns).
+        # 'auto': taken from the first walker of the first batch; None: grid order
+        self.column_order = None
+        self.etable_ordered = None
+        if isinstance(column_order, str) and column_order == 'auto' and \
+                os.environ.get('PB_COLUMN_ORDER', '1') == '0':
+            column_order = None                       # (A/B switch: grid order)
+        self._auto_order = isinstance(column_order, str) and column_order == 'auto'
+        if isinstance(column_order, str) and not self._auto_order:
+            raise ValueError("column_order: 'auto', None or a permutation of range(nwave)")
+        if column_order is not None and not self._auto_order:
+            self._pending_order = column_order
+        else:
+            self._pending_order = None
         self.continuum = continuum          # pyratbay_amd.continuum.Continuum or None
         self.etable = etable if isinstance(etable, torch.Tensor) else dev(etable)
         self.nspec, self.ntemp, self.nlayers, self.nwave = self.etable.shape
@@ -1193,6 +1221,45 @@ class TableSpectrum:
             self.mu = dev(quadrature_mu)
             self.weights = dev(quadrature_weights)
         self.ec = torch.zeros((self.nlayers, self.nwave), dtype=torch.float64, device='cuda')
+        if self._pending_order is not None:
+            self.set_column_order(self._pending_order)
+
+    def set_column_order(self, order):
+        """Work the columns of eval_bands' transit batches in the order `order` (a permutation of
+        range(nwave); None: back to grid order).  A second copy of the table is kept with its
+        wavenumber axis in that order, so that every stage still streams contiguous columns."""
+        if order is None:
+            self.column_order = self.etable_ordered = None
+            return
+        order = torch.as_tensor(order, device='cuda').to(torch.int64).contiguous()
+        if order.shape != (self.nwave,) or \
+                not bool(torch.equal(torch.sort(order).values,
+                                     torch.arange(self.nwave, device='cuda'))):
+            raise ValueError('column order: not a permutation of range(nwave)')
+        out = torch.empty_like(self.etable)
+        for s in range(self.nspec):               # (species by species: a bounded temporary)
+            torch.index_select(self.etable[s], -1, order, out=out[s])
+        self.etable_ordered = out
+        self.column_order = order.to(torch.int32)
+
+    def order_columns(self, temp, dens, radius=None):
+        """Order the columns by the layer at which the model (temp[L], dens[L, nspec], radius[L])
+        becomes optically thick (its ideep, _trapezoid.c:259-273).  The reference stops a column
+        there; the matrix-core transit kernel can stop only when all 32 columns of a wavefront
+        have -- which neighbours on the wavenumber grid never do together (a line core next to a
+        window), and columns of similar depth do: at C5's shape 62 % of the products and 76 % of
+        the layer reads remain.  Any model near the ones to come will do (walkers of a retrieval
+        differ by per cent); the spectra do not depend on the order, only the time does."""
+        temp = (temp if isinstance(temp, torch.Tensor) else dev(temp)).reshape(1, -1)
+        dens = (dens if isinstance(dens, torch.Tensor) else dev(dens)).reshape(1, self.nlayers, -1)
+        rad = self.radius if radius is None else \
+            (radius if isinstance(radius, torch.Tensor) else dev(radius))
+        rad = rad.reshape(1, -1).contiguous()
+        ec = interp_ec_batch(self.etable, self.ttable, temp.contiguous(), dens.contiguous())
+        _, _, ideep = transit_spectrum_batch(ec, transit_path_device(rad, self.itop), rad,
+                                             self.rstar, self.itop, self.nlayers, self.maxdepth,
+                                             want_depth=True)
+        self.set_column_order(torch.sort(ideep[0], stable=True).indices)
 
     def set_radius(self, radius):
         self.radius = dev(radius)
@@ -1266,6 +1333,12 @@ class TableSpectrum:
             radius = self.radius.view(1, -1)
         shared_radius = radius.shape[0] == 1
         transit = self.rt_path == 'transit'
+        if transit and self._auto_order and self.column_order is None and nw > 0 and \
+                self.nwave >= 64 and not self._one_pass():
+            # (a walker outside the table's range would order by garbage: wait for a valid one)
+            t0 = temps[0]
+            if bool(((t0 >= self.tmin) & (t0 <= self.tmax)).all()):
+                self.order_columns(t0, dens[0], radius[0])
         path1 = (transit_path_device(radius[0], self.itop).view(1, -1)
                  if shared_radius and transit else None)
         # Consecutive chunks are independent: with `streams` > 1 (PB_EVAL_STREAMS) chunk i runs on
@@ -1326,7 +1399,9 @@ class TableSpectrum:
                                           self.maxdepth)
             bands.integrate_batch(spectra, out[w0:w1])
             return
-        ec = interp_ec_batch(self.etable, self.ttable, temps[w0:w1], dens[w0:w1])
+        ordered = self.rt_path == 'transit' and self.column_order is not None
+        ec = interp_ec_batch(self.etable_ordered if ordered else self.etable, self.ttable,
+                             temps[w0:w1], dens[w0:w1])
         if self.rt_path != 'transit':
             rad = radius.expand(n, -1) if shared_radius else radius[w0:w1]
             intervals = (rad[:, :-1] - rad[:, 1:]).contiguous()            # -diff(radius)
@@ -1340,6 +1415,11 @@ class TableSpectrum:
         else:
             rad = radius[w0:w1].contiguous()
             path = transit_path_device(rad, self.itop)
-        spectra = transit_spectrum_batch(ec, path, rad, self.rstar, self.itop, self.nlayers,
-                                         self.maxdepth)
+        if ordered:
+            # columns in depth order: wavefronts stop at the row tile where theirs have all crossed
+            spectra = transit_spectrum_ordered(ec, path, rad, self.column_order, self.rstar,
+                                               self.itop, self.nlayers, self.maxdepth)
+        else:
+            spectra = transit_spectrum_batch(ec, path, rad, self.rstar, self.itop, self.nlayers,
+                                             self.maxdepth)
         bands.integrate_batch(spectra, out[w0:w1])

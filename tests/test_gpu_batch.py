@@ -125,6 +125,86 @@ def test_transit_spectrum_batch_vs_oracle(eng, orc, itop, ibottom, maxdepth, row
         np.testing.assert_allclose(host(only[w]), ws, rtol=RTOL)
 
 
+@pytest.mark.parametrize('nlayers', [2, 9, 16, 17, 40, 64, 81, 100, 128])
+def test_transit_ordered_columns(eng, orc, monkeypatch, nlayers):
+    """pb_transit_spectrum_ordered (row tile by row tile, a wavefront stops where its 32 columns
+    have all crossed maxdepth): for the columns in a random order and in the order of their first
+    crossing, every instantiation (1 ... 8 row tiles), ragged widths, top layers, bottoms and
+    maximum depths that stop early / never -- the spectra in grid order, bit for bit those of
+    pb_transit_spectrum_batch on the unpermuted ec (the layers-outer kernel, PB_TRANSIT_MFMA=4,
+    and the row-tile kernel in grid order), 1e-13 of the vector kernels, and of the oracle."""
+    import torch
+    rng = np.random.default_rng(40 + nlayers)
+    W = int(rng.choice([2, 31, 33, 700, 1601]))
+    nw = 3
+    c = cases.column_case(seed=60 + nlayers, nlayers=nlayers, nwave=W)
+    # columns that cross at very different rows (a line core beside a window)
+    ecs = np.array([c['ec'] * 10.0**rng.uniform(-3, 3, (1, W)) * 10.0**rng.uniform(-1, 1)
+                    for _ in range(nw)])
+    radius = np.array([np.sort(c['radius'] * (1 + 0.01 * rng.uniform(-1, 1)))[::-1]
+                       for _ in range(nw)])
+    rad_d, ec_d = eng.dev(radius), eng.dev(ecs)
+    for itop, ibottom, maxdepth in ((0, nlayers, 10.0), (nlayers // 3, nlayers, 0.3),
+                                    (0, max(2, nlayers - 1), np.inf)):
+        if min(ibottom, nlayers) - itop < 2:
+            continue
+        path = eng.transit_path_device(rad_d, itop)
+        monkeypatch.setenv('PB_TRANSIT_MFMA', '4')
+        ref = eng.transit_spectrum_batch(ec_d, path, rad_d, c['rstar'], itop, ibottom, maxdepth)
+        monkeypatch.delenv('PB_TRANSIT_MFMA')
+        rows = eng.transit_spectrum_batch(ec_d, path, rad_d, c['rstar'], itop, ibottom, maxdepth)
+        assert torch.equal(rows, ref)
+        _, _, ideep = eng.transit_spectrum_batch(ec_d[:1], path[:1], rad_d[:1], c['rstar'], itop,
+                                                 ibottom, maxdepth, want_depth=True)
+        by_depth = torch.sort(ideep[0], stable=True).indices
+        for order in (torch.as_tensor(rng.permutation(W), device='cuda'), by_depth):
+            got = eng.transit_spectrum_ordered(ec_d[:, :, order].contiguous(), path, rad_d,
+                                               order.to(torch.int32), c['rstar'], itop, ibottom,
+                                               maxdepth)
+            assert torch.equal(got, ref), (itop, ibottom, maxdepth)
+        monkeypatch.setenv('PB_TRANSIT_MFMA', '0')
+        vec = eng.transit_spectrum_batch(ec_d, path, rad_d, c['rstar'], itop, ibottom, maxdepth)
+        monkeypatch.delenv('PB_TRANSIT_MFMA')
+        np.testing.assert_allclose(host(ref), host(vec), rtol=1e-13)
+    wd, wi = orc.optical_depth_transit(ecs[1], radius[1], 0, nlayers, 10.0)
+    ws = orc.transmission(wd, radius[1], c['rstar'], wi, 0)
+    path = eng.transit_path_device(rad_d, 0)
+    got = eng.transit_spectrum_batch(ec_d, path, rad_d, c['rstar'], 0, nlayers, 10.0)
+    np.testing.assert_allclose(host(got[1]), ws, rtol=RTOL)
+
+
+def test_eval_bands_column_order(eng):
+    """TableSpectrum.eval_bands orders the columns by the first walker's optical depth
+    (column_order='auto'): band fluxes bit for bit those of the grid order (column_order=None)
+    and of an order given by the caller; a non-permutation is refused."""
+    import torch
+    from pyratbay_amd import synth
+    rng = np.random.default_rng(77)
+    nspec, ntemp, L, W, nw = 3, 6, 33, 2049, 10
+    g = synth.spectral_grid(4000.0, 4000.0 + (W - 1) * 0.05 + 0.01, 0.05, 12)
+    wn = g['wn']
+    ttable = np.linspace(300.0, 3000.0, ntemp)
+    press = np.logspace(-6, 2, L)
+    etable = 10.0**rng.uniform(-27, -21, (nspec, ntemp, L, 1)) * \
+        10.0**rng.uniform(-3, 3, (nspec, 1, 1, W))
+    radius0 = np.linspace(8.0e9, 7.0e9, L)
+    bands = [(lo, np.ones(hi - lo), 1.0) for lo, hi in ((5, 900), (800, 2040))]
+    pb = eng.PassBands(wn, bands)
+    temps = 1500.0 * (1 + 0.1 * rng.uniform(-1, 1, (nw, 1))) * np.linspace(0.8, 1.2, L)
+    dens = (press / temps)[:, :, None] * 7.2e21 * 10.0**rng.uniform(-7, -3, (nw, 1, nspec))
+    radius = radius0[None] * (1 + 0.01 * rng.uniform(-1, 1, (nw, 1)))
+    args = [eng.dev(x) for x in (temps, dens)]
+    out = {}
+    for name, order in (('grid', None), ('auto', 'auto'), ('given', rng.permutation(W))):
+        model = eng.TableSpectrum(etable, ttable, wn, radius0, 8.8e10, column_order=order)
+        out[name] = model.eval_bands(*args, pb, radius=eng.dev(radius)).clone()
+        assert (model.column_order is None) == (name == 'grid')
+    assert torch.equal(out['auto'], out['grid']) and torch.equal(out['given'], out['grid'])
+    assert bool(torch.isfinite(out['grid']).all())
+    with pytest.raises(ValueError):
+        eng.TableSpectrum(etable, ttable, wn, radius0, 8.8e10, column_order=np.zeros(W, int))
+
+
 def test_fused_transit_equals_split(eng):
     """The fused column kernel against the two-kernel form it replaced (a separate process so
     that PB_TRANSIT=split is read afresh): same depth, ideep, spectrum bits."""
