@@ -504,6 +504,16 @@ int pb_emission_flux_batch(double *flux_d, const double *ec_d, const double *int
                            const double *wn_d, const double *temp_d, const double *mu_d,
                            const double *weights_d, int nmu, double maxdepth, int itop,
                            int ibottom, int nlayers, int nwave, int nwalkers, void *stream);
+/* The same batch with its columns in an order of the caller's choosing (columns that become
+ * optically thick at similar layers side by side: a wavefront walks the layers until its LAST lane
+ * has reached maxdepth, _trapezoid.c:190-200).  ec_d and wn_d hold the columns in that order,
+ * column_d[nwave] the grid index of each; flux_d[nwalkers,nwave] is written in grid order.  Per
+ * column the arithmetic does not depend on the order: same bits as pb_emission_flux_batch. */
+int pb_emission_flux_ordered(double *flux_d, const double *ec_d, const double *intervals_d,
+                             const double *wn_d, const double *temp_d, const double *mu_d,
+                             const double *weights_d, const int32_t *column_d, int nmu,
+                             double maxdepth, int itop, int ibottom, int nlayers, int nwave,
+                             int nwalkers, void *stream);
 /* PassBand.integrate for a batch of full-grid spectra: bandflux_d[nwalkers,nbands]
  * (x heights_d[b] when given). */
 int pb_band_integrate_batch(double *bandflux_d, const double *spectrum_d, const double *wn_d,

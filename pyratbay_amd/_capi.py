@@ -84,6 +84,7 @@ _PROTOS = {
     'pb_table_transit_batch': [vp, vp, vp, vp, vp, vp, vp, f64, i32, i32, f64, i32, i32, i32, i32,
                                i32, vp, vp],
     'pb_emission_flux_batch': [vp, vp, vp, vp, vp, vp, vp, i32, f64, i32, i32, i32, i32, i32, vp],
+    'pb_emission_flux_ordered': [vp, vp, vp, vp, vp, vp, vp, vp, i32, f64, i32, i32, i32, i32, i32, vp],
     'pb_band_integrate_batch': [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp],
     'pb_reject_walkers': [vp, vp, f64, f64, i32, i32, i32, vp],
     'pb_optdepth': [vp, vp, i64, vp, i32, f64, vp, i32, i32, vp],

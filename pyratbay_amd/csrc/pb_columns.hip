@@ -524,7 +524,7 @@ template <int MU>
 __global__ void k_emission_fused(double *flux, const double *ec, const double *intervals,
                                  const double *wn, const double *temp, const double *mu,
                                  const double *weights, int nmu, double maxdepth, int itop,
-                                 int ibottom, int nlayers, int nwave)
+                                 int ibottom, int nlayers, int nwave, const int32_t *scatter)
 {
     extern __shared__ double s_kt[];        // [2][nlayers]: kKB T of this walker and its reciprocal
     const int wk = blockIdx.y;
@@ -584,7 +584,8 @@ __global__ void k_emission_fused(double *flux, const double *ec, const double *i
             total += val * weights[m];
         }
     }
-    flux[(int64_t)wk * nwave + j] = total;
+    // (ordered batches: column j of ec / wn is column scatter[j] of the grid)
+    flux[(int64_t)wk * nwave + (scatter ? scatter[j] : j)] = total;
 }
 
 // ---------------------------------------------------------------------------
@@ -1138,10 +1139,37 @@ int pb_loglike(double *loglike_d, const double *bandflux_d, const double *data_d
     return PB_OK;
 }
 
+static int emission_batch(double *flux_d, const double *ec_d, const double *intervals_d,
+                          const double *wn_d, const double *temp_d, const double *mu_d,
+                          const double *weights_d, const int32_t *column_d, int nmu,
+                          double maxdepth, int itop, int ibottom, int nlayers, int nwave,
+                          int nwalkers, void *stream);
+
 int pb_emission_flux_batch(double *flux_d, const double *ec_d, const double *intervals_d,
                            const double *wn_d, const double *temp_d, const double *mu_d,
                            const double *weights_d, int nmu, double maxdepth, int itop,
                            int ibottom, int nlayers, int nwave, int nwalkers, void *stream)
+{
+    return emission_batch(flux_d, ec_d, intervals_d, wn_d, temp_d, mu_d, weights_d, nullptr, nmu,
+                          maxdepth, itop, ibottom, nlayers, nwave, nwalkers, stream);
+}
+
+int pb_emission_flux_ordered(double *flux_d, const double *ec_d, const double *intervals_d,
+                             const double *wn_d, const double *temp_d, const double *mu_d,
+                             const double *weights_d, const int32_t *column_d, int nmu,
+                             double maxdepth, int itop, int ibottom, int nlayers, int nwave,
+                             int nwalkers, void *stream)
+{
+    PB_REQUIRE(column_d || nwave == 0, "pb_emission_flux_ordered: null column index");
+    return emission_batch(flux_d, ec_d, intervals_d, wn_d, temp_d, mu_d, weights_d, column_d, nmu,
+                          maxdepth, itop, ibottom, nlayers, nwave, nwalkers, stream);
+}
+
+static int emission_batch(double *flux_d, const double *ec_d, const double *intervals_d,
+                          const double *wn_d, const double *temp_d, const double *mu_d,
+                          const double *weights_d, const int32_t *column_d, int nmu,
+                          double maxdepth, int itop, int ibottom, int nlayers, int nwave,
+                          int nwalkers, void *stream)
 {
     PB_REQUIRE(nlayers >= 1 && nwave >= 0 && nwalkers >= 0, "pb_emission_flux_batch: bad shape");
     PB_REQUIRE(nmu >= 1 && nmu <= kMaxMu, "pb_emission_flux_batch: nmu must be 1..%d", kMaxMu);
@@ -1157,11 +1185,11 @@ int pb_emission_flux_batch(double *flux_d, const double *ec_d, const double *int
     if (nmu <= 8)
         k_emission_fused<8><<<grid, kBlock, ((size_t)2 * nlayers + kMaxMu) * 8, pb::as_stream(stream)>>>(
         flux_d, ec_d, intervals_d, wn_d, temp_d, mu_d, weights_d, nmu, maxdepth, itop, ibottom,
-        nlayers, nwave);
+        nlayers, nwave, column_d);
     else
         k_emission_fused<kMaxMu><<<grid, kBlock, ((size_t)2 * nlayers + kMaxMu) * 8, pb::as_stream(stream)>>>(
         flux_d, ec_d, intervals_d, wn_d, temp_d, mu_d, weights_d, nmu, maxdepth, itop, ibottom,
-        nlayers, nwave);
+        nlayers, nwave, column_d);
     PB_LAUNCH_CHECK();
     return PB_OK;
 }

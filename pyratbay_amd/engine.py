@@ -574,11 +574,18 @@ def table_transit_batch(etable, ttable, temps, dens, raypath, radius, rstar, ito
     return spectrum
 
 
-def emission_flux_batch(ec, intervals, wn, temps, mu, weights, itop, ibottom, maxdepth):
+def emission_flux_batch(ec, intervals, wn, temps, mu, weights, itop, ibottom, maxdepth,
+                        column=None):
     """plane-parallel optical depth + emission flux for a batch: ec[nw, L, W],
-    intervals[nw, L-1], temps[nw, L] -> flux[nw, W] (no cloud deck)."""
+    intervals[nw, L-1], temps[nw, L] -> flux[nw, W] (no cloud deck).  With `column` (int32[W]) the
+    columns of ec and wn are in that order (grid index of each) and flux comes in grid order."""
     nw, nlayers, nwave = ec.shape
     flux = torch.empty((nw, nwave), dtype=torch.float64, device=ec.device)
+    if column is not None:
+        call('pb_emission_flux_ordered', _ptr(flux), _ptr(ec), _ptr(intervals.contiguous()),
+             _ptr(wn), _ptr(temps.contiguous()), _ptr(mu), _ptr(weights), _ptr(column), len(mu),
+             float(maxdepth), int(itop), int(ibottom), nlayers, nwave, nw, _stream())
+        return flux
     call('pb_emission_flux_batch', _ptr(flux), _ptr(ec), _ptr(intervals.contiguous()), _ptr(wn),
          _ptr(temps.contiguous()), _ptr(mu), _ptr(weights), len(mu), float(maxdepth), int(itop),
          int(ibottom), nlayers, nwave, nw, _stream())
@@ -1190,7 +1197,7 @@ class TableSpectrum:
                  timestamps=True, column_order='auto'):
         require_gpu()
         self._timer = StageTimer() if timestamps else None
-        # eval_bands, transit geometry: the order the columns are worked in (see order_columns).
+        # eval_bands: the order the columns are worked in (see order_columns).
         # 'auto': taken from the first walker of the first batch; None: grid order
         self.column_order = None
         self.etable_ordered = None
@@ -1225,7 +1232,7 @@ class TableSpectrum:
             self.set_column_order(self._pending_order)
 
     def set_column_order(self, order):
-        """Work the columns of eval_bands' transit batches in the order `order` (a permutation of
+        """Work the columns of eval_bands' batches in the order `order` (a permutation of
         range(nwave); None: back to grid order).  A second copy of the table is kept with its
         wavenumber axis in that order, so that every stage still streams contiguous columns."""
         if order is None:
@@ -1241,6 +1248,7 @@ class TableSpectrum:
             torch.index_select(self.etable[s], -1, order, out=out[s])
         self.etable_ordered = out
         self.column_order = order.to(torch.int32)
+        self.wn_ordered = self.wn[order].contiguous()
 
     def order_columns(self, temp, dens, radius=None):
         """Order the columns by the layer at which the model (temp[L], dens[L, nspec], radius[L])
@@ -1256,10 +1264,18 @@ class TableSpectrum:
             (radius if isinstance(radius, torch.Tensor) else dev(radius))
         rad = rad.reshape(1, -1).contiguous()
         ec = interp_ec_batch(self.etable, self.ttable, temp.contiguous(), dens.contiguous())
-        _, _, ideep = transit_spectrum_batch(ec, transit_path_device(rad, self.itop), rad,
-                                             self.rstar, self.itop, self.nlayers, self.maxdepth,
-                                             want_depth=True)
-        self.set_column_order(torch.sort(ideep[0], stable=True).indices)
+        if self.rt_path == 'transit':
+            _, _, ideep = transit_spectrum_batch(ec, transit_path_device(rad, self.itop), rad,
+                                                 self.rstar, self.itop, self.nlayers,
+                                                 self.maxdepth, want_depth=True)
+            ideep = ideep[0]
+        else:
+            # (emission: a wavefront of the fused kernel walks the layers until its last lane has
+            # reached maxdepth -- lanes that stop together waste nothing)
+            _, ideep = plane_parallel_optical_depth(
+                ec[0], (rad[0, :-1] - rad[0, 1:]).contiguous(), self.itop, self.nlayers,
+                self.maxdepth)
+        self.set_column_order(torch.sort(ideep, stable=True).indices)
 
     def set_radius(self, radius):
         self.radius = dev(radius)
@@ -1333,8 +1349,8 @@ class TableSpectrum:
             radius = self.radius.view(1, -1)
         shared_radius = radius.shape[0] == 1
         transit = self.rt_path == 'transit'
-        if transit and self._auto_order and self.column_order is None and nw > 0 and \
-                self.nwave >= 64 and not self._one_pass():
+        if self._auto_order and self.column_order is None and nw > 0 and self.nwave >= 64 and \
+                not (transit and self._one_pass()):
             # (a walker outside the table's range would order by garbage: wait for a valid one)
             t0 = temps[0]
             if bool(((t0 >= self.tmin) & (t0 <= self.tmax)).all()):
@@ -1399,14 +1415,16 @@ class TableSpectrum:
                                           self.maxdepth)
             bands.integrate_batch(spectra, out[w0:w1])
             return
-        ordered = self.rt_path == 'transit' and self.column_order is not None
+        ordered = self.column_order is not None
         ec = interp_ec_batch(self.etable_ordered if ordered else self.etable, self.ttable,
                              temps[w0:w1], dens[w0:w1])
         if self.rt_path != 'transit':
             rad = radius.expand(n, -1) if shared_radius else radius[w0:w1]
             intervals = (rad[:, :-1] - rad[:, 1:]).contiguous()            # -diff(radius)
-            spectra = emission_flux_batch(ec, intervals, self.wn, temps[w0:w1], self.mu,
-                                          self.weights, self.itop, self.nlayers, self.maxdepth)
+            spectra = emission_flux_batch(ec, intervals, self.wn_ordered if ordered else self.wn,
+                                          temps[w0:w1], self.mu, self.weights, self.itop,
+                                          self.nlayers, self.maxdepth,
+                                          self.column_order if ordered else None)
             bands.integrate_batch(spectra, out[w0:w1])
             return
         if shared_radius:

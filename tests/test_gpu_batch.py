@@ -173,10 +173,12 @@ def test_transit_ordered_columns(eng, orc, monkeypatch, nlayers):
     np.testing.assert_allclose(host(got[1]), ws, rtol=RTOL)
 
 
-def test_eval_bands_column_order(eng):
+@pytest.mark.parametrize('rt_path', ['transit', 'emission'])
+def test_eval_bands_column_order(eng, rt_path):
     """TableSpectrum.eval_bands orders the columns by the first walker's optical depth
-    (column_order='auto'): band fluxes bit for bit those of the grid order (column_order=None)
-    and of an order given by the caller; a non-permutation is refused."""
+    (column_order='auto'; transit: rows of the matrix-core kernel, emission: layers of the fused
+    kernel): band fluxes bit for bit those of the grid order (column_order=None) and of an order
+    given by the caller; a non-permutation is refused."""
     import torch
     from pyratbay_amd import synth
     rng = np.random.default_rng(77)
@@ -196,7 +198,8 @@ def test_eval_bands_column_order(eng):
     args = [eng.dev(x) for x in (temps, dens)]
     out = {}
     for name, order in (('grid', None), ('auto', 'auto'), ('given', rng.permutation(W))):
-        model = eng.TableSpectrum(etable, ttable, wn, radius0, 8.8e10, column_order=order)
+        model = eng.TableSpectrum(etable, ttable, wn, radius0, 8.8e10, rt_path=rt_path,
+                                  column_order=order)
         out[name] = model.eval_bands(*args, pb, radius=eng.dev(radius)).clone()
         assert (model.column_order is None) == (name == 'grid')
     assert torch.equal(out['auto'], out['grid']) and torch.equal(out['given'], out['grid'])
