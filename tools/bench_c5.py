@@ -254,16 +254,40 @@ def main(args):
             torch.cuda.synchronize()
             return ev0.elapsed_time(ev1) / reps
 
-        interp_ms = timed(lambda: engine.interp_ec_batch(model.etable, model.ttable, temps, dens))
-        ec = engine.interp_ec_batch(model.etable, model.ttable, temps, dens)
+        # (as eval_bands runs them: the columns in the depth order of the first walker it saw)
+        ordered = model.column_order is not None
+        table = model.etable_ordered if ordered else model.etable
+        interp_ms = timed(lambda: engine.interp_ec_batch(table, model.ttable, temps, dens))
+        ec = engine.interp_ec_batch(table, model.ttable, temps, dens)
+        grid_order_ms = None
         if rt == 'emission':
             intervals = (radius[:, :-1] - radius[:, 1:]).contiguous()
             transit_ms = timed(lambda: engine.emission_flux_batch(
-                ec, intervals, model.wn, temps, model.mu, model.weights, 0, nlayers, 10.0))
+                ec, intervals, model.wn_ordered if ordered else model.wn, temps, model.mu,
+                model.weights, 0, nlayers, 10.0, model.column_order))
+            depth_rows = None
         else:
             path = engine.transit_path_device(radius, 0)
-            transit_ms = timed(lambda: engine.transit_spectrum_batch(
-                ec, path, radius, atm['rstar'], 0, nlayers, 10.0))
+            if ordered:
+                transit_ms = timed(lambda: engine.transit_spectrum_ordered(
+                    ec, path, radius, model.column_order, atm['rstar'], 0, nlayers, 10.0))
+            else:
+                transit_ms = timed(lambda: engine.transit_spectrum_batch(
+                    ec, path, radius, atm['rstar'], 0, nlayers, 10.0))
+            # rows of ec the reference's loop reads: down to each column's first crossing
+            _, _, ideep = engine.transit_spectrum_batch(ec, path, radius, atm['rstar'], 0, nlayers,
+                                                        10.0, want_depth=True)
+            depth_rows = float((ideep.double() + 1).sum().item())
+            del ideep
+        if ordered:
+            ec_grid = engine.interp_ec_batch(model.etable, model.ttable, temps, dens)
+            if rt == 'emission':
+                grid_order_ms = timed(lambda: engine.emission_flux_batch(
+                    ec_grid, intervals, model.wn, temps, model.mu, model.weights, 0, nlayers, 10.0))
+            else:
+                grid_order_ms = timed(lambda: engine.transit_spectrum_batch(
+                    ec_grid, path, radius, atm['rstar'], 0, nlayers, 10.0))
+            del ec_grid
         # compulsory bytes of ONE batched launch.  interp: every table slice (species x layer x
         # temperature node) that some walker of the batch brackets is read once -- walkers in the
         # same bracket share it -- and every walker's ec is written; transit: every walker's ec
@@ -274,10 +298,11 @@ def main(args):
         nodes = sum(len(np.union1d(tlo[:, k], tlo[:, k] + 1)) for k in range(nlayers))
         interp_bytes = 8.0 * NSPEC * nwave * nodes + 8.0 * nlayers * nwave * nloc
         transit_bytes = (8.0 * nlayers * nwave + 8.0 * nwave) * nloc
+        if depth_rows is not None:
+            # (transit: the rows down to every column's first crossing -- what the reference's
+            # optical-depth loop touches, _trapezoid.c:259-273 -- not the whole of ec)
+            transit_bytes = 8.0 * depth_rows + 8.0 * nwave * nloc
         mfma = os.environ.get('PB_TRANSIT_MFMA', '1') != '0'
-        # matrix-core form: per 32 columns 2 x 60 v_mfma_f64_16x16x4_f64 (the blocks of the
-        # 80 x 80 ray-path matrix on or below its diagonal) = 7680 flop per column
-        transit_flops = 2.0 * 60 * 2048 / 32 * nwave * nloc
         nmu = len(model.mu) if rt == 'emission' else 0
         kernels = [
             {'kernel': 'k_emission_fused', 'kernel_ms': transit_ms, 'kernel_bytes': transit_bytes,
@@ -285,11 +310,12 @@ def main(args):
                           'exp(-depth / mu) (plane_parallel_optical_depth + blackbody + intensity '
                           'in one pass, depth and B never stored); ec read once')}
             if rt == 'emission' else
-            {'kernel': 'k_transit_mfma<5,4>' if mfma else 'k_transit_pair<16>',
+            {'kernel': 'k_transit_mfma_rows<5,4,512>' if mfma else 'k_transit_pair<16>',
              'kernel_ms': transit_ms, 'kernel_bytes': transit_bytes,
-             'bound_by': ('FP64 matrix pipe (120 v_mfma_f64_16x16x4_f64 per 32 columns = '
-                          f'{transit_flops / (transit_ms * 1e-3) / 1e12:.1f} TFLOP/s) + 80 exp per '
-                          'column on the vector ALU; ec read once') if mfma else
+             'bound_by': ('FP64 matrix pipe (at most 120 v_mfma_f64_16x16x4_f64 per 32 columns, '
+                          'row tile by row tile until the 32 columns have all crossed maxdepth) + '
+                          'one exp per (column, row above the crossing) on the vector ALU; the '
+                          'layers of ec down to the exit tile read once') if mfma else
                          'FP64 vector ALU (3160 fma + 80 exp per column), not HBM'},
             {'kernel': 'k_interp_ec_batch2<4,true>' if os.environ.get('PB_INTERP_PAIRS', '1') != '0' else 'k_interp_ec_batch<4,true>', 'kernel_ms': interp_ms,
              'kernel_bytes': interp_bytes, 'bound_by': 'HBM (ec written per walker)'}]
@@ -328,7 +354,11 @@ def main(args):
                        'table_bytes': int(model.etable.numel() * 8),
                        'parallelism': 'single GPU' if world == 1 else
                        f'walker replicas x{world} + all-gather of band fluxes',
-                       'init_seconds': round(t_init, 3), 'one_pass': one_pass},
+                       'init_seconds': round(t_init, 3), 'one_pass': one_pass,
+                       'column_order': ('depth order of the first walker (TableSpectrum.'
+                                        'order_columns): spectra do not depend on it'
+                                        if ordered else 'grid order'),
+                       'rt_kernel_ms_grid_order': grid_order_ms},
             'roofline': {'bound': 'hbm', 'kernel': dom['kernel'], 'achieved': dom['achieved'],
                          'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': dom['frac'],
                          'traffic': traffic, 'kernel_ms': dom['kernel_ms'],

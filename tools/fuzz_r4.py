@@ -162,6 +162,48 @@ def partition_case(eng, rng):
     assert np.array_equal(got, want), 'partition table: device != host'
 
 
+def ordered_case(eng, rng):
+    """The retrieval batches with their columns in depth order (pb_transit_spectrum_ordered,
+    pb_emission_flux_ordered through TableSpectrum.eval_bands) against grid order: band fluxes
+    bit for bit; the transit spectra of a random permutation against the oracle."""
+    import torch
+    from oracle import oracle as orc
+    from pyratbay_amd import synth
+    nspec, ntemp = int(rng.integers(1, 6)), int(rng.integers(2, 9))
+    L, W, nw = int(rng.integers(2, 120)), int(rng.integers(64, 3000)), int(rng.integers(1, 9))
+    g = synth.spectral_grid(4000.0, 4000.0 + (W - 1) * 0.05 + 0.01, 0.05, 12)
+    ttable = np.linspace(300.0, 3000.0, ntemp)
+    press = np.logspace(-6, 2, L)
+    etable = 10.0**rng.uniform(-27, -21, (nspec, ntemp, L, 1)) * \
+        10.0**rng.uniform(-3, 3, (nspec, 1, 1, W))
+    radius0 = np.linspace(8.0e9, 7.0e9, L)
+    lo = int(rng.integers(0, W // 2))
+    bands = [(lo, np.ones(W - 1 - lo), 1.0)]
+    pb = eng.PassBands(g['wn'], bands)
+    temps = 1500.0 * (1 + 0.1 * rng.uniform(-1, 1, (nw, 1))) * np.linspace(0.8, 1.2, L)
+    dens = (press / temps)[:, :, None] * 7.2e21 * 10.0**rng.uniform(-7, -3, (nw, 1, nspec))
+    radius = radius0[None] * (1 + 0.01 * rng.uniform(-1, 1, (nw, 1)))
+    args = [eng.dev(x) for x in (temps, dens)]
+    for rt in ('transit', 'emission'):
+        out = []
+        for order in (None, 'auto', rng.permutation(W)):
+            model = eng.TableSpectrum(etable, ttable, g['wn'], radius0, 8.8e10, rt_path=rt,
+                                      column_order=order)
+            out.append(model.eval_bands(*args, pb, radius=eng.dev(radius)).clone())
+        assert torch.equal(out[0], out[1]) and torch.equal(out[0], out[2]), f'{rt}: order changes bits'
+    # one walker's spectrum through the ordered transit kernel against the oracle
+    if L >= 2:
+        ec = eng.interp_ec_batch(eng.dev(etable), eng.dev(ttable), args[0][:1], args[1][:1])
+        rad = eng.dev(radius[:1])
+        order = torch.as_tensor(rng.permutation(W), device='cuda')
+        got = eng.transit_spectrum_ordered(ec[:, :, order].contiguous(),
+                                           eng.transit_path_device(rad, 0), rad,
+                                           order.to(torch.int32), 8.8e10, 0, L, 10.0)
+        wd, wi = orc.optical_depth_transit(ec[0].cpu().numpy(), radius[0], 0, L, 10.0)
+        ws = orc.transmission(wd, radius[0], 8.8e10, wi, 0)
+        np.testing.assert_allclose(got[0].cpu().numpy(), ws, rtol=1e-12)
+
+
 def main():
     count = int(sys.argv[1]) if len(sys.argv) > 1 else 200
     seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 41000
@@ -177,6 +219,8 @@ def main():
             if i % 4 == 3:
                 for _ in range(20):
                     partition_case(eng, rng)
+                for _ in range(3):
+                    ordered_case(eng, rng)
             else:
                 info = ext_case(eng, ref, rng, seed)
                 nwave_layers += info['wave']
