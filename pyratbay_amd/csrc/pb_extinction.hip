@@ -2952,7 +2952,7 @@ static int lbl_extinction(pb_lbl *p, double *ext_d, int64_t wbegin, int64_t wcou
     // share of the phases.  A launch ends when its slowest workgroup does, so small launches
     // and launches of long-running workgroups are split further:
     //  * light tiles (C2: ~8 records per phase row): aim for ~2000 workgroups.  Layer shards
-    //    of C2 (tools/sweep_split.sh): 40 layers 0.70 ms unsplit / 0.65 in two; 20 layers
+    //    of C2 (a sweep of round 2): 40 layers       0.70 ms unsplit / 0.65 in two; 20 layers
     //    0.40 in two / 0.37 in four; 10 layers 0.23 in four or eight; all 80 layers 1.19
     //    unsplit / 1.20 in two.
     //  * heavy tiles (>= 64 groups per phase row and 2048 samples: 1e6 lines on 1e5 samples;

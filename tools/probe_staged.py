@@ -17,7 +17,7 @@ Patches pyratbay_amd/csrc/pb_extinction.hip + pb_ext_args.h IN PLACE (restore th
            records, and the shader clock the kernel ran at (clock64 against wall_clock64)
 Build the object with the flags of csrc/Makefile, link it with the other objects into
 build_ab/libpbhip_p<bits>.so and run `PB_PROBE_LIB=build_ab/libpbhip_p<bits>.so python
-tools/layer_cost.py c2 16`.  Findings of round 2: profiles/r02_gather_ab.md."""
+tools/bench_stages.py c2` (tools/wg_probe_run.py does both for the workgroup time stamps).  Findings of round 2: profiles/r02_gather_ab.md."""
 import os
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
