@@ -14,6 +14,8 @@
 #   <tag>_kernel_stats_{c5,c5em}.csv  rocprofv3 kernel stats of the retrieval batches
 #   <tag>_gather_wave.log             staged kernel alone against staged + wave-autonomous kernel (C2, 1e6 lines)
 #   <tag>_wshard.log, <tag>_rank_rccl.log   per-rank times of the wavenumber decomposition
+#   <tag>_ordered.log                 retrieval batch: transit kernels in grid / depth order, c5 and c5-emission with the ordering off and on
+#   <tag>_tile_times_c2bands.log      per-tile time spread of a band-structured list (tools/tile_times.py)
 #   <tag>_pmc_c2.json                 SQ / cache counters of the C2 kernels (tools/pmc.sh)
 #   <tag>_write_size_probe.csv        WRITE_SIZE of 8- and 16-byte-per-lane stores (tools/write_size_probe.hip)
 #   pmc_traffic.json                  FETCH_SIZE / WRITE_SIZE of the dominant kernels, every workload
@@ -50,6 +52,9 @@ echo "other workloads done"
 { python tools/bench_rank_rccl.py 8 c2 3; python tools/bench_rank_rccl.py 4 c2 3; python tools/bench_rank_rccl.py 2 c2 3; python tools/bench_rank_rccl.py 8 c2-1e6 3; } 2>&1 | grep "rank " > gpurun_out/${tag}_rank_rccl.log
 python tools/bench_dropin.py 2>&1 | grep drop-in > gpurun_out/${tag}_dropin.log
 echo "rank shards done"
+{ python tools/bench_ordered.py; for o in 0 1 0 1; do echo "PB_COLUMN_ORDER=$o:"; PB_COLUMN_ORDER=$o python bench.py --workload c5 --no-cpu-baseline | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(' c5', round(d['value']), 'evals/s', round(d['ms_per_step'], 3), 'ms per 64 walkers')"; done; for o in 0 1; do echo "PB_COLUMN_ORDER=$o:"; PB_COLUMN_ORDER=$o python bench.py --workload c5-emission --steps 40 --no-cpu-baseline | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(' c5-emission', round(d['value']), 'evals/s', round(d['ms_per_step'], 3), 'ms per 64 walkers')"; done; } 2>&1 | grep -v amdgpu.ids > gpurun_out/${tag}_ordered.log
+python tools/tile_times.py c2-bands 5 2>&1 | grep -v amdgpu.ids > gpurun_out/${tag}_tile_times_c2bands.log
+echo "ordered batches and tile times done"
 fi
 if [ "$part" = "b" ]; then
 bash tools/pmc.sh gpurun_out/pmc_${tag} c2 > gpurun_out/pmc_${tag}.log 2>&1
