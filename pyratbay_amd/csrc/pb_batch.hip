@@ -1646,14 +1646,15 @@ int pb_transit_fused_launch(double *depth_d, int32_t *ideep_d, double *spectrum_
                 case 3: PB_MFMA_ROWS(3, 4, 256); break;
                 case 4: PB_MFMA_ROWS(4, 4, 256); break;
                 case 5:
-                    if (tb >= 1024)
+                    // 80 layers: the B operands alone are 80 registers.  Three wavefronts per SIMD
+                    // of up to 168 registers (no spills) beat four of 128 (24 spilled): 1.23
+                    // against 1.31 ms per 64 walkers at C5's shape; PB_MFMA_TB=512|1024: the latter
+                    if (getenv("PB_MFMA_TB") && tb >= 1024)
                         PB_MFMA_ROWS(5, 4, 1024);
-                    else if (tb >= 512)
+                    else if (getenv("PB_MFMA_TB") && tb >= 512)
                         PB_MFMA_ROWS(5, 4, 512);
-                    else if (tb >= 256)
-                        PB_MFMA_ROWS(5, 4, 256);
                     else
-                        PB_MFMA_ROWS(5, 4, 128);
+                        PB_MFMA_ROWS(5, 3, 256);
                     break;
                 case 6: PB_MFMA_ROWS(6, 2, 256); break;
                 case 7: PB_MFMA_ROWS(7, 2, 256); break;

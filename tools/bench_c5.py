@@ -310,7 +310,7 @@ def main(args):
                           'exp(-depth / mu) (plane_parallel_optical_depth + blackbody + intensity '
                           'in one pass, depth and B never stored); ec read once')}
             if rt == 'emission' else
-            {'kernel': 'k_transit_mfma_rows<5,4,512>' if mfma else 'k_transit_pair<16>',
+            {'kernel': 'k_transit_mfma_rows<5,3,256>' if mfma else 'k_transit_pair<16>',
              'kernel_ms': transit_ms, 'kernel_bytes': transit_bytes,
              'bound_by': ('FP64 matrix pipe (at most 120 v_mfma_f64_16x16x4_f64 per 32 columns, '
                           'row tile by row tile until the 32 columns have all crossed maxdepth) + '
