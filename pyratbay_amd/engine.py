@@ -1353,7 +1353,10 @@ class TableSpectrum:
                 not (transit and self._one_pass()):
             # (a walker outside the table's range would order by garbage: wait for a valid one)
             t0 = temps[0]
-            if bool(((t0 >= self.tmin) & (t0 <= self.tmax)).all()):
+            table_bytes = self.etable.numel() * 8
+            if torch.cuda.mem_get_info()[0] < 1.25 * table_bytes:
+                self._auto_order = False      # no room for the second copy of the table: grid order
+            elif bool(((t0 >= self.tmin) & (t0 <= self.tmax)).all()):
                 self.order_columns(t0, dens[0], radius[0])
         path1 = (transit_path_device(radius[0], self.itop).view(1, -1)
                  if shared_radius and transit else None)
