@@ -33,8 +33,10 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 # HIP maps streams onto this many hardware queues (default 4); the pipelines, the default stream
-# and RCCL's own streams are more than four at N > 1, and two streams on one queue do not overlap
-os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
+# and RCCL's own streams are more than four at N > 1, and two streams on one queue do not overlap.
+# 16: two `resolution`-mode plans in flight have 2 x (1 + 4) streams of their own -- c2-res 275 ->
+# 291 spectra/s against 8 queues, C2 unchanged (1123-1128 with 8, 16 or 24)
+os.environ.setdefault('GPU_MAX_HW_QUEUES', '16')
 
 C4_SPECIES = ('H2', 'He', 'H2O', 'CO', 'CO2', 'CH4')
 C4_VMR = (0.85, 0.149, 4e-4, 5e-4, 1e-7, 1e-4)
