@@ -827,6 +827,15 @@ def main():
                        'init_seconds': round(t_init, 3)},
             'roofline': roof,
         }
+        if w.get('resolution'):
+            # (the `resolution` path reads the layers' factors back once per call unless the run
+            # plans are predicted: DESIGN.md section 6b)
+            st = model.lbl.dyn_stats()
+            out['config']['run_plans'] = (
+                'predicted from the last read-back (PB_RES_DYN_PREDICT=1): '
+                f'{st[0]} predicted / {st[1]} synchronous calls of this plan'
+                if os.environ.get('PB_RES_DYN_PREDICT') == '1' else
+                'one stream synchronisation per call (default)')
         if latency_ms is not None:
             out['config']['unpipelined_ms_per_spectrum'] = latency_ms
         if primary.get('priming_spectra'):

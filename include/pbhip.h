@@ -207,6 +207,19 @@ int pb_lbl_last_layer_kinds(pb_lbl *p, int32_t *resident_h, int32_t *block_h, in
  * layers whose longest phase row is at most 384 samples; all 0 when that kernel was off).
  * Synchronises the stream. */
 int pb_lbl_last_wave_layers(pb_lbl *p, int32_t *wave_h, int nlayers, void *stream);
+/* `resolution` plans in gather mode 6 (per-layer dynamic grids, _extcoeff.c:185-195, 320-326): the
+ * run plan of a call -- which layers share an oversampling factor, which Lorentz rows of the re-cut
+ * tables they read -- needs the layers' factors on the host: one stream synchronisation per call.
+ * pb_lbl_set_dyn_predict(plan, 1) removes it: from the second call on the plan is taken from the
+ * last read-back (asynchronous), a device check marks the layers it fits and the direct gather
+ * computes the others, so the result is right whatever the prediction (to the direct gather's
+ * 1e-12 of the dynamic grids; bit for bit while the prediction fits, i.e. always for a steady
+ * atmosphere), and such calls can be captured into a HIP graph.  A read-back that contradicts its
+ * prediction makes the next 8 calls synchronous.  Default off (PB_RES_DYN_PREDICT=1: on).
+ * stats = {calls planned from a prediction, synchronous calls, read-backs that contradicted their
+ * prediction}. */
+int pb_lbl_set_dyn_predict(pb_lbl *p, int on);
+int pb_lbl_dyn_stats(pb_lbl *p, int64_t stats[3]);
 /* The same call in two halves, for wavenumber shards on several GPUs.  _begin derives the layer
  * state and the records of the groups within reach of the shard, with the per-row maxima
  * (_extcoeff.c:203-226) over THOSE groups only -- 1/N of the exp() work; the caller then

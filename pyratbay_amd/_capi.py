@@ -64,6 +64,8 @@ _PROTOS = {
     'pb_lbl_last_state': [vp, vp, vp, i32, i32, vp],
     'pb_lbl_last_layer_kinds': [vp, vp, vp, i32, vp],
     'pb_lbl_last_wave_layers': [vp, vp, i32, vp],
+    'pb_lbl_dyn_stats': [vp, vp],
+    'pb_lbl_set_dyn_predict': [vp, i32],
     'pb_lbl_last_work': [vp, C.POINTER(i64 * 3), vp],
     'pb_lbl_last_table_samples': [vp, C.POINTER(i64), vp],
     'pb_lbl_timing_begin': [vp, i32],

@@ -133,6 +133,9 @@ struct LblArgs {
     // lists of uneven density (band heads): the tiles under a head hold 10-100 x the records of
     // the others and would end the launch alone.
     const int32_t *tsplit;
+    // layers a launch leaves alone (lskip[layer] != 0): the direct gather of a host-free
+    // `resolution` call computes only the layers its predicted run plan did not fit
+    const int32_t *lskip;
     // tsplit[t] == 0: the tile is too sparse for the staged kernel (a few records per phase row:
     // its time is its ~300 barrier steps whatever they hold) and is computed by the global gather,
     // launched beside it over the tiles so marked; ts_tile = samples per tile of that table;

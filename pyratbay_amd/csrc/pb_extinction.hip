@@ -167,6 +167,13 @@ __global__ __launch_bounds__(64) void k_layer_state(LblArgs a)
     }
 }
 
+// a wave-uniform int written by an earlier kernel, by a scalar load
+__device__ __forceinline__ int uniform_load_i32(const int32_t *p, int64_t i)
+{
+    typedef const int32_t __attribute__((address_space(4))) *cptr;
+    return ((cptr)(unsigned long long)p)[i];
+}
+
 // ---------------------------------------------------------------------------
 // 2. per layer / output row maximum line strength over all in-range lines
 // ---------------------------------------------------------------------------
@@ -174,6 +181,8 @@ __global__ __launch_bounds__(kBlock) void k_kmax(LblArgs a, int lines_per_block)
 {
     extern __shared__ unsigned long long s_max[];
     const int layer = blockIdx.y;
+    if (a.lskip && uniform_load_i32(a.lskip, layer))
+        return;
     for (int r = threadIdx.x; r < a.nrows; r += kBlock)
         s_max[r] = 0ull;
     __syncthreads();
@@ -1934,6 +1943,8 @@ __global__ __launch_bounds__(kBlock) void k_ext_linterp(LblArgs a)
     decode_block(a, tile, layer);
     if (layer < 0)
         return;
+    if (a.lskip && uniform_load_i32(a.lskip, layer))
+        return;
     const int row = blockIdx.y;
 
     const int64_t t0 = a.wbegin + (int64_t)tile * kBlock;
@@ -2059,12 +2070,15 @@ __global__ __launch_bounds__(kBlock) void k_dyn_interp(double *ext, const double
                                                       const double *wn, double wn0,
                                                       const double *dwnstep, int64_t d0,
                                                       int64_t dcount, int64_t wbegin,
-                                                      int64_t wcount, int nrows)
+                                                      int64_t wcount, int nrows,
+                                                      const int32_t *ok)
 {
     const int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (j >= wcount)
         return;
     const int lr = blockIdx.y;
+    if (!uniform_load_i32(ok, lr / nrows))               // (a layer the run plan did not fit)
+        return;
     const double step = dwnstep[lr / nrows];
     const double wn_i = wn[wbegin + j];
     const int64_t ilo = (int)((wn_i - wn0) / step);
@@ -2073,6 +2087,33 @@ __global__ __launch_bounds__(kBlock) void k_dyn_interp(double *ext, const double
     const double v1 = ilo + 1 >= d0 && ilo + 1 < d0 + dcount ? src[ilo + 1] : 0.0;
     const double wnlo = wn0 + step * ilo;
     ext[(int64_t)lr * wcount + j] += (v0 * (wnlo + step - wn_i) + v1 * (wn_i - wnlo)) / step;
+}
+
+// Which layers does the run plan of a host-free `resolution` call fit?  The plan was made from
+// the factors and Lorentz rows the layers had when they were last read back; a layer is computed
+// by its run iff its factor is the predicted one and every Lorentz row its isotopes select is
+// filled in the re-cut table of that factor (unfilled rows read as zeros: wrong, never a fault).
+__global__ void k_dyn_check(int32_t *ok, const int32_t *ofactor, const int32_t *ilor,
+                            const int32_t *pred_f, const uint8_t *const *pred_mask, int nlayers,
+                            int niso)
+{
+    const int layer = blockIdx.x * blockDim.x + threadIdx.x;
+    if (layer >= nlayers)
+        return;
+    bool good = ofactor[layer] == pred_f[layer];
+    const uint8_t *mask = pred_mask[layer];
+    for (int i = 0; i < niso; i++)
+        good = good && mask[ilor[(int64_t)layer * niso + i]] != 0;
+    ok[layer] = good ? 1 : 0;
+}
+
+// the per-row maxima of a run's layers -> the plan's (only the layers the run computed)
+__global__ void k_dyn_kmax(unsigned long long *dst, const unsigned long long *src,
+                           const int32_t *ok, int nl, int nrows)
+{
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < nl * nrows && ok[e / nrows])
+        dst[e] = src[e];
 }
 
 // ---------------------------------------------------------------------------
@@ -2252,6 +2293,25 @@ struct pb_lbl {
         int lane;
     };
     std::vector<DynSub> dyn;
+    // Host-free calls (opt-in, pb_lbl_set_dyn_predict): the run plan comes from the factors /
+    // Lorentz rows the layers had when they were last read back (pred_*), a device check marks the
+    // layers it fits (d_ok), the direct gather computes the others; this call's state is read back
+    // asynchronously (rb_*) and adopted by a later call.  A read-back that contradicts the
+    // prediction makes the next dyn_hold calls synchronous (one stream synchronisation each, the
+    // default form): atmospheres that change from call to call are not worth predicting.  Opt-in
+    // because a layer that takes the direct gather differs from the same layer on its dynamic grid
+    // in the last bits (the same terms in another order): with the prediction on, a result can
+    // depend on the plan's history at the 1e-13 level; with a steady atmosphere it never does.
+    std::vector<int32_t> pred_f, pred_ilor, used_f;
+    int pred_layers = 0, pred_cap = 0, dyn_hold = 0;
+    bool pred_dirty = false, rb_pending = false, dyn_fallback = false;
+    int dyn_predict = 0;             // pb_lbl_set_dyn_predict
+    int32_t *d_pred_f = nullptr, *d_ok = nullptr, *rb_host = nullptr;
+    const uint8_t **d_pred_mask = nullptr;
+    size_t rb_cap = 0;
+    int rb_layers = 0;
+    hipEvent_t rb_ev = nullptr;
+    int64_t dyn_spec_calls = 0, dyn_sync_calls = 0, dyn_mispredicted = 0;
     uint64_t dyn_call = 0;
     int dyn_runs = 0;                // runs of equal-factor layers of the last call
     // the runs of a call are independent until ext: dealt to side streams (deep layers have
@@ -2506,6 +2566,8 @@ int pb_lbl_create(pb_lbl **out, pb_voigt *voigt, pb_lines *lines, const double *
     p->ndivs = ndivs;
     p->max_layers = max_layers;
     p->resolution = resolution ? 1 : 0;
+    if (const char *e = getenv("PB_RES_DYN_PREDICT"))
+        p->dyn_predict = resolution && atoi(e) == 1 ? 1 : 0;
     p->cutoff = cutoff;
     p->ethresh = ethresh;
     p->wnstep = wnstep;
@@ -3188,6 +3250,7 @@ static int lbl_extinction(pb_lbl *p, double *ext_d, int64_t wbegin, int64_t wcou
     }
     a.use_records = use_records ? 1 : 0;
 
+    bool dyn_fall = false;
     // (a fine grid shorter than two steps of the coarsest dynamic grid has no constant-step form)
     if (p->resolution && p->gather_mode == 6 && phase == 0 && l->ngroups > 0 &&
         l->onwn > 2 * (int64_t)v->osamp &&
@@ -3196,10 +3259,16 @@ static int lbl_extinction(pb_lbl *p, double *ext_d, int64_t wbegin, int64_t wcou
                                           z_iso_stride, z_layer_stride, nlayers, add, s);
         // a re-cut table row that cannot be addressed (pb_voigt_ensure_rows) before any run has
         // added to ext: the direct gather below computes the call instead
-        if (!(rc == PB_ERR_UNSUPPORTED && p->dyn_runs == 0))
-            return rc;
+        if (!(rc == PB_ERR_UNSUPPORTED && p->dyn_runs == 0)) {
+            if (rc != PB_OK || !p->dyn_fallback)
+                return rc;
+            // a call planned from a prediction: the layers the plan did not fit (none, as a
+            // rule: the launches below then end at once) go through the direct gather
+            dyn_fall = true;
+            a.lskip = p->d_ok;
+        }
     }
-    if (phase != 2) {
+    if (phase != 2 && !dyn_fall) {
     k_layer_state<<<nlayers, 64, ((size_t)a.nlor + a.ndop) * 8 + (size_t)a.ndivs * 4, s>>>(a);
     PB_LAUNCH_CHECK();
     }
@@ -3364,10 +3433,10 @@ static int lbl_extinction(pb_lbl *p, double *ext_d, int64_t wbegin, int64_t wcou
     if (phase == 1)
         return PB_OK;
     const int layer_groups = (nlayers + 7) / 8;
-    const bool timed = p->ev_used + 2 <= (int)p->ev.size();
+    const bool timed = !dyn_fall && p->ev_used + 2 <= (int)p->ev.size();
     if (timed)
         PB_HIP(hipEventRecord(p->ev[p->ev_used], s));
-    p->last_gather = scatter ? 4
+    p->last_gather = dyn_fall ? 6 : scatter ? 4
                              : (p->resolution ? 3 : rounds ? 5 : staged ? 2 : 1) +
                                    (resident ? 8 : 0) + (a.wave_cap > 0 ? 16 : 0);
     if (scatter) {
@@ -3836,13 +3905,138 @@ static int lbl_resolution_dyn(pb_lbl *p, LblArgs &a, double *ext_d, int64_t wbeg
                (long long)l->onwn);
     k_layer_state<<<nlayers, 64, ((size_t)a.nlor + a.ndop) * 8 + (size_t)a.ndivs * 4, s>>>(a);
     PB_LAUNCH_CHECK();
+    const size_t nstate = (size_t)nlayers * (1 + p->niso);
+    // a finished read-back of an earlier call: adopt it as the prediction; if it contradicts the
+    // prediction that call was planned with, the atmosphere is moving -- synchronise for a while
+    hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &capturing) != hipSuccess)
+        (void)hipGetLastError();
+    if (capturing != hipStreamCaptureStatusNone) {
+        // (no event query while a graph is being captured)
+    } else if (p->rb_pending && hipEventQuery(p->rb_ev) == hipSuccess) {
+        p->rb_pending = false;
+        if (p->rb_layers == nlayers && p->pred_layers == nlayers) {
+            const int32_t *f = p->rb_host, *il = p->rb_host + nlayers;
+            const bool same_f = std::equal(f, f + nlayers, p->used_f.begin());
+            if (!same_f || !std::equal(il, il + (size_t)nlayers * p->niso, p->pred_ilor.begin())) {
+                p->pred_f.assign(f, f + nlayers);
+                p->pred_ilor.assign(il, il + (size_t)nlayers * p->niso);
+                p->pred_dirty = true;
+            }
+            if (!same_f) {
+                p->dyn_mispredicted++;
+                p->dyn_hold = 8;
+            }
+        }
+    } else if (p->rb_pending) {
+        (void)hipGetLastError();                          // (hipErrorNotReady is not an error)
+    }
+    // (a captured call cannot synchronise: it is planned from the prediction or not at all)
+    const bool spec = p->dyn_predict && p->pred_layers == nlayers &&
+                      (capturing != hipStreamCaptureStatusNone || p->dyn_hold == 0);
+    PB_REQUIRE(spec || capturing == hipStreamCaptureStatusNone,
+               "pb_lbl_extinction: a `resolution` plan in gather mode 6 can be captured into a "
+               "graph only with pb_lbl_set_dyn_predict(plan, 1) and after one spectrum of this "
+               "many layers");
     p->h_ofactor.resize((size_t)nlayers);
     p->h_ilor.resize((size_t)nlayers * p->niso);
-    PB_HIP(hipMemcpyAsync(p->h_ofactor.data(), p->ls_ofactor, (size_t)nlayers * 4,
-                          hipMemcpyDeviceToHost, s));
-    PB_HIP(hipMemcpyAsync(p->h_ilor.data(), p->li_ilor, (size_t)nlayers * p->niso * 4,
-                          hipMemcpyDeviceToHost, s));
-    PB_HIP(hipStreamSynchronize(s));      // (also: every run of the previous call has ended)
+    if (!spec) {
+        PB_HIP(hipMemcpyAsync(p->h_ofactor.data(), p->ls_ofactor, (size_t)nlayers * 4,
+                              hipMemcpyDeviceToHost, s));
+        PB_HIP(hipMemcpyAsync(p->h_ilor.data(), p->li_ilor, (size_t)nlayers * p->niso * 4,
+                              hipMemcpyDeviceToHost, s));
+        PB_HIP(hipStreamSynchronize(s));
+        if (p->pred_layers != nlayers || p->pred_f != p->h_ofactor || p->pred_ilor != p->h_ilor) {
+            p->pred_f = p->h_ofactor;
+            p->pred_ilor = p->h_ilor;
+            p->pred_layers = nlayers;
+            p->pred_dirty = true;
+        }
+        if (p->dyn_hold > 0)
+            p->dyn_hold--;
+        p->dyn_sync_calls++;
+    } else {
+        p->h_ofactor = p->pred_f;
+        p->h_ilor = p->pred_ilor;
+        p->dyn_spec_calls++;
+        if (!p->rb_pending && capturing == hipStreamCaptureStatusNone) {
+            if (nstate > p->rb_cap) {
+                if (p->rb_host)
+                    (void)hipHostFree(p->rb_host);
+                p->rb_host = nullptr;
+                p->rb_cap = 0;
+                PB_HIP(hipHostMalloc((void **)&p->rb_host, nstate * 4, hipHostMallocDefault));
+                p->rb_cap = nstate;
+            }
+            if (!p->rb_ev)
+                PB_HIP(hipEventCreateWithFlags(&p->rb_ev, hipEventDisableTiming));
+            PB_HIP(hipMemcpyAsync(p->rb_host, p->ls_ofactor, (size_t)nlayers * 4,
+                                  hipMemcpyDeviceToHost, s));
+            PB_HIP(hipMemcpyAsync(p->rb_host + nlayers, p->li_ilor, (size_t)nlayers * p->niso * 4,
+                                  hipMemcpyDeviceToHost, s));
+            PB_HIP(hipEventRecord(p->rb_ev, s));
+            p->rb_pending = true;
+            p->rb_layers = nlayers;
+        }
+    }
+    p->used_f = p->h_ofactor;                             // (what this call is planned with)
+    p->dyn_fallback = spec;
+    // every sub-plan and Lorentz row of the plan exists before the device check runs; then the
+    // prediction (factor and row mask of the factor's table, per layer) goes to the device
+    for (int l0 = 0; l0 < nlayers;) {
+        const int f = p->h_ofactor[(size_t)l0];
+        int l1 = l0 + 1;
+        while (l1 < nlayers && p->h_ofactor[(size_t)l1] == f)
+            l1++;
+        pb_lbl::DynSub *sub = nullptr;
+        int rc = dyn_subplan(p, f, s, &sub);
+        if (rc)
+            return rc;
+        std::vector<int> rows(p->h_ilor.begin() + (size_t)l0 * p->niso,
+                              p->h_ilor.begin() + (size_t)l1 * p->niso);
+        std::sort(rows.begin(), rows.end());
+        rows.erase(std::unique(rows.begin(), rows.end()), rows.end());
+        rc = pb_voigt_ensure_rows(sub->voigt, rows.data(), (int)rows.size(), s);
+        if (rc)
+            return rc;
+        l0 = l1;
+    }
+    if (nlayers > p->pred_cap) {
+        PB_HIP(hipStreamSynchronize(s));
+        (void)hipFree(p->d_pred_f);
+        (void)hipFree(p->d_ok);
+        (void)hipFree((void *)p->d_pred_mask);
+        p->d_pred_f = p->d_ok = nullptr;
+        p->d_pred_mask = nullptr;
+        p->pred_cap = 0;
+        PB_HIP(hipMalloc(&p->d_pred_f, (size_t)nlayers * 4));
+        PB_HIP(hipMalloc(&p->d_ok, (size_t)nlayers * 4));
+        PB_HIP(hipMalloc((void **)&p->d_pred_mask, (size_t)nlayers * sizeof(void *)));
+        p->pred_cap = nlayers;
+        p->pred_dirty = true;
+    }
+    if (p->pred_dirty) {
+        PB_REQUIRE(capturing == hipStreamCaptureStatusNone,
+                   "pb_lbl_extinction: the run plan of a `resolution` call changed while a graph "
+                   "was being captured");
+        std::vector<const uint8_t *> masks((size_t)nlayers);
+        for (int layer = 0; layer < nlayers; layer++) {
+            pb_lbl::DynSub *sub = nullptr;
+            const int rc = dyn_subplan(p, p->h_ofactor[(size_t)layer], s, &sub);
+            if (rc)
+                return rc;
+            masks[(size_t)layer] = sub->voigt->d_rowmask;
+        }
+        PB_HIP(hipMemcpyAsync(p->d_pred_f, p->h_ofactor.data(), (size_t)nlayers * 4,
+                              hipMemcpyHostToDevice, s));
+        PB_HIP(hipMemcpyAsync((void *)p->d_pred_mask, masks.data(), (size_t)nlayers * sizeof(void *),
+                              hipMemcpyHostToDevice, s));
+        PB_HIP(hipStreamSynchronize(s));                  // (`masks` is a local; rare)
+        p->pred_dirty = false;
+    }
+    k_dyn_check<<<pb::div_up(nlayers, 64), 64, 0, s>>>(p->d_ok, p->ls_ofactor, p->li_ilor,
+                                                      p->d_pred_f, p->d_pred_mask, nlayers, p->niso);
+    PB_LAUNCH_CHECK();
     int lanes = 4;
     if (const char *e = getenv("PB_RES_DYN_STREAMS"))
         lanes = std::max(1, std::min(8, atoi(e)));
@@ -3958,8 +4152,9 @@ static int lbl_resolution_dyn(pb_lbl *p, LblArgs &a, double *ext_d, int64_t wbeg
         if (rc)
             break;
         // (pb_lbl_last_state / pb_lbl_kmax_buffer of this plan report the run's maxima)
-        if (hipMemcpyAsync(p->kmax_bits + (size_t)l0 * a.nrows, q->kmax_bits,
-                           (size_t)nl * a.nrows * 8, hipMemcpyDeviceToDevice, t) != hipSuccess) {
+        k_dyn_kmax<<<pb::div_up(nl * a.nrows, 64), 64, 0, t>>>(
+            p->kmax_bits + (size_t)l0 * a.nrows, q->kmax_bits, p->d_ok + l0, nl, a.nrows);
+        if (hipGetLastError() != hipSuccess) {
             pb::set_error("pb_lbl_extinction: copy of the per-row maxima failed");
             rc = PB_ERR_HIP;
             break;
@@ -3967,7 +4162,7 @@ static int lbl_resolution_dyn(pb_lbl *p, LblArgs &a, double *ext_d, int64_t wbeg
         dim3 grid((unsigned)pb::div_up(wcount, (int64_t)kBlock), (unsigned)(nl * a.nrows));
         k_dyn_interp<<<grid, kBlock, 0, t>>>(ext_d + (int64_t)l0 * a.nrows * wcount, sub->ktmp,
                                             p->d_wn, p->wn0, p->ls_dwnstep + l0, d0, d1 - d0,
-                                            wbegin, wcount, a.nrows);
+                                            wbegin, wcount, a.nrows, p->d_ok + l0);
         if (hipGetLastError() != hipSuccess) {
             pb::set_error("pb_lbl_extinction: k_dyn_interp launch failed");
             rc = PB_ERR_HIP;
@@ -4115,6 +4310,23 @@ int pb_lbl_last_wave_layers(pb_lbl *p, int32_t *wave_h, int nlayers, void *strea
     return PB_OK;
 }
 
+int pb_lbl_set_dyn_predict(pb_lbl *p, int on)
+{
+    PB_REQUIRE(p, "pb_lbl_set_dyn_predict: null handle");
+    PB_REQUIRE(p->resolution, "pb_lbl_set_dyn_predict: the plan is not a `resolution` plan");
+    p->dyn_predict = on ? 1 : 0;
+    return PB_OK;
+}
+
+int pb_lbl_dyn_stats(pb_lbl *p, int64_t stats[3])
+{
+    PB_REQUIRE(p && stats, "pb_lbl_dyn_stats: null pointer");
+    stats[0] = p->dyn_spec_calls;
+    stats[1] = p->dyn_sync_calls;
+    stats[2] = p->dyn_mispredicted;
+    return PB_OK;
+}
+
 int pb_lbl_last_work(pb_lbl *p, int64_t work[3], void *stream)
 {
     PB_REQUIRE(p && work, "pb_lbl_last_work: null pointer");
@@ -4241,6 +4453,13 @@ void pb_lbl_destroy(pb_lbl *p)
         (void)hipEventDestroy(e);
     if (p->dyn_fork)
         (void)hipEventDestroy(p->dyn_fork);
+    if (p->rb_ev)
+        (void)hipEventDestroy(p->rb_ev);
+    (void)hipFree(p->d_pred_f);
+    (void)hipFree(p->d_ok);
+    (void)hipFree((void *)p->d_pred_mask);
+    if (p->rb_host)
+        (void)hipHostFree(p->rb_host);
     delete p;
 }
 

@@ -37,6 +37,13 @@ struct pb_voigt {
     std::vector<int64_t> row_pos;
     std::vector<double *> row_data;
     int64_t lazy_bytes = 0;
+    // Rows not filled yet read as ZEROS: the device offsets of their cells point into one block
+    // of zeros as long as the longest row (+ pads), so a launch that was planned from a
+    // prediction of the rows its layers need (the host-free `resolution` path) can never read
+    // outside an allocation -- a wrong prediction costs a recomputed layer, not a fault.
+    // d_rowmask[m] = 1 once Lorentz row m is filled (the device-side validity check reads it).
+    double *zero_block = nullptr;
+    uint8_t *d_rowmask = nullptr;
 };
 
 int pb_voigt_ensure_flat(pb_voigt *v, hipStream_t stream);

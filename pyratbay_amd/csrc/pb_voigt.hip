@@ -420,6 +420,44 @@ int pb_voigt_rephase(pb_voigt **out, pb_voigt *src, int osamp, hipStream_t s)
     for (int m = 0; m < v->nlor; m++)
         v->row_pos[(size_t)m] = v->pm_base[(size_t)m * v->ndop];
     v->row_data.assign((size_t)v->nlor, nullptr);
+    // the block of zeros that every row not yet filled reads (see pb_internal.h), the anchor of
+    // the table's offsets (as in pb_voigt_ensure_rows) and the cells' offsets into the block;
+    // the host mirror pm_base keeps the layout positions of unfilled rows (ensure_rows needs them)
+    {
+        int64_t longest = 0;
+        for (int m = 0; m < v->nlor; m++)
+            longest = std::max(longest, v->row_pos[(size_t)m + 1] - v->row_pos[(size_t)m]);
+        const size_t count = (size_t)longest + 2 * kPmPad;
+        auto fail = [&](int code, const char *what) {
+            pb::set_error("pb_voigt_rephase: %s", what);
+            pb_voigt_destroy(v);
+            return code;
+        };
+        if (hipMalloc(&v->zero_block, count * sizeof(double)) != hipSuccess)
+            return fail(PB_ERR_NOMEM, "cannot allocate the block of zeros of unfilled rows");
+        if (hipMalloc(&v->d_rowmask, (size_t)std::max(v->nlor, 1)) != hipSuccess)
+            return fail(PB_ERR_NOMEM, "cannot allocate the row mask");
+        if (hipMemsetAsync(v->zero_block, 0, count * sizeof(double), s) != hipSuccess ||
+            hipMemsetAsync(v->d_rowmask, 0, (size_t)std::max(v->nlor, 1), s) != hipSuccess)
+            return fail(PB_ERR_HIP, "zeroing failed");
+        double *zdata = v->zero_block + kPmPad;
+        const uintptr_t span = ((uintptr_t)1 << 39) * sizeof(double);
+        const uintptr_t at = reinterpret_cast<uintptr_t>(zdata);
+        v->d_pm = reinterpret_cast<double *>(at > span ? at - span : (uintptr_t)0);
+        const int64_t zoff = (int64_t)((at - reinterpret_cast<uintptr_t>(v->d_pm)) / sizeof(double));
+        if (zoff - kPmPad < 0 || zoff + longest + kPmPad >= ((int64_t)1 << 40))
+            return fail(PB_ERR_UNSUPPORTED, "the block of zeros cannot be addressed with 40-bit offsets");
+        std::vector<int64_t> based(v->pm_base.size());
+        for (int m = 0; m < v->nlor; m++)
+            for (int d = 0; d < v->ndop; d++) {
+                const size_t k = (size_t)m * v->ndop + d;
+                based[k] = zoff + (v->pm_base[k] - v->row_pos[(size_t)m]);
+            }
+        if (hipMemcpyAsync(v->d_pm_base, based.data(), based.size() * 8, hipMemcpyHostToDevice,
+                           s) != hipSuccess ||
+            hipStreamSynchronize(s) != hipSuccess)           // (`based` is a local)
+            return fail(PB_ERR_HIP, "uploading the cell offsets failed");
+    }
     src->rephased.push_back(v);
     *out = v;
     return PB_OK;
@@ -505,6 +543,8 @@ int pb_voigt_ensure_rows(pb_voigt *v, const int *rows, int n, hipStream_t s)
         if (hipMemcpyAsync(v->d_pm_base + k0, based.data(), (size_t)v->ndop * 8,
                            hipMemcpyHostToDevice, s) != hipSuccess)
             return fail("uploading the cell offsets");
+        if (v->d_rowmask && hipMemsetAsync(v->d_rowmask + m, 1, 1, s) != hipSuccess)
+            return fail("marking the row");
         if (hipStreamSynchronize(s) != hipSuccess)   // `based` is a local
             return fail("the stream");
         for (int d = 0; d < v->ndop; d++)
@@ -675,6 +715,8 @@ void pb_voigt_destroy(pb_voigt *v)
         pb_voigt_destroy(r);
     for (double *block : v->row_data)
         (void)hipFree(block);
+    (void)hipFree(v->zero_block);
+    (void)hipFree(v->d_rowmask);
     (void)hipFree(v->d_pm_alloc);
     (void)hipFree(v->d_flat);
     (void)hipFree(v->d_cells);

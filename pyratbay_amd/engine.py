@@ -453,6 +453,20 @@ class LBL:
         call('pb_lbl_last_wave_layers', self._h, hptr(wave), nlayers, _stream())
         return wave
 
+    def set_dyn_predict(self, on=True):
+        """`resolution` plans, gather mode 'dynamic': plan every call from the last read-back of
+        the layers' oversampling factors instead of synchronising the stream (pbhip.h:
+        pb_lbl_set_dyn_predict); needed to capture such a call into a HIP graph."""
+        call('pb_lbl_set_dyn_predict', self._h, int(bool(on)))
+
+    def dyn_stats(self):
+        """`resolution` plans, gather mode 'dynamic': (calls planned from the last read-back of the
+        layers' factors -- no stream synchronisation --, synchronous calls, read-backs that
+        contradicted the prediction their call was planned with)."""
+        st = np.zeros(3, np.int64)
+        call('pb_lbl_dyn_stats', self._h, hptr(st))
+        return tuple(int(v) for v in st)
+
     def close(self):
         if self._h:
             call('pb_lbl_destroy', self._h)
@@ -823,7 +837,8 @@ class LBLSpectrum:
     def __init__(self, case, rt_path='transit', wbegin=0, wcount=None, itop=0,
                  quadrature_mu=None, quadrature_weights=None, keep_flat=False,
                  voigt=None, lines=None, tint=0.0, flux_top=None, continuum=None,
-                 continuum_density=None, timestamps=True, materialize_depth=True):
+                 continuum_density=None, timestamps=True, materialize_depth=True,
+                 predict_runs=False):
         require_gpu()
         # per-stage HIP-event timers behind the `timestamps` property (the reference's
         # pyrat.timestamps keys); timestamps=False: run() records no events
@@ -865,6 +880,12 @@ class LBLSpectrum:
             # an object made for many spectra: the one-time constant-step sub-plans of the layers'
             # dynamic grids pay off from the second spectrum on (a bare LBL plan keeps the direct gather)
             self.lbl.set_gather_mode('dynamic')
+            # predict_runs: plan every call from the last read-back of the layers' oversampling
+            # factors instead of synchronising the stream in every call (LBL.set_dyn_predict;
+            # results to 1e-12 of the default, bit for bit for a steady atmosphere; capturable)
+            if predict_runs:
+                self.lbl.set_dyn_predict(True)
+        self.predict_runs = bool(predict_runs) and self.resolution
         # atmosphere state, resident (+ the host copy of the temperatures that the continuum
         # terms take their per-layer factors from)
         self.temp_host = np.array(atm['temp'], float)
@@ -1054,12 +1075,16 @@ class LBLSpectrum:
         depth, spectrum -- is then ONE graph launch, with inputs read from and outputs
         written to the same device buffers (update the atmosphere with set_atmosphere()).
         The first call allocates workspaces, so it runs once eagerly before the capture.
-        Not for the `resolution` mode's dynamic-grid path: the set of launches there depends on the
-        atmosphere (the layers' oversampling factors are read back every call)."""
-        if self.resolution and self.lbl.gather_mode == 'dynamic':
+        The `resolution` mode's dynamic-grid path needs predict_runs=True: its launches depend on
+        the layers' oversampling factors, which the default form reads back in every call; the
+        captured plan is the one of the atmosphere at capture time, and layers of a later
+        atmosphere that it does not fit are computed by the direct gather inside the graph."""
+        if self.resolution and self.lbl.gather_mode == 'dynamic' and not self.predict_runs:
             raise RuntimeError("capture(): the dynamic-grid path of the `resolution` mode reads "
                                "the layers' factors back on every call and cannot be captured; "
-                               "lbl.set_gather_mode('auto') selects the direct gather")
+                               "LBLSpectrum(..., predict_runs=True) plans its calls from the last "
+                               "read-back instead, lbl.set_gather_mode('auto') selects the direct "
+                               "gather")
         self.run()
         torch.cuda.synchronize()
         graph = torch.cuda.CUDAGraph()

@@ -482,6 +482,69 @@ def test_shard_pipeline_single_process(eng, case):
         hinted.lbl.set_concurrency(0)
 
 
+def test_resolution_mode_predicted_runs(eng, monkeypatch):
+    """`resolution` mode with the run plan taken from the last read-back of the layers' factors
+    (LBLSpectrum(predict_runs=True), pb_lbl_set_dyn_predict) instead of a stream synchronisation
+    in every call.  A steady atmosphere: every spectrum bit for bit the default form's, the calls
+    after the first planned from the prediction, none contradicted.  An atmosphere whose factors
+    differ: the layers the plan does not fit go through the direct gather in the same call --
+    right at once (1e-12 of a fresh default model, same zero pattern), the contradiction is
+    noticed and the next calls synchronise, after which the prediction is used again.  Such a
+    model can be captured into a graph, and the graph stays right when the atmosphere changes."""
+    import torch
+    from pyratbay_amd import synth
+    monkeypatch.delenv('PB_RES_DYN_PREDICT', raising=False)
+    case = synth.lbl_case(2001, 8, 5000, wnosamp=24, nlor=14, ndop=7, extent=60.0, cutoff=3.0,
+                          niso=2, seed=19, resolution=60000.0)
+    atm, iso = case['atm'], case['iso']
+    ref = eng.LBLSpectrum(case, rt_path='transit')
+    want = ref.run().clone()
+    want_ec = ref.ec.clone()
+    model = eng.LBLSpectrum(case, rt_path='transit', voigt=ref.voigt, lines=ref.lines,
+                            predict_runs=True)
+    for _ in range(6):
+        assert torch.equal(model.run(), want)
+        assert torch.equal(model.ec, want_ec)
+    torch.cuda.synchronize()
+    spec, sync, missed = model.lbl.dyn_stats()
+    assert sync == 1 and spec == 5 and missed == 0, (spec, sync, missed)
+    assert ref.lbl.dyn_stats()[0] == 0                     # the default form never predicts
+    # another atmosphere: hotter and reversed in pressure order -> other factors per layer
+    temp2 = atm['temp'][::-1].copy() * 1.3
+    dens2 = atm['dens'][::-1].copy() * 0.05
+    isoz2 = iso['isoz'][:, ::-1].copy()
+    ref.set_atmosphere(temp2, dens2, isoz2)
+    want2 = ref.run().clone()
+    want2_ec = ref.ec.clone()
+    of_a, _ = ref.lbl.last_state(atm['nlayers'], 1)
+    model.set_atmosphere(temp2, dens2, isoz2)
+    got2 = model.run().clone()                            # planned from the OLD atmosphere
+    assert model.lbl.dyn_stats()[0] == 6
+    e, w = model.ec.cpu().numpy(), want2_ec.cpu().numpy()
+    assert np.array_equal(e == 0, w == 0)
+    np.testing.assert_allclose(e, w, rtol=1e-12)
+    np.testing.assert_allclose(got2.cpu().numpy(), want2.cpu().numpy(), rtol=1e-12)
+    torch.cuda.synchronize()
+    for _ in range(12):                                    # contradiction seen: synchronous calls,
+        assert torch.equal(model.run(), want2)             # (exact again), then predictions again
+        torch.cuda.synchronize()
+    spec, sync, missed = model.lbl.dyn_stats()
+    assert missed >= 1 and sync >= 1 + 8 and spec >= 6 + 2, (spec, sync, missed)
+    # capture: the graph holds the plan of this atmosphere ...
+    replay = model.capture()
+    assert torch.equal(replay(), want2)
+    # ... and stays right for the first one (layers it does not fit: direct gather in the graph)
+    model.set_atmosphere(atm['temp'], atm['dens'], iso['isoz'])
+    out = replay().clone()
+    np.testing.assert_allclose(out.cpu().numpy(), want.cpu().numpy(), rtol=1e-12)
+    e, w = model.ec.cpu().numpy(), want_ec.cpu().numpy()
+    assert np.array_equal(e == 0, w == 0)
+    np.testing.assert_allclose(e, w, rtol=1e-12)
+    # the default form still refuses to be captured
+    with pytest.raises(RuntimeError, match='cannot be captured'):
+        ref.capture()
+
+
 def test_resolution_mode_spectrum(eng, orc):
     """A constant-resolving-power output grid through LBLSpectrum (the reference's `resolution`
     mode: the kept samples are interpolated from the dynamic grid, _extcoeff.c:320-326 /

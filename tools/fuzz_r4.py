@@ -204,6 +204,42 @@ def ordered_case(eng, rng):
         np.testing.assert_allclose(got[0].cpu().numpy(), ws, rtol=1e-12)
 
 
+def predicted_case(eng, rng, seed):
+    """`resolution` mode with the run plan predicted from the last read-back
+    (LBLSpectrum(predict_runs=True)) against the default (synchronous) form over a random sequence
+    of atmospheres on ONE pair of models: bit for bit while the atmosphere repeats, 1e-12 with the
+    same zero pattern when it changes (the layers the plan does not fit take the direct gather)."""
+    import torch
+    from pyratbay_amd import synth
+    nl = int(rng.integers(2, 12))
+    case = synth.lbl_case(int(rng.integers(600, 2500)), nl, int(rng.integers(500, 6000)),
+                          wnosamp=int(rng.choice([12, 24, 36])), nlor=14, ndop=7, extent=60.0,
+                          cutoff=3.0, niso=2, seed=seed, resolution=float(rng.choice([3e4, 6e4, 1e5])))
+    atm, iso = case['atm'], case['iso']
+    ref = eng.LBLSpectrum(case, timestamps=False)
+    mod = eng.LBLSpectrum(case, voigt=ref.voigt, lines=ref.lines, timestamps=False,
+                          predict_runs=True)
+    state = (atm['temp'].copy(), atm['dens'].copy(), iso['isoz'].copy())
+    for step in range(int(rng.integers(6, 16))):
+        changed = step > 0 and rng.random() < 0.4
+        if changed:
+            perm = rng.permutation(nl) if rng.random() < 0.5 else np.arange(nl)
+            state = (atm['temp'][perm] * rng.uniform(0.7, 1.4), atm['dens'][perm] *
+                     10.0**rng.uniform(-1.5, 1.0), iso['isoz'][:, perm].copy())
+            ref.set_atmosphere(*state)
+            mod.set_atmosphere(*state)
+        want, want_ec = ref.run().clone(), ref.ec.clone()
+        got = mod.run()
+        e, w = mod.ec.cpu().numpy(), want_ec.cpu().numpy()
+        assert np.array_equal(e == 0, w == 0), f'step {step}: zero pattern'
+        np.testing.assert_allclose(e, w, rtol=1e-12, err_msg=f'step {step}')
+        np.testing.assert_allclose(got.cpu().numpy(), want.cpu().numpy(), rtol=1e-12)
+        if rng.random() < 0.5:
+            torch.cuda.synchronize()                  # (lets the read-back land before the next call)
+    spec, sync, missed = mod.lbl.dyn_stats()
+    return spec, missed
+
+
 def main():
     count = int(sys.argv[1]) if len(sys.argv) > 1 else 200
     seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 41000
@@ -211,7 +247,7 @@ def main():
     from pyratbay_amd import engine as eng
     eng.require_gpu()
     assert ref.available(), 'fuzz_r4 needs the compiled reference (oracle/_ref)'
-    fails, nwave_layers, ntiles, nband = 0, 0, 0, 0
+    fails, nwave_layers, ntiles, nband, npred, nmiss = 0, 0, 0, 0, 0, 0
     for i in range(count):
         seed = seed0 + i
         rng = np.random.default_rng(seed)
@@ -221,6 +257,9 @@ def main():
                     partition_case(eng, rng)
                 for _ in range(3):
                     ordered_case(eng, rng)
+                sp, mi = predicted_case(eng, rng, seed)
+                npred += sp
+                nmiss += mi
             else:
                 info = ext_case(eng, ref, rng, seed)
                 nwave_layers += info['wave']
@@ -234,7 +273,8 @@ def main():
                 break
     print(f'fuzz_r4: {count} cases from seed {seed0}: {fails} failures; wave-kernel layers '
           f'{nwave_layers}, cases where the per-tile dispatch changed the launch {ntiles}, '
-          f'band-structured lists {nband}')
+          f'band-structured lists {nband}; `resolution` calls planned from a prediction {npred}, '
+          f'contradicted read-backs {nmiss}')
     sys.exit(1 if fails else 0)
 
 

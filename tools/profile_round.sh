@@ -11,6 +11,7 @@
 #   <tag>_bench_c2_driverflags.json   --steps 20 --warmup 5
 #   <tag>_kernel_stats.csv            rocprofv3 --kernel-trace --stats of the default bench, one at a time
 #   <tag>_bench_{c2res,c3,c4,c5,c5em,c2bands,c3bands}.json   the other workloads
+#   <tag>_bench_c2res_predict.json    c2-res with the run plans predicted (PB_RES_DYN_PREDICT=1)
 #   <tag>_kernel_stats_{c5,c5em}.csv  rocprofv3 kernel stats of the retrieval batches
 #   <tag>_gather_wave.log             staged kernel alone against staged + wave-autonomous kernel (C2, 1e6 lines)
 #   <tag>_wshard.log, <tag>_rank_rccl.log   per-rank times of the wavenumber decomposition
@@ -42,6 +43,7 @@ echo "kernel stats done"
 python bench.py --workload c5 > gpurun_out/${tag}_bench_c5.json 2> gpurun_out/${tag}_bench_c5.err || exit 1
 python bench.py --workload c5-emission --steps 40 > gpurun_out/${tag}_bench_c5em.json 2> gpurun_out/${tag}_bench_c5em.err || exit 1
 python bench.py --workload c2-res > gpurun_out/${tag}_bench_c2res.json 2> gpurun_out/${tag}_bench_c2res.err || exit 1
+PB_RES_DYN_PREDICT=1 python bench.py --workload c2-res --no-cpu-baseline > gpurun_out/${tag}_bench_c2res_predict.json 2> gpurun_out/${tag}_bench_c2res_predict.err || exit 1
 python bench.py --workload c2-bands --no-north-star > gpurun_out/${tag}_bench_c2bands.json 2> gpurun_out/${tag}_bench_c2bands.err || exit 1
 python bench.py --workload c3 --steps 5 --warmup 2 --cpu-layers 4 > gpurun_out/${tag}_bench_c3.json 2> gpurun_out/${tag}_bench_c3.err || exit 1
 python bench.py --workload c3-bands --steps 5 --warmup 2 --cpu-layers 4 > gpurun_out/${tag}_bench_c3bands.json 2> gpurun_out/${tag}_bench_c3bands.err || exit 1
