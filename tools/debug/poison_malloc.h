@@ -8,8 +8,14 @@ inline hipError_t raw_malloc(void **p, size_t n) { return hipMalloc(p, n); }
 template <class T> inline hipError_t pmalloc(T **p, size_t n)
 {
     hipError_t e = raw_malloc((void **)p, n);
-    if (e == hipSuccess && n)
+    // (hipMemset of device memory returns before the fill has run, and the null stream does not
+    // order it against the library's non-blocking streams: without the wait the fill can land
+    // AFTER the first kernels that write the buffer -- seen as NaNs in valid results)
+    if (e == hipSuccess && n) {
         e = hipMemset(*p, 0xFF, n);
+        if (e == hipSuccess)
+            e = hipDeviceSynchronize();
+    }
     return e;
 }
 }  // namespace pbpoison
