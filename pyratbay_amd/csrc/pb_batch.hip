@@ -178,7 +178,10 @@ __global__ __launch_bounds__(kBlock) void k_interp_ec_batch(
 // 512 B).  The rows of ec and of the table start at layer * nwave samples, 8-byte aligned only when
 // nwave is odd, so the pairs start at the first EVEN absolute element of the row: the accesses are
 // then 16-byte aligned; the odd sample in front of / behind the pairs is done by one lane on its own.
-template <int kS, bool kFull>
+// NP = pair slots per thread, kBlock slots apart (every store instruction of a workgroup still
+// covers 4 KiB of consecutive samples): NP = 2 halves the per-walker scalar loads, waits and
+// branches per byte written (0.902 against 0.914 ms per 64 walkers at C5's shape, same bits).
+template <int kS, bool kFull, int NP>
 __global__ __launch_bounds__(kBlock) void k_interp_ec_batch2(
     double *ec, const double *etable, const int32_t *tlo, const double *coef, int nmol,
     int ntemp, int nlayers, int nwave, int nwalkers, int chunk)
@@ -199,50 +202,65 @@ __global__ __launch_bounds__(kBlock) void k_interp_ec_batch2(
     // first sample of the row whose absolute element index is even (all slices / walkers share
     // the parity when slice and nlayers * nwave are of one parity -- checked by the launcher)
     const int head = (int)(((int64_t)k * nwave) & 1);
-    const int gt = blockIdx.x * kBlock + threadIdx.x;
-    // thread 0 of a row that starts at an odd element takes that sample alone; the pairs follow
-    const int ii = head ? (gt == 0 ? 0 : 1 + 2 * (gt - 1)) : 2 * gt;
-    if (ii >= nwave)
-        return;
-    const bool pair = !(head && gt == 0) && ii + 1 < nwave;
-    const double *tab = etable + (int64_t)k * nwave + ii;
-    d2 lo[kS], hi[kS];
-    auto load = [&](int j, int b) -> d2 {
-        const double *p = tab + ((int64_t)j * ntemp + b) * slice;
-        if (pair)
-            return *reinterpret_cast<const d2 *>(p);
+    // slot q of a row: its first sample alone when the row starts at an odd element, then pairs
+    int ii[NP];
+    bool live[NP], pair[NP];
+#pragma unroll
+    for (int p = 0; p < NP; p++) {
+        const int q = (blockIdx.x * NP + p) * kBlock + threadIdx.x;
+        ii[p] = head ? (q == 0 ? 0 : 1 + 2 * (q - 1)) : 2 * q;
+        live[p] = ii[p] < nwave;
+        pair[p] = live[p] && !(head && q == 0) && ii[p] + 1 < nwave;
+        if (!live[p])
+            ii[p] = 0;                                      // (a valid address; never stored)
+    }
+    if (!live[0])
+        return;                                             // (slots ascend with p)
+    const double *tab = etable + (int64_t)k * nwave;
+    d2 lo[NP][kS], hi[NP][kS];
+    auto load = [&](int p, int j, int b) -> d2 {
+        const double *ptr = tab + ii[p] + ((int64_t)j * ntemp + b) * slice;
+        if (pair[p])
+            return *reinterpret_cast<const d2 *>(ptr);
         d2 v;
-        v.x = p[0];
+        v.x = ptr[0];
         v.y = 0.0;
         return v;
     };
 #pragma unroll
-    for (int j = 0; j < kS; j++)
-        hi[j] = kFull || j < nmol ? load(j, bmin) : d2{0.0, 0.0};
+    for (int p = 0; p < NP; p++)
+#pragma unroll
+        for (int j = 0; j < kS; j++)
+            hi[p][j] = kFull || j < nmol ? load(p, j, bmin) : d2{0.0, 0.0};
     for (int b = bmin; b <= bmax; b++) {
 #pragma unroll
-        for (int j = 0; j < kS; j++) {
-            lo[j] = hi[j];
-            hi[j] = kFull || j < nmol ? load(j, b + 1) : d2{0.0, 0.0};
-        }
+        for (int p = 0; p < NP; p++)
+#pragma unroll
+            for (int j = 0; j < kS; j++) {
+                lo[p][j] = hi[p][j];
+                hi[p][j] = kFull || j < nmol ? load(p, j, b + 1) : d2{0.0, 0.0};
+            }
         for (int w = w0; w < w1; w++) {
             const int64_t wk = (int64_t)w * nlayers + k;
             if (ctlo[wk] != b)
                 continue;                                   // wave-uniform
             const ccoef_t co = (ccoef_t)(unsigned long long)(coef + wk * 2 * kS);
-            d2 acc = {0.0, 0.0};
 #pragma unroll
-            for (int j = 0; j < kS; j++)
-                if (kFull || j < nmol) {
-                    // same products and sums per sample as the one-sample kernel
-                    acc.x += lo[j].x * co[j] + hi[j].x * co[kS + j];
-                    acc.y += lo[j].y * co[j] + hi[j].y * co[kS + j];
-                }
-            double *dst = ec + wk * nwave + ii;
-            if (pair)
-                *reinterpret_cast<d2 *>(dst) = acc;
-            else
-                dst[0] = acc.x;
+            for (int p = 0; p < NP; p++) {
+                d2 acc = {0.0, 0.0};
+#pragma unroll
+                for (int j = 0; j < kS; j++)
+                    if (kFull || j < nmol) {
+                        // same products and sums per sample as the one-sample kernel
+                        acc.x += lo[p][j].x * co[j] + hi[p][j].x * co[kS + j];
+                        acc.y += lo[p][j].y * co[j] + hi[p][j].y * co[kS + j];
+                    }
+                double *dst = ec + wk * nwave + ii[p];
+                if (pair[p])
+                    *reinterpret_cast<d2 *>(dst) = acc;
+                else if (live[p])
+                    dst[0] = acc.x;
+            }
         }
     }
 }
@@ -759,6 +777,72 @@ __global__ __launch_bounds__(TB, WPS) void k_transit_mfma(
 // products, their order and the epilogue's arithmetic are those of k_transit_mfma: same bits.
 // Columns that cross at similar rows must sit together for the exit to happen: the caller orders
 // the columns (TableSpectrum.column_order) and passes `scatter`, the grid index of each column.
+template <int B, int E, class F>
+__device__ __forceinline__ void static_for_rows(F &&f)
+{
+    if constexpr (B < E) {
+        f(std::integral_constant<int, B>{});
+        static_for_rows<B + 1, E>(f);
+    }
+}
+
+// pb::exp_s of four values at once, cut into 15 slices of four independent instructions each (the
+// same operations in the same order per value: same bits), so that the slices of one column tile's
+// epilogue can be issued between the matrix products of the other (k_transit_mfma_rows).
+struct Exp4 {
+    double x[4], n[4], r[4], p[4];
+};
+constexpr int kExp4Slices = 15;
+template <int S>
+__device__ __forceinline__ void exp4_slice(Exp4 &e)
+{
+    using pb::sgpr_const;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        if constexpr (S == 0)
+            e.n[j] = rint(e.x[j] * sgpr_const(0x1.71547652b82fep+0));
+        else if constexpr (S == 1)
+            e.r[j] = fma(e.n[j], sgpr_const(-0x1.62e42fefa39efp-1), e.x[j]);
+        else if constexpr (S == 2)
+            e.r[j] = fma(sgpr_const(-0x1.abc9e3b39803fp-56), e.n[j], e.r[j]);
+        else if constexpr (S == 3)
+            e.p[j] = fma(sgpr_const(0x1.ade156a5dcb37p-26), e.r[j], sgpr_const(0x1.28af3fca7ab0cp-22));
+        else if constexpr (S == 4)
+            e.p[j] = fma(e.r[j], e.p[j], sgpr_const(0x1.71dee623fde64p-19));
+        else if constexpr (S == 5)
+            e.p[j] = fma(e.r[j], e.p[j], sgpr_const(0x1.a01997c89e6b0p-16));
+        else if constexpr (S == 6)
+            e.p[j] = fma(e.r[j], e.p[j], sgpr_const(0x1.a01a014761f6ep-13));
+        else if constexpr (S == 7)
+            e.p[j] = fma(e.r[j], e.p[j], sgpr_const(0x1.6c16c1852b7b0p-10));
+        else if constexpr (S == 8)
+            e.p[j] = fma(e.r[j], e.p[j], sgpr_const(0x1.1111111122322p-7));
+        else if constexpr (S == 9)
+            e.p[j] = fma(e.r[j], e.p[j], sgpr_const(0x1.55555555502a1p-5));
+        else if constexpr (S == 10)
+            e.p[j] = fma(e.r[j], e.p[j], sgpr_const(0x1.5555555555511p-3));
+        else if constexpr (S == 11)
+            e.p[j] = fma(e.r[j], e.p[j], sgpr_const(0x1.000000000000bp-1));
+        else if constexpr (S == 12)
+            e.p[j] = fma(e.r[j], e.p[j], 1.0);
+        else if constexpr (S == 13)
+            e.p[j] = fma(e.r[j], e.p[j], 1.0);
+        else if constexpr (S == 14) {
+            double v = ldexp(e.p[j], (int)e.n[j]);
+            v = e.x[j] > 1024.0 ? __builtin_huge_val() : v;
+            e.p[j] = e.x[j] < -1075.0 ? 0.0 : v;            // the result
+        }
+    }
+}
+template <int B, int E>
+__device__ __forceinline__ void exp4_slices(Exp4 &e)
+{
+    if constexpr (B < E) {
+        exp4_slice<B>(e);
+        exp4_slices<B + 1, E>(e);
+    }
+}
+
 template <int MT, int WPS, int TB>
 __global__ __launch_bounds__(TB, WPS) void k_transit_mfma_rows(
     double *spectrum, const double *ec, const double *qblk, const double *radius, int nblk,
@@ -813,12 +897,30 @@ __global__ __launch_bounds__(TB, WPS) void k_transit_mfma_rows(
         // measured slower, 1.27 against 1.16 ms at C5's shape -- the loads an exit wastes)
         if constexpr (m + 1 < MT)                         // (clamped rows: harmless past the end)
             loadb(std::integral_constant<int, m + 1>{});
+        // Column tile 0's products; then column tile 1's with the exponentials of tile 0's rows
+        // between them: a product holds the matrix pipe for 64 cycles, the slices issue meanwhile
+        // (pinned by scheduling barriers: left alone, the compiler keeps the products together).
+        // Tile 0's exponentials are computed for all four rows and selected afterwards.  Same bits;
+        // 1.19 against 1.21 ms per 64 walkers at C5's shape.
         v4d C[2] = {v4d{0.0, 0.0, 0.0, 0.0}, v4d{0.0, 0.0, 0.0, 0.0}};
+        Exp4 e0;
+        {
+            constexpr int K = 4 * m + 4;
 #pragma unroll
-        for (int ks = 0; ks < 4 * m + 4; ks++) {
-            const double a = sq[(qblocks(m) + ks) * 64];
-            C[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b[ks][0], C[0], 0, 0, 0);
-            C[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b[ks][1], C[1], 0, 0, 0);
+            for (int ks = 0; ks < K; ks++)
+                C[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(sq[(qblocks(m) + ks) * 64], b[ks][0], C[0],
+                                                            0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+                e0.x[j] = -C[0][j];
+            __builtin_amdgcn_sched_barrier(0);
+            static_for_rows<0, K>([&](auto ksc) {
+                constexpr int ks = decltype(ksc)::value;
+                C[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(sq[(qblocks(m) + ks) * 64], b[ks][1], C[1],
+                                                            0, 0, 0);
+                exp4_slices<(ks * kExp4Slices) / K, ((ks + 1) * kExp4Slices) / K>(e0);
+                __builtin_amdgcn_sched_barrier(0);
+            });
         }
 #pragma unroll
         for (int t = 0; t < 2; t++) {
@@ -838,7 +940,11 @@ __global__ __launch_bounds__(TB, WPS) void k_transit_mfma_rows(
                 const int r = 16 * m + 4 * j + kq;
                 const bool in = r < nimpact && r <= fst;
                 const double rr = srad[16 * m + 4 * j];
-                const double fv = in ? pb::exp_s(-C[t][j]) * rr : 0.0;
+                double fv;
+                if (t == 0)
+                    fv = in ? e0.p[j] * rr : 0.0;
+                else
+                    fv = in ? pb::exp_s(-C[t][j]) * rr : 0.0;
                 const double up = __shfl(fv, src_lane);   // q > 0: row r - 1; q = 0: row r + 3
                 const double fprev = kq > 0 ? up : carry[t];
                 carry[t] = up;
@@ -865,7 +971,11 @@ __global__ __launch_bounds__(TB, WPS) void k_transit_mfma_rows(
         a += __shfl_xor(a, 32);
         if (kq == 0 && ok[t]) {
             const int64_t dst = scatter ? scatter[col0 + t] : col0 + t;
-            spectrum[(int64_t)w * nwave + dst] = (rtop * rtop + 2 * (a * 0.5)) / (rstar * rstar);
+            // (an index outside the grid -- a caller's column_d that is not a permutation -- is
+            // dropped, not written out of bounds)
+            if (dst >= 0 && dst < nwave)
+                spectrum[(int64_t)w * nwave + dst] =
+                    (rtop * rtop + 2 * (a * 0.5)) / (rstar * rstar);
         }
     }
 }
@@ -1825,13 +1935,26 @@ int pb_interp_ec_batch(double *ec_d, const double *etable_d, const double *ttabl
     static const bool pairs_on = !(getenv("PB_INTERP_PAIRS") && atoi(getenv("PB_INTERP_PAIRS")) == 0);
     const bool pairs = pairs_on && nwave >= 4 && (((int64_t)nlayers * nwave) % 2 == 0) &&
                        ((uintptr_t)ec_d % 16 == 0) && ((uintptr_t)etable_d % 16 == 0);
+    // two pair slots per thread for launches that still fill the chip with half the workgroups
+    // (up to four species: with eight, 146 registers would cost a wavefront per SIMD)
+    int np = 1;
+    if (pairs && nmol <= 4 && (int64_t)pb::div_up(nwave / 2 + 2, 2 * kBlock) * nlayers *
+                         pb::div_up(nwalkers, chunk) >= 4096)
+        np = 2;
+    if (const char *e = getenv("PB_INTERP_NP"))
+        np = atoi(e) == 2 ? 2 : 1;
     if (pairs)
-        grid.x = pb::div_up(nwave / 2 + 2, kBlock);
+        grid.x = pb::div_up(nwave / 2 + 2, kBlock * np);
 #define PB_INTERP(S, FULL)                                                                     \
     do {                                                                                       \
-        if (pairs)                                                                             \
-            k_interp_ec_batch2<S, FULL><<<grid, kBlock, 0, s>>>(ec_d, etable_d, tlo, coef, nmol, \
-                                                                ntemp, nlayers, nwave, nwalkers, chunk); \
+        if (pairs && np == 2)                                                                  \
+            k_interp_ec_batch2<S, FULL, 2><<<grid, kBlock, 0, s>>>(ec_d, etable_d, tlo, coef,  \
+                                                                   nmol, ntemp, nlayers, nwave, \
+                                                                   nwalkers, chunk);           \
+        else if (pairs)                                                                        \
+            k_interp_ec_batch2<S, FULL, 1><<<grid, kBlock, 0, s>>>(ec_d, etable_d, tlo, coef,  \
+                                                                   nmol, ntemp, nlayers, nwave, \
+                                                                   nwalkers, chunk);           \
         else                                                                                   \
             k_interp_ec_batch<S, FULL><<<grid, kBlock, 0, s>>>(ec_d, etable_d, tlo, coef, nmol,  \
                                                                ntemp, nlayers, nwave, nwalkers, chunk); \

@@ -584,8 +584,11 @@ __global__ void k_emission_fused(double *flux, const double *ec, const double *i
             total += val * weights[m];
         }
     }
-    // (ordered batches: column j of ec / wn is column scatter[j] of the grid)
-    flux[(int64_t)wk * nwave + (scatter ? scatter[j] : j)] = total;
+    // (ordered batches: column j of ec / wn is column scatter[j] of the grid; an index outside
+    // the grid is dropped, not written out of bounds)
+    const int dst = scatter ? scatter[j] : j;
+    if (dst >= 0 && dst < nwave)
+        flux[(int64_t)wk * nwave + dst] = total;
 }
 
 // ---------------------------------------------------------------------------

@@ -440,6 +440,7 @@ int pb_voigt_rephase(pb_voigt **out, pb_voigt *src, int osamp, hipStream_t s)
         if (hipMemsetAsync(v->zero_block, 0, count * sizeof(double), s) != hipSuccess ||
             hipMemsetAsync(v->d_rowmask, 0, (size_t)std::max(v->nlor, 1), s) != hipSuccess)
             return fail(PB_ERR_HIP, "zeroing failed");
+        v->lazy_bytes += (int64_t)count * 8;              // (reported with the table's bytes)
         double *zdata = v->zero_block + kPmPad;
         const uintptr_t span = ((uintptr_t)1 << 39) * sizeof(double);
         const uintptr_t at = reinterpret_cast<uintptr_t>(zdata);
