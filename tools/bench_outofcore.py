@@ -69,7 +69,10 @@ def main():
                device_memory_gib=torch.cuda.mem_get_info()[1] / 2**30 -
                torch.cuda.mem_get_info()[0] / 2**30)
     print(json.dumps(rec), flush=True)
-    if args.check:
+    if args.check and lbl.last_chunks == 0:
+        print('the records fit the budget: the call was not chunked, nothing to compare '
+              '(lower --budget-gib or raise --lines)', flush=True)
+    elif args.check:
         # the same list in ONE call (its records fit in HBM here: that is what the budget is
         # for on a smaller card or a longer list), one workgroup per tile as in the chunked form
         os.environ['PB_STAGE_SPLIT'] = '1'
