@@ -80,3 +80,49 @@ def test_lbl_plan_rejects_bad_calls(eng):
         lbl.set_gather_mode('fastest')
     ok = lbl.extinction(t[:2].contiguous(), d[:2].contiguous(), z[:, :2].contiguous())
     assert ok.shape == (2, 1, 257) and bool((ok >= 0).all())
+
+
+def test_ordered_batches_drop_indices_outside_the_grid(eng):
+    """pb_transit_spectrum_ordered / pb_emission_flux_ordered scatter every column to the grid
+    index the caller gives; an index outside the grid (a column_d that is not a permutation) is
+    dropped by the kernels, not written out of bounds: the other columns are those of the
+    unordered call, bit for bit, and the spectrum array is touched nowhere else."""
+    import torch
+    import cases
+    rng = np.random.default_rng(3)
+    L, W, nw = 24, 333, 2
+    c = cases.column_case(seed=4, nlayers=L, nwave=W)
+    ecs = np.array([c['ec'] * 10.0**rng.uniform(-1, 1) for _ in range(nw)])
+    radius = np.array([c['radius'] for _ in range(nw)])
+    ec_d, rad_d = eng.dev(ecs), eng.dev(radius)
+    path = eng.transit_path_device(rad_d, 0)
+    want = eng.transit_spectrum_batch(ec_d, path, rad_d, c['rstar'], 0, L, 10.0)
+    order = torch.arange(W, device='cuda', dtype=torch.int32)
+    bad = order.clone()
+    bad[7], bad[100], bad[W - 1] = -1, W, 2**30
+    keep = torch.ones(W, dtype=torch.bool, device='cuda')
+    keep[[7, 100, W - 1]] = False
+    # (a guard band around the spectrum: the library writes through raw pointers)
+    buf = torch.full((nw * W + 2 * 4096,), 7.0, dtype=torch.float64, device='cuda')
+    spec = buf[4096:4096 + nw * W].view(nw, W)
+    nwork = eng._capi.lib().pb_transit_work_doubles(L, 0, L, W, nw)
+    work = torch.empty(nwork, dtype=torch.float64, device='cuda')
+    eng.call('pb_transit_spectrum_ordered', eng._ptr(spec), eng._ptr(ec_d), eng._ptr(path),
+             eng._ptr(rad_d), eng._ptr(bad), float(c['rstar']), 0, L, 10.0, L, W, nw,
+             eng._ptr(work), eng._stream())
+    assert torch.equal(spec[:, keep], want[:, keep])
+    assert bool((spec[:, ~keep] == 7.0).all())
+    assert bool((buf[:4096] == 7.0).all()) and bool((buf[4096 + nw * W:] == 7.0).all())
+    # emission
+    temps = eng.dev(np.array([c['temp'] for _ in range(nw)]))
+    intervals = (rad_d[:, :-1] - rad_d[:, 1:]).contiguous()
+    mu, wts = eng.default_quadrature()
+    mu_d, w_d, wn_d = eng.dev(mu), eng.dev(wts), eng.dev(c['wn'])
+    want_e = eng.emission_flux_batch(ec_d, intervals, wn_d, temps, mu_d, w_d, 0, L, 10.0)
+    buf.fill_(7.0)
+    eng.call('pb_emission_flux_ordered', eng._ptr(spec), eng._ptr(ec_d), eng._ptr(intervals),
+             eng._ptr(wn_d), eng._ptr(temps), eng._ptr(mu_d), eng._ptr(w_d), eng._ptr(bad),
+             len(mu), 10.0, 0, L, L, W, nw, eng._stream())
+    assert torch.equal(spec[:, keep], want_e[:, keep])
+    assert bool((spec[:, ~keep] == 7.0).all())
+    assert bool((buf[:4096] == 7.0).all()) and bool((buf[4096 + nw * W:] == 7.0).all())
