@@ -11,17 +11,19 @@ import torch
 import bench
 from pyratbay_amd import engine, dist as pbdist
 
-world, r, depth = 8, 4, int(os.environ.get('DEPTH', '3'))
+world = int(os.environ.get('WORLD', '8'))
+r, depth = world // 2, int(os.environ.get('DEPTH', '3'))
 K = int(os.environ.get('STACK', '2'))
 case = bench.make_case(bench.WORKLOADS[sys.argv[1] if len(sys.argv) > 1 else 'c2'])
 g, atm, ln, iso, vg = (case[k] for k in ('grid', 'atm', 'lines', 'iso', 'voigt'))
 nwave, L = g['nwave'], atm['nlayers']
-b = pbdist.uniform_bounds(nwave, world)
+b = pbdist.uniform_bounds(nwave, world) if world > 1 else np.array([0, nwave])
 w0, wc = int(b[r]), int(b[r + 1] - b[r])
 streams = engine.side_streams(depth)
 
 def timed(submit, per, n=300):
-    for _ in range(60): submit()
+    n = max(20, n // (1 if world > 1 else 4))
+    for _ in range(max(10, n // 5)): submit()
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(n): submit()
     torch.cuda.synchronize(); return 1e3 * (time.perf_counter() - t0) / (n * per)
