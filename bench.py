@@ -75,6 +75,12 @@ WORKLOADS = {
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 LDS_PEAK_TBS = 150.0      # MI355X_MICROARCH.md: ds_read_b64/b128 aggregate, every CU streaming
 NORTH_STAR = 'c2-1e6'     # north_star's >= 50x target configuration
+# GPU-only legs of the default run: (workload, timed steps, warm-up steps) -- every other BASELINE
+# configuration in its single-GPU form + the two other grid / list structures, so that the
+# driver's one `python bench.py` times them all
+LEGS = (('c3', 5, 2), ('c4', 3, 1), ('c5', 40, 3), ('c5-emission', 24, 3), ('c2-res', 30, 3),
+        ('c2-bands', 50, 4))
+LEG_TIMEOUT_S = 150.0
 
 
 class stdout_to_stderr:
@@ -332,6 +338,51 @@ def dominant_kernel(lbl, nlayers):
     return name
 
 
+def roofline_block(model, gather_ms, launches, nlayers_rank, wcount, nlayers, nwave, value,
+                   traffic_workload):
+    """The `roofline` object of a line-by-line workload, for its dominant kernel (the extinction
+    gather).  What binds that kernel is the LDS read rate: every profile
+    sample it multiplies is one 8-byte LDS read, zero lanes around a row included, counted on the
+    device from the record windows of the last launch -- that is the headline block
+    (`bound: "lds"`).  SURVEY 8(d)'s algorithmic HBM bytes of the same launch (line list read
+    once, 26 B/line; ec written once, 8 B per layer x sample of the shard) over the same kernel
+    time stand beside it as `hbm_algorithmic`, the PMC traffic as `traffic` (HBM bytes per
+    launch).  A launch that kept no packed records (global gather, dynamic grids) has no lane
+    count: its headline block is the HBM one."""
+    n_lines = model.lines.nlines
+    kernel_bytes = 26.0 * n_lines + 8.0 * nlayers_rank * wcount
+    path_bytes = 26.0 * n_lines + 32.0 * nlayers * nwave + 8.0 * nwave
+    kernel_ms = gather_ms / max(launches, 1)
+    achieved = kernel_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
+    kernel = dominant_kernel(model.lbl, nlayers_rank)
+    traffic = measured_traffic(traffic_workload) if traffic_workload else None
+    hbm = {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+           'frac': achieved / HBM_PEAK_GBS, 'kernel_bytes': kernel_bytes,
+           'path_bytes_per_spectrum': path_bytes, 'path_GBps': path_bytes * value / 1e9}
+    # the operand SURVEY 8(d)'s byte count leaves out: the Voigt-table samples the launch's
+    # live records select, each counted once (what any evaluation must read of `profile`)
+    tsamp = model.lbl.last_table_samples()
+    if tsamp is not None:
+        wt = (kernel_bytes + 8.0 * tsamp) / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
+        hbm['table_bytes_unique'] = 8.0 * tsamp
+        hbm['with_table'] = {'bytes': kernel_bytes + 8.0 * tsamp, 'achieved': wt,
+                             'frac': wt / HBM_PEAK_GBS,
+                             'note': 'kernel_bytes + distinct table samples x 8 B: compare with '
+                                     '`traffic`'}
+    work = model.lbl.last_work()
+    if work is not None and kernel_ms > 0:
+        lds_tbps = work['fma_lanes_issued'] * 8.0 / (kernel_ms * 1e-3) / 1e12
+        return {'bound': 'lds', 'kernel': kernel, 'achieved': lds_tbps, 'peak': LDS_PEAK_TBS,
+                'unit': 'TB/s', 'frac': lds_tbps / LDS_PEAK_TBS, 'traffic': traffic,
+                'kernel_ms': kernel_ms,
+                'lds_bytes': work['fma_lanes_issued'] * 8.0,
+                'fma_lanes_useful': work['fma_lanes_useful'],
+                'fma_lanes_issued': work['fma_lanes_issued'],
+                'f64_fma_TFLOPs': 2.0 * work['fma_lanes_useful'] / (kernel_ms * 1e-3) / 1e12,
+                'hbm_algorithmic': hbm}
+    return dict(hbm, kernel=kernel, traffic=traffic, kernel_ms=kernel_ms)
+
+
 def measured_traffic(workload):
     """HBM bytes per launch of the dominant kernel from the PMC passes of tools/pmc_traffic.sh
     -- used only when that file was produced with THIS build of libpbhip.so (hash match);
@@ -388,6 +439,52 @@ def self_launch(argv, nranks):
                     procs[q].terminate()         # exactly the children started above
         time.sleep(0.05)
     return rc
+
+
+def start_legs(names):
+    """One idle child per leg, started BEFORE this process touches the GPU (`--leg-wait`: the
+    child imports nothing and makes no GPU call until it reads a line from stdin)."""
+    known = {n: (k, w) for n, k, w in LEGS}
+    procs = []
+    for name in names:
+        if name not in known:
+            raise SystemExit(f'--legs: unknown leg {name!r} (known: {sorted(known)})')
+        steps, warm = known[name]
+        cmd = [sys.executable, os.path.abspath(__file__), '--leg-wait', '--workload', name,
+               '--steps', str(steps), '--warmup', str(warm), '--no-cpu-baseline',
+               '--sustain-seconds', '0']
+        procs.append((name, subprocess.Popen(cmd, stdin=subprocess.PIPE, stdout=subprocess.PIPE,
+                                             stderr=subprocess.DEVNULL, text=True, cwd=ROOT)))
+    return procs
+
+
+def run_legs(procs):
+    """Release the leg children one after the other and keep the short form of each one's JSON
+    line: value, ms_per_step, the dominant kernel and its roofline block.  A leg that fails or
+    exceeds LEG_TIMEOUT_S is reported as such (and killed by PID); the others still run."""
+    legs = {}
+    for name, p in procs:
+        t0 = time.perf_counter()
+        try:
+            stdout, _ = p.communicate('go\n', timeout=LEG_TIMEOUT_S)
+            line = [ln for ln in stdout.splitlines() if ln.startswith('{')][-1]
+            d = json.loads(line)
+            cfg = d.get('config', {})
+            legs[name] = {
+                'metric': d['metric'], 'value': d['value'], 'unit': d['unit'],
+                'steps': d['steps'], 'warmup': d['warmup'], 'ms_per_step': d['ms_per_step'],
+                'workload': cfg.get('workload'), 'parallelism': cfg.get('parallelism'),
+                'init_seconds': cfg.get('init_seconds'), 'roofline': d.get('roofline'),
+                'gpu_state': cfg.get('gpu_state'),
+                'wall_seconds': round(time.perf_counter() - t0, 1)}
+            for k in ('unpipelined_ms_per_spectrum', 'column_order', 'run_plans'):
+                if cfg.get(k) is not None:
+                    legs[name][k] = cfg[k]
+        except Exception as e:                                   # noqa: BLE001
+            p.kill()
+            legs[name] = {'error': f'{type(e).__name__}: {e}'[:200],
+                          'wall_seconds': round(time.perf_counter() - t0, 1)}
+    return legs
 
 
 def launch_selftest(mode):
@@ -457,6 +554,12 @@ def main():
     ap.add_argument('--rank-worker', action='store_true', help=argparse.SUPPRESS)
     ap.add_argument('--selftest-launch', default=None, choices=['ok', 'fail'],
                     help=argparse.SUPPRESS)
+    ap.add_argument('--no-legs', action='store_true',
+                    help='skip the GPU-only legs of the default c2 run (the other BASELINE '
+                         'configurations, each a child process of its own: `legs` in the JSON line)')
+    ap.add_argument('--legs', default=','.join(n for n, _, _ in LEGS),
+                    help='comma-separated legs of the default run (default: %(default)s)')
+    ap.add_argument('--leg-wait', action='store_true', help=argparse.SUPPRESS)
     ap.add_argument('--sustain-seconds', type=float, default=3.0,
                     help='length of the sustained legs at N=1 (config.sustained; 0: skip)')
     args = ap.parse_args()
@@ -464,6 +567,11 @@ def main():
         return cpu_worker()
     if args.rank_worker:
         return rank_worker()
+    if args.leg_wait:
+        # a leg of the default run: started before the parent touched the GPU, idle (nothing
+        # imported, no GPU call) until the parent says go
+        if not sys.stdin.readline().strip():
+            return                                           # the parent went away
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         # plain `python bench.py --gpus N`: start the ranks ourselves (before any GPU call)
         sys.exit(self_launch(sys.argv[1:], args.gpus))
@@ -496,10 +604,15 @@ def main():
                                      stdin=subprocess.PIPE, stdout=subprocess.PIPE, text=True,
                                      cwd=ROOT)
 
+    leg_procs = []
+    if world == 1 and args.workload == 'c2' and not args.no_legs and not args.leg_wait:
+        leg_procs = start_legs([n for n in args.legs.split(',') if n])
+
     import torch
     import torch.distributed as dist
     from pyratbay_amd import engine
     from pyratbay_amd.dist import SpectrumGather, LayerShardedTransit
+    from tools.gpu_state import Sampler
 
     # PB_REHEARSE=1: every rank on GPU 0 with gloo (collectives staged through the host) --
     # only to rehearse the N>1 code path on a one-GPU box; never a benchmark setting
@@ -667,9 +780,11 @@ def main():
         torch.cuda.synchronize()
         res['init_seconds'] = round(time.perf_counter() - t0, 3)
 
-        elapsed, gather_ms, launches = timed_steps(
-            run_steps, args.steps, args.warmup, model.lbl, world, dist, torch.cuda.synchronize,
-            dev_reduce)
+        with Sampler() as state:
+            elapsed, gather_ms, launches = timed_steps(
+                run_steps, args.steps, args.warmup, model.lbl, world, dist,
+                torch.cuda.synchronize, dev_reduce)
+        res['gpu_state'] = state.summary()
         # (replicas: every rank completed `steps` spectra of its own in that time)
         res.update(model=model, elapsed=elapsed, gather_ms=gather_ms, launches=launches,
                    value=args.steps / elapsed * (world if kind == 'replicas' else 1),
@@ -700,8 +815,10 @@ def main():
                 return [out]
             sus = {'seconds_target': args.sustain_seconds}
             n = max(args.steps, int(np.ceil(1.05 * args.sustain_seconds * args.steps / elapsed)))
-            el, _, _ = timed_steps(run_steps, n, 0, model.lbl, world, dist,
-                                   torch.cuda.synchronize, dev_reduce, kernel_events=False)
+            with Sampler() as state:
+                el, _, _ = timed_steps(run_steps, n, 0, model.lbl, world, dist,
+                                       torch.cuda.synchronize, dev_reduce, kernel_events=False)
+            res['gpu_state'] = state.summary() or res.get('gpu_state')
             key = f"in_flight_{res.get('streams', 1)}"
             sus[key] = {'spectra_per_s': n / el, 'spectra': n, 'seconds': el}
             if pipelined:
@@ -767,42 +884,9 @@ def main():
     if rank == 0:
         ms_per_step = 1e3 * elapsed / args.steps
         value = args.steps / elapsed
-        # dominant kernel: the extinction gather (roofline.kernel).  Algorithmic bytes per
-        # launch = the part of SURVEY 8(d)'s per-spectrum figure that this kernel moves: read
-        # the line list once (26 B/line), write ec once (8 B per layer x sample of the shard).
         n_lines = model.lines.nlines
-        kernel_bytes = 26.0 * n_lines + 8.0 * nlayers_rank * wcount
-        path_bytes = 26.0 * n_lines + 32.0 * nlayers * nwave + 8.0 * nwave
-        kernel_ms = gather_ms / max(launches, 1)
-        achieved = kernel_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
-        roof = {'bound': 'hbm', 'kernel': dominant_kernel(model.lbl, nlayers_rank),
-                'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                'frac': achieved / HBM_PEAK_GBS,
-                'traffic': measured_traffic(args.workload) if world == 1 else None,
-                'kernel_ms': kernel_ms, 'kernel_bytes': kernel_bytes,
-                'path_bytes_per_spectrum': path_bytes, 'path_GBps': path_bytes * value / 1e9}
-        # what the gather kernel IS bound by: every profile sample it multiplies is one 8-byte
-        # LDS read (zero lanes around a row included) -- counted on the device from the record
-        # windows of the last launch
-        # the operand SURVEY 8(d)'s byte count leaves out: the Voigt-table samples the launch's
-        # live records select, each counted once (what any evaluation must read of `profile`)
-        tsamp = model.lbl.last_table_samples()
-        if tsamp is not None:
-            roof['table_bytes_unique'] = 8.0 * tsamp
-            roof['with_table'] = {
-                'bytes': kernel_bytes + 8.0 * tsamp,
-                'achieved': (kernel_bytes + 8.0 * tsamp) / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0,
-                'note': 'kernel_bytes + distinct table samples x 8 B: compare with `traffic`'}
-            roof['with_table']['frac'] = roof['with_table']['achieved'] / HBM_PEAK_GBS
-        work = model.lbl.last_work()
-        if work is not None and kernel_ms > 0:
-            lds_tbps = work['fma_lanes_issued'] * 8.0 / (kernel_ms * 1e-3) / 1e12
-            roof['binding'] = {'bound': 'lds', 'achieved_TBps': lds_tbps,
-                               'peak_TBps': LDS_PEAK_TBS, 'frac': lds_tbps / LDS_PEAK_TBS,
-                               'fma_lanes_useful': work['fma_lanes_useful'],
-                               'fma_lanes_issued': work['fma_lanes_issued'],
-                               'f64_fma_TFLOPs': 2.0 * work['fma_lanes_useful'] /
-                               (kernel_ms * 1e-3) / 1e12}
+        roof = roofline_block(model, gather_ms, launches, nlayers_rank, wcount, nlayers, nwave,
+                              value, args.workload if world == 1 else None)
         if world == 1:
             par = 'single GPU' + (f", {primary['streams']} independent spectra in flight on "
                                   f"{primary['streams']} HIP streams" if pipelined else '')
@@ -844,6 +928,9 @@ def main():
             out['config']['cold_value'] = primary['cold_value']
         if primary.get('sustained') is not None:
             out['config']['sustained'] = primary['sustained']
+        if primary.get('gpu_state') is not None:
+            # clocks / power / temperature while the sustained (else the timed) steps ran
+            out['config']['gpu_state'] = primary['gpu_state']
         if world > 1:
             # both decompositions of the same run
             out['config']['value_from'] = primary['kind']
@@ -892,6 +979,10 @@ def main():
                         # crosses xGMI
                         row['speedup_before_collectives'] = single[name] / row['ms_per_spectrum']
             out['config']['rank_projection'] = proj
+        if leg_procs:
+            # the other BASELINE configurations, GPU only, one child process at a time (this
+            # process's GPU work is over; the CPU legs and the rank projection have finished)
+            out['legs'] = run_legs(leg_procs)
         print(json.dumps(out), flush=True)
     if pool is not None:
         pool.close()
@@ -959,7 +1050,11 @@ def north_star_gpu(c2_model):
     torch.cuda.synchronize()
     gpu_s = (time.perf_counter() - t0) / steps
     gather_ms, launches = model.lbl.timing_end()
+    nwave, nlayers = case['grid']['nwave'], case['atm']['nlayers']
+    roof = roofline_block(model, gather_ms, launches, nlayers, nwave, nlayers, nwave, 1.0 / gpu_s,
+                          NORTH_STAR)
     return dict(w=w, case=case, model=model, gpu_s=gpu_s, gather_ms=gather_ms, launches=launches,
+                roofline=roof,
                 ec=model.ec.cpu().numpy()[:, 0], spectrum=model.spectrum.cpu().numpy())
 
 
@@ -971,7 +1066,7 @@ def north_star_leg(ns, pool):
                          gpu_spectrum=ns['spectrum'], rt_path='transit')
     leg = {'workload': w['label'], 'gpu_ms_per_spectrum': 1e3 * gpu_s,
            'gpu_spectra_per_s': 1.0 / gpu_s, 'kernel': model.lbl.last_gather_kernel,
-           'kernel_ms': ns['gather_ms'] / max(ns['launches'], 1),
+           'kernel_ms': ns['gather_ms'] / max(ns['launches'], 1), 'roofline': ns['roofline'],
            'cpu_baseline': one, 'cpu_baseline_allcores': many,
            'speedup_vs_1core': one['seconds_per_spectrum'] / gpu_s,
            'target_speedup': 50.0}

@@ -824,6 +824,56 @@ def default_quadrature():
     return np.cos(raygrid), np.pi * (np.sin(bounds[1:])**2 - np.sin(bounds[:-1])**2)
 
 
+def _legendre_newton(n):
+    """Gauss-Legendre nodes and weights on [-1, 1] by Newton's iteration on P_n in extended
+    precision, ascending nodes.  Correctly rounded to ~1 ulp -- which is NOT what the reference
+    uses: SciPy's roots_legendre (Golub-Welsch eigenvalues + one Newton step) is up to 3 ulp off
+    in the nodes and up to 1.5e-13 relative in the weights at n <= 16 (tests/test_host_logic.py)."""
+    ld = np.longdouble
+    k = np.arange(1, n + 1, dtype=ld)
+    x = np.cos(np.pi * (k - ld(0.25)) / (n + ld(0.5)))
+
+    def pn(x):
+        p0, p1 = np.ones_like(x), x.copy()
+        for j in range(2, n + 1):
+            p0, p1 = p1, ((2 * j - 1) * x * p1 - (j - 1) * p0) / j
+        return p1, n * (x * p1 - p0) / (x * x - 1)
+    for _ in range(60):
+        p, dp = pn(x)
+        dx = p / dp
+        x = x - dx
+        if np.max(np.abs(dx)) < 1e-19:
+            break
+    _, dp = pn(x)
+    w = 2 / ((1 - x * x) * dp * dp)
+    return x[::-1].astype(float), w[::-1].astype(float)
+
+
+def gauss_quadrature(n, use_scipy=True):
+    """(mu, weights) of the reference for `quadrature = n` (pyrat/spectrum.py:41-49):
+    Gauss-Legendre nodes x_i, weights w_i of order n mapped to q = (x + 1) / 2, mu = sqrt(q),
+    weights = pi/2 w -- the flux integral  2 pi Int_0^1 I(mu) mu dmu = pi Int_0^1 I dq.  The
+    reference takes (x, w) from scipy.special.p_roots; so does this function when SciPy is
+    importable (same call of the same third-party library: bit-identical mu and weights --
+    tests/golden/g18_p_roots.npz holds SciPy 1.15.3's values); without SciPy (or with
+    use_scipy=False) the nodes come from _legendre_newton (within 3 ulp / 1.5e-13 of SciPy's).
+    n <= 16: the emission kernels keep at most 16 running sums per column."""
+    n = int(n)
+    if not 1 <= n <= 16:
+        raise ValueError(f'quadrature = {n}: 1 ... 16 nodes are supported')
+    nodes = weights = None
+    if use_scipy:
+        try:
+            from scipy.special import roots_legendre
+            nodes, weights = roots_legendre(n)
+        except ImportError:
+            pass
+    if nodes is None:
+        nodes, weights = _legendre_newton(n)
+    qnodes = 0.5 * (nodes + 1.0)
+    return np.sqrt(qnodes), 0.5 * np.pi * weights
+
+
 # --------------------------------------------------------------------------
 # Whole-path model: the three timed stages of Pyrat.run() (pyrat_obj.py:203-214)
 # --------------------------------------------------------------------------
@@ -1215,7 +1265,19 @@ class TableSpectrum:
     """Retrieval inner loop on sampled cross sections (Line_Sample path,
     pyratbay/opacity/line_sampling.py:394-463 -> _extcoeff.interp_ec): the table
     etable[nspec, ntemp, nlayers, nwave] stays resident; each eval() interpolates it to the
-    layer temperatures, weights by the species densities, and runs optical depth + RT."""
+    layer temperatures, weights by the species densities, and runs optical depth + RT.
+
+    column_order='auto' (default) has a ONE-TIME cost in the first eval_bands() call of a model
+    with >= 64 columns: the first walker's temperatures are checked on the host (one stream
+    synchronisation), its spectrum is computed to order the columns by optical depth
+    (order_columns: interpolation + transit/plane-parallel depth + a sort) and a permuted SECOND
+    COPY of the table is made (2 x the table's memory from then on; skipped when
+    1.25 x table + 2 x the batch's ec buffer do not fit in free memory, when the ordered kernels
+    do not support the shape -- transit geometry with more than 128 impact parameters -- or while
+    the stream is being captured into a graph).  Every later call is launch-only.  To keep the first call
+    free of both, call order_columns(temp, dens) yourself during set-up or pass
+    column_order=None (grid order).  In a multi-rank run every rank orders by its own first
+    walker: results do not depend on the order, memory use per rank is the same 2 x table."""
 
     def __init__(self, etable, ttable, wn, radius, rstar, rt_path='transit', itop=0,
                  maxdepth=10.0, quadrature_mu=None, quadrature_weights=None, continuum=None,
@@ -1363,7 +1425,8 @@ class TableSpectrum:
         optional per-walker radius[nw, L] (the hydrostatic profile changes with every model),
         bands: PassBands on this model's grid -> bandflux[nw, nbands].  Every stage is ONE
         launch per chunk of walkers -- interp_ec, transit_path, optical depth + transmission,
-        band integration -- with no per-walker Python and no host synchronisation.  Walkers
+        band integration -- with no per-walker Python and no host synchronisation (except the
+        one-time column ordering of the first call with column_order='auto': class docstring).  Walkers
         whose temperatures leave the table's range get +inf, like eval()'s reject path
         (pyrat_obj.py:302-320, 378-380)."""
         assert self.rt_path in ('transit', 'emission') and self.continuum is None, \
@@ -1376,11 +1439,18 @@ class TableSpectrum:
         transit = self.rt_path == 'transit'
         if self._auto_order and self.column_order is None and nw > 0 and self.nwave >= 64 and \
                 not (transit and self._one_pass()):
-            # (a walker outside the table's range would order by garbage: wait for a valid one)
+            # ONE-TIME set-up of the first batch (class docstring): a host read-back, a sort and a
+            # permuted second copy of the table.  Skipped -- grid order, nothing else changes --
+            # where the ordered kernels do not exist for the shape, while the stream is being
+            # captured into a graph, and when the second copy + this batch's ec would not fit.
             t0 = temps[0]
             table_bytes = self.etable.numel() * 8
-            if torch.cuda.mem_get_info()[0] < 1.25 * table_bytes:
+            ec_bytes = 8 * min(chunk, nw) * self.nlayers * self.nwave
+            if not self._ordered_supported() or torch.cuda.is_current_stream_capturing():
+                self._auto_order = self._auto_order and self._ordered_supported()
+            elif torch.cuda.mem_get_info()[0] < 1.25 * table_bytes + 2 * ec_bytes:
                 self._auto_order = False      # no room for the second copy of the table: grid order
+            # (a walker outside the table's range would order by garbage: wait for a valid one)
             elif bool(((t0 >= self.tmin) & (t0 <= self.tmax)).all()):
                 self.order_columns(t0, dens[0], radius[0])
         path1 = (transit_path_device(radius[0], self.itop).view(1, -1)
@@ -1414,6 +1484,14 @@ class TableSpectrum:
              self.nlayers, bands.nbands, nw, _stream())
         return out
 
+    def _ordered_supported(self):
+        """Whether the depth-ordered kernels exist for this model's shape: the transit form is the
+        matrix-core kernel only (pb_transit_spectrum_ordered: 2 ... 128 impact parameters, i.e.
+        2 <= nlayers - itop <= 128); the emission form has no limit."""
+        if self.rt_path != 'transit':
+            return True
+        return 2 <= self.nlayers - self.itop <= 128 and self.nwave >= 2
+
     def _one_pass(self):
         """The transit batch through pb_table_transit_batch (interpolation, optical depth and
         transmission in one pass, ec never stored): opt-in (`one_pass = True` or
@@ -1443,7 +1521,9 @@ class TableSpectrum:
                                           self.maxdepth)
             bands.integrate_batch(spectra, out[w0:w1])
             return
-        ordered = self.column_order is not None
+        # (an explicit order on a shape the ordered transit kernel does not take -- more than 128
+        # impact parameters -- is worked in grid order: the spectra do not depend on the order)
+        ordered = self.column_order is not None and self._ordered_supported()
         ec = interp_ec_batch(self.etable_ordered if ordered else self.etable, self.ttable,
                              temps[w0:w1], dens[w0:w1])
         if self.rt_path != 'transit':

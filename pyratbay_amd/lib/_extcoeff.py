@@ -88,17 +88,17 @@ def _content_key(a):
     A larger buffer is identified by (address, shape, strides, dtype, writeable); the first
     time it is hashed in full, afterwards only a 64-KiB strided probe of it is -- when the
     probe differs (an in-place edit, or another array at a recycled address) the full hash is
-    taken again; a read-only buffer (no writeable array anywhere in its base chain) is
-    trusted by identity alone.  An in-place edit of such a huge WRITEABLE array (`own`, the
-    Voigt table) that misses every probed element is not seen: call invalidate() after it."""
+    taken again.  The probe is taken for read-only buffers too (a freed
+    read-only table whose address the allocator hands to another read-only array of the same
+    shape -- large mmap'd blocks are recycled that way -- or setflags(write=True), an edit,
+    setflags(write=False) must be seen; identity alone cannot promise either).  An in-place edit
+    of such a huge array (`own`, the Voigt table) that misses every probed element is not seen:
+    call invalidate() after it."""
     a = np.asarray(a)
     if a.nbytes <= _SMALL_BYTES:
         return a.shape, _hash(_bytes(a))
-    frozen = _frozen(a)
-    ident = (a.__array_interface__['data'][0], a.shape, a.strides, a.dtype.str, frozen)
+    ident = (a.__array_interface__['data'][0], a.shape, a.strides, a.dtype.str, _frozen(a))
     ent = _seen.get(ident)
-    if frozen and ent is not None:
-        return a.shape, ent[0]
     probe = _probe(a)
     if ent is not None and ent[1] == probe:
         return a.shape, ent[0]

@@ -208,6 +208,43 @@ def test_eval_bands_column_order(eng, rt_path):
         eng.TableSpectrum(etable, ttable, wn, radius0, 8.8e10, column_order=np.zeros(W, int))
 
 
+@pytest.mark.parametrize('L,itop', [(150, 0), (129, 0), (150, 30), (2, 1)])
+def test_eval_bands_beyond_the_ordered_kernel(eng, orc, L, itop):
+    """Shapes the depth-ordered transit kernel does not take (more than 128 impact parameters, or
+    fewer than 2): the default column_order='auto' must fall through to the grid-order kernels
+    (it used to raise on the first eval_bands call), an explicit order likewise; (150, 30) has 120
+    impact parameters and does order.  Band fluxes against the oracle chain."""
+    import torch
+    from pyratbay_amd import synth
+    rng = np.random.default_rng(300 + L + itop)
+    nspec, ntemp, W, nw = 2, 5, 321, 5
+    g = synth.spectral_grid(4000.0, 4000.0 + (W - 1) * 0.05 + 0.01, 0.05, 12)
+    wn = g['wn']
+    ttable = np.linspace(300.0, 3000.0, ntemp)
+    press = np.logspace(-6, 2, L)
+    etable = 10.0**rng.uniform(-27, -21, (nspec, ntemp, L, 1)) * \
+        10.0**rng.uniform(-3, 3, (nspec, 1, 1, W))
+    radius0 = np.linspace(8.0e9, 7.0e9, L)
+    pb = eng.PassBands(wn, [(3, np.ones(300), 1.0)])
+    temps = 1500.0 * (1 + 0.1 * rng.uniform(-1, 1, (nw, 1))) * np.linspace(0.8, 1.2, L)
+    dens = (press / temps)[:, :, None] * 7.2e21 * 10.0**rng.uniform(-7, -3, (nw, 1, nspec))
+    out = {}
+    for name, order in (('grid', None), ('auto', 'auto'), ('given', rng.permutation(W))):
+        model = eng.TableSpectrum(etable, ttable, wn, radius0, 8.8e10, itop=itop,
+                                  column_order=order)
+        out[name] = model.eval_bands(eng.dev(temps), eng.dev(dens), pb).clone()
+        if name == 'auto':
+            assert (model.column_order is not None) == (2 <= L - itop <= 128)
+    assert torch.equal(out['auto'], out['grid']) and torch.equal(out['given'], out['grid'])
+    for w in (0, nw - 1):
+        ec = np.zeros((L, W))
+        orc.interp_ec(ec, etable, ttable, temps[w], dens[w], 0, L)
+        depth, ideep = orc.optical_depth_transit(ec, radius0, itop, L, 10.0)
+        spec = orc.transmission(depth, radius0, 8.8e10, ideep, itop)
+        want = np.trapezoid(spec[3:303], wn[3:303])
+        np.testing.assert_allclose(host(out['grid'][w])[0], want, rtol=1e-11)
+
+
 def test_fused_transit_equals_split(eng):
     """The fused column kernel against the two-kernel form it replaced (a separate process so
     that PB_TRANSIT=split is read afresh): same depth, ideep, spectrum bits."""

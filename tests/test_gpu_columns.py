@@ -283,3 +283,56 @@ def test_plane_parallel_depth_stop_rules(eng, orc, nlayers):
                 what = (nlayers, itop, ibottom, maxdepth)
                 assert np.array_equal(host(i), wi), what
                 assert np.array_equal(host(d), wd), what
+
+
+def test_special_values_in_the_short_divisions(eng, orc):
+    """pb::quot (x / d as product + exact residual + one correction) must behave like the
+    reference's C division for the special values it can meet: an infinite
+    optical depth gives exp(-inf / mu) = 0, not NaN; a layer at T = 0 radiates B = 0, not NaN.
+    The intensity of columns whose deepest layers are opaque to infinity, and the Planck function
+    of a zero-temperature layer, against the oracle (IEEE division, no -ffast-math)."""
+    import torch
+    c = cases.column_case(seed=17, nlayers=12, nwave=70)
+    L, W = c['nlayers'], c['nwave']
+    depth = np.cumsum(np.abs(c['ec']) * 1e9, axis=0)
+    depth[0] = 0.0
+    depth[8:, ::3] = np.inf                       # opaque to infinity below layer 8
+    depth[5:, 1::7] = np.inf
+    ideep = np.full(W, L - 1, np.int32)
+    temp = c['temp'].copy()
+    temp[3] = 0.0
+    B = host(eng.blackbody_wn_2D(eng.dev(c['wn']), eng.dev(temp)))
+    want_B = orc.blackbody_wn_2D(c['wn'], temp)
+    assert np.all(np.isfinite(B)) and np.all(B[3] == 0.0) and np.all(want_B[3] == 0.0)
+    np.testing.assert_allclose(B, want_B, rtol=RTOL)
+    want = orc.intensity(depth, ideep, want_B, c['mu'], 0)
+    assert np.all(np.isfinite(want))
+    got = host(eng.intensity(eng.dev(depth), eng.dev(ideep, torch.int32), eng.dev(want_B),
+                             eng.dev(c['mu']), 0))
+    np.testing.assert_allclose(got, want, rtol=1e-11, atol=1e-300)
+    weights = np.array([0.3, 0.25, 0.2, 0.15, 0.1])
+    flux = host(eng.emission_flux(eng.dev(depth), eng.dev(ideep, torch.int32), eng.dev(c['wn']),
+                                  eng.dev(temp), eng.dev(c['mu']), eng.dev(weights), 0))
+    np.testing.assert_allclose(flux, np.sum(want * weights[:, None], axis=0), rtol=1e-11)
+
+
+@pytest.mark.parametrize('n', [1, 5, 16])
+def test_emission_flux_gauss_quadrature(eng, orc, n):
+    """`quadrature = n` (pyrat/spectrum.py:41-49, 366-377): the emission flux over the
+    Gauss-Legendre angles of engine.gauss_quadrature against the oracle chain (plane-parallel
+    depth -> Planck -> intensity per mu -> weighted sum); n = 16 fills every running sum of the
+    kernel."""
+    c = cases.column_case(seed=23 + n, nlayers=30, nwave=333)
+    mu, weights = eng.gauss_quadrature(n)
+    h = -np.diff(c['radius'])
+    depth, ideep = eng.plane_parallel_optical_depth(eng.dev(c['ec']), eng.dev(h), 0,
+                                                    c['nlayers'], 10.0)
+    flux, inten = eng.emission_flux(depth, ideep, eng.dev(c['wn']), eng.dev(c['temp']),
+                                    eng.dev(mu), eng.dev(weights), 0, want_intensity=True)
+    wd = np.zeros_like(c['ec'])
+    wi = np.zeros(c['nwave'], np.int32)
+    orc.plane_parallel_optical_depth(wd, wi, c['ec'], h, 10.0, 0, c['nlayers'])
+    B = orc.blackbody_wn_2D(c['wn'], c['temp'])
+    want = orc.intensity(wd, wi, B, mu, 0)
+    np.testing.assert_allclose(host(inten), want, rtol=1e-11, atol=1e-300)
+    np.testing.assert_allclose(host(flux), np.sum(want * weights[:, None], axis=0), rtol=1e-11)

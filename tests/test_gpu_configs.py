@@ -320,3 +320,105 @@ def test_full_size_c5_batch(eng, orc):
         want = [np.trapezoid(spec[s:s + len(r)] * r, g['wn'][s:s + len(r)]) * h
                 for s, r, h in inp['bands']]
         np.testing.assert_allclose(got[w], want, rtol=RTOL)
+
+
+# ---------------------------------------------------------------------------
+# C3 as BASELINE.json states it: "1e6 wavenumbers x 80 layers, 1e6-line list, emission +
+# _blackbody path" -- the whole run() at full size; the RT half (plane_parallel_optical_depth ->
+# blackbody_wn_2D -> intensity -> quadrature sum: _trapezoid.c:175-213, 304-341,
+# _blackbody.c:35-75, pyrat/spectrum.py:366-377) against the oracle on EVERY column
+# ---------------------------------------------------------------------------
+def test_full_size_c3_emission(eng, orc):
+    import torch
+    from pyratbay_amd import synth
+    cfg = FULL['c3']
+    t0 = time.time()
+    case = synth.lbl_case(*cfg['args'], seed=42, **cfg['kw'])
+    g, atm = case['grid'], case['atm']
+    nl, nw = atm['nlayers'], g['nwave']
+    assert (nl, nw) == (80, 1000001)
+    model = eng.LBLSpectrum(case, rt_path='emission')
+    spectrum = model.run()
+    torch.cuda.synchronize()
+    t_gpu = time.time() - t0
+    again = model.run()
+    assert torch.equal(again, spectrum), 'two runs differ'
+    assert model.lbl.last_gather_kernel.endswith('k_ext_staged')
+    assert model.depth.shape == (nl, nw) and model.ideep.shape == (nw,)
+    ec = host(model.ec)[:, 0]
+    # extinction: oracle parity on one sampled layer (test_full_size_config[c3] covers more)
+    profile = model.voigt.flat()
+    layer = 44
+    want_row = oracle_rows(orc, case, model.voigt, profile, layer, True, case['ethresh'])
+    worst_ec = check(ec[layer:layer + 1], want_row, f'c3 emission ec layer {layer}')
+    del profile
+    # RT stages from the HIP ec, every column, on the host
+    t1 = time.time()
+    depth = np.zeros((nl, nw))
+    ideep = np.full(nw, nl - 1, np.int32)
+    orc.plane_parallel_optical_depth(depth, ideep, ec, -orc.ediff(atm['radius']),
+                                     case['maxdepth'], 0, nl)
+    B = orc.blackbody_wn_2D(g['wn'], atm['temp'])
+    mu, weights = host(model.mu), host(model.weights)
+    inten = orc.intensity(depth, ideep, B, mu, 0)
+    want = np.sum(inten * weights[:, None], axis=0)
+    t_orc = time.time() - t1
+    assert np.array_equal(host(model.ideep), ideep), 'ideep differs'
+    got_depth = host(model.depth)
+    np.testing.assert_allclose(got_depth, depth, rtol=1e-12, atol=0)
+    got = host(spectrum)
+    assert np.all(np.isfinite(got)) and np.all(got > 0)
+    np.testing.assert_allclose(got, want, rtol=RTOL)
+    # the columns stop at very different layers (line cores high up, windows at the bottom) and
+    # the last columns of the 8e7-element arrays are as right as the first (64-bit indexing)
+    assert ideep.min() < nl - 1 and ideep.max() == nl - 1
+    np.testing.assert_allclose(got[-1000:], want[-1000:], rtol=RTOL)
+    print(f'c3 emission: W={nw} L={nl}; set-up + first run {t_gpu:.1f} s; oracle RT on all '
+          f'columns {t_orc:.1f} s; ec layer {layer} {worst_ec:.1e}; spectrum max rel err '
+          f'{np.max(np.abs(got / want - 1)):.2e}; ideep {ideep.min()}..{ideep.max()} exact')
+
+
+def test_full_size_c5_emission_batch(eng, orc):
+    """C5's batch in emission geometry at full size (1e5 wavenumbers x 80 layers x 64 walkers,
+    `bench.py --workload c5-emission`): run-to-run bitwise equal, independent of the chunking
+    and of the column order, rejects, and sampled walkers against the oracle chain interp_ec ->
+    plane-parallel depth -> Planck -> intensity -> quadrature -> band trapezoids."""
+    import torch
+    from tools import bench_c5
+    inp = bench_c5.inputs()
+    g, atm = inp['grid'], inp['atm']
+    nl, nw = atm['nlayers'], g['nwave']
+    model = eng.TableSpectrum(inp['etable'], inp['ttable'], g['wn'], atm['radius'], atm['rstar'],
+                              rt_path='emission')
+    bands = eng.PassBands(g['wn'], inp['bands'])
+    temps, dens, radius = bench_c5.walkers(inp, 64, 700)
+    temps[9, 11] = 299.0                                 # below the table: rejected
+    td, dd, rd = eng.dev(temps), eng.dev(dens), eng.dev(radius)
+    flux = model.eval_bands(td, dd, bands, radius=rd, chunk=64)
+    assert model.column_order is not None                # (ordered by the first walker's depth)
+    again = model.eval_bands(td, dd, bands, radius=rd, chunk=64)
+    assert torch.equal(flux, again), 'two runs differ'
+    got = host(flux)
+    assert got.shape == (64, 24) and np.all(np.isinf(got[9])) and np.all(got[9] > 0)
+    ok = [w for w in range(64) if w != 9]
+    assert np.all(np.isfinite(got[ok]))
+    halves = torch.cat([model.eval_bands(td[a:b], dd[a:b], bands, radius=rd[a:b], chunk=32)
+                        for a, b in ((0, 32), (32, 64))])
+    assert torch.equal(halves[ok], flux[ok])
+    del model
+    torch.cuda.empty_cache()
+    grid = eng.TableSpectrum(inp['etable'], inp['ttable'], g['wn'], atm['radius'], atm['rstar'],
+                             rt_path='emission', column_order=None)
+    assert torch.equal(grid.eval_bands(td, dd, bands, radius=rd, chunk=64)[ok], flux[ok])
+    mu, weights = eng.default_quadrature()
+    for w in (2, 33, 63):
+        ec = np.zeros((nl, nw))
+        orc.interp_ec(ec, inp['etable'], inp['ttable'], temps[w], dens[w], 0, nl)
+        depth = np.zeros((nl, nw))
+        ideep = np.zeros(nw, np.int32)
+        orc.plane_parallel_optical_depth(depth, ideep, ec, -np.diff(radius[w]), 10.0, 0, nl)
+        inten = orc.intensity(depth, ideep, orc.blackbody_wn_2D(g['wn'], temps[w]), mu, 0)
+        spec = np.sum(inten * weights[:, None], axis=0)
+        want = [np.trapezoid(spec[s:s + len(r)] * r, g['wn'][s:s + len(r)]) * h
+                for s, r, h in inp['bands']]
+        np.testing.assert_allclose(got[w], want, rtol=RTOL)

@@ -267,7 +267,7 @@ def test_extinction_cache_sees_a_single_edited_line(hip):
     """with the default thresholds the line-list arrays are hashed in full on
     every call, so an in-place edit of ONE element that no strided probe would visit (here
     element 12 345 of gf, then two swapped lines) changes the result like in the reference,
-    which re-reads its inputs on every call.  A read-only huge buffer is trusted by identity."""
+    which re-reads its inputs on every call.  A read-only huge buffer is probed like a writeable one."""
     mod = hip._extcoeff
     mod.invalidate()
     case, profile, psize, pindex = _dropin_case()
@@ -285,19 +285,26 @@ def test_extinction_cache_sees_a_single_edited_line(hip):
     ln['elow'][[i, j]] = ln['elow'][[j, i]]
     swapped = _dropin_call(hip, case, profile, psize, pindex, 1)
     assert not np.array_equal(swapped, base)
-    # frozen buffers: identity is enough (no probe, no re-hash)
+    # read-only buffers are probed like any other: an unfreeze-edit-refreeze at
+    # the same address, or another read-only array at a recycled address, must change the key
     big = np.arange(5 << 20, dtype=float)                 # 40 MiB > 32 MiB
     big.setflags(write=False)
     view = big[:]
     assert mod._frozen(view) and not mod._frozen(np.arange(4.0)[:2])
     k1 = mod._content_key(view)
-    calls = []
-    real = mod._probe
+    calls, full = [], []
+    real, real_digest = mod._probe, mod._digest
     mod._probe = lambda a: (calls.append(1), real(a))[1]
+    mod._digest = lambda a: (full.append(1), real_digest(a))[1]
     try:
-        assert mod._content_key(view) == k1 and not calls
+        assert mod._content_key(view) == k1 and len(calls) == 1 and not full   # probe, no re-hash
+        big.setflags(write=True)
+        big *= 2.0                                        # (every element: the probe sees it)
+        big.setflags(write=False)
+        k2 = mod._content_key(big[:])
+        assert k2 != k1 and full
     finally:
-        mod._probe = real
+        mod._probe, mod._digest = real, real_digest
     mod.invalidate()
 
 

@@ -64,3 +64,26 @@ def test_synthetic_case_shapes():
         assert np.all(np.diff(v) >= 0)
     assert np.all(np.diff(ln['lid']) >= 0)
     assert np.all(np.diff(atm['radius']) < 0)      # top to bottom
+
+
+def test_gauss_quadrature_like_the_reference(golden):
+    """`quadrature = n` (pyrat/spectrum.py:41-49): engine.gauss_quadrature against fixture G18
+    (SciPy's p_roots and the mu / weights the reference derives, n = 1 ... 16) -- bit for bit
+    through the same SciPy call, and the SciPy-free Newton form within 1e-14 (mu: 3 ulp of a node near -1 are amplified by q = (x + 1) / 2) /
+    2e-13 (weights: SciPy's own are that far from the correctly rounded ones).  The weights of
+    every order integrate the hemisphere: sum = pi / 2 * 2 = pi."""
+    import importlib
+    import pytest
+    engine = importlib.import_module('pyratbay_amd.engine')
+    g = golden('g18_p_roots')
+    for n in range(1, 17):
+        mu, w = engine.gauss_quadrature(n)
+        assert np.array_equal(mu, g[f'mu_{n}']) and np.array_equal(w, g[f'weights_{n}']), n
+        mu2, w2 = engine.gauss_quadrature(n, use_scipy=False)
+        np.testing.assert_allclose(mu2, g[f"mu_{n}"], rtol=1e-14)
+        np.testing.assert_allclose(w2, g[f'weights_{n}'], rtol=2e-13)
+        np.testing.assert_allclose(np.sum(w2), np.pi, rtol=1e-15)
+        assert np.all(np.diff(mu) > 0) and 0 < mu[0] and mu[-1] < 1
+    for bad in (0, 17):
+        with pytest.raises(ValueError):
+            engine.gauss_quadrature(bad)

@@ -201,13 +201,15 @@ def main(args):
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
-    t0 = time.perf_counter()
-    for i in range(steps):
-        out = step(i)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
+    from tools.gpu_state import Sampler
+    with Sampler() as state:
+        t0 = time.perf_counter()
+        for i in range(steps):
+            out = step(i)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        elapsed = time.perf_counter() - t0
     if world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64, device='cpu' if rehearse else 'cuda')
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -358,7 +360,8 @@ def main(args):
                        'column_order': ('depth order of the first walker (TableSpectrum.'
                                         'order_columns): spectra do not depend on it'
                                         if ordered else 'grid order'),
-                       'rt_kernel_ms_grid_order': grid_order_ms},
+                       'rt_kernel_ms_grid_order': grid_order_ms,
+                       'gpu_state': state.summary()},
             'roofline': {'bound': 'hbm', 'kernel': dom['kernel'], 'achieved': dom['achieved'],
                          'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': dom['frac'],
                          'traffic': traffic, 'kernel_ms': dom['kernel_ms'],
