@@ -78,7 +78,7 @@ NORTH_STAR = 'c2-1e6'     # north_star's >= 50x target configuration
 # GPU-only legs of the default run: (workload, timed steps, warm-up steps) -- every other BASELINE
 # configuration in its single-GPU form + the two other grid / list structures, so that the
 # driver's one `python bench.py` times them all
-LEGS = (('c3', 5, 2), ('c4', 3, 1), ('c5', 40, 3), ('c5-emission', 24, 3), ('c2-res', 30, 3),
+LEGS = (('c3', 10, 2), ('c4', 5, 1), ('c5', 157, 4), ('c5-emission', 157, 4), ('c2-res', 50, 4),
         ('c2-bands', 50, 4))
 LEG_TIMEOUT_S = 150.0
 

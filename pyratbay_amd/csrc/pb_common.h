@@ -103,15 +103,16 @@ __host__ __device__ inline int64_t ceil_div(int64_t a, int64_t b)
 // refinement (3 instructions instead of ~12).  Claim: within 1 ulp of x / d for d, x / d and the
 // residual in the normal range (no proof of correct rounding: Markstein's theorem wants a faithful
 // q, which RN(x RN(1/d)) is not guaranteed to be); measured: the same bits as x / d on every one of
-// 4e9 random (x, d) pairs of tools/quot_probe.hip, drawn over the ranges the callers use
+// 6.9e10 random (x, d) pairs of tools/quot_probe.hip, drawn over the ranges the callers use
 // (temperatures, mu, kT; numerators over 600 binades).  Special values: x = +-inf, d = 0 and
 // d = +-inf make the short form NaN where the division is +-inf or 0 (exp(-inf / mu) must be 0,
-// B(T = 0) must be 0 like in the reference); a NaN result therefore takes the true division.
+// B(T = 0) must be 0 like in the reference), and x = -0 gives +0; a result that is NaN or zero
+// (one compare: also a quotient that underflowed) therefore takes the true division.
 __device__ __forceinline__ double quot(double x, double d, double inv)
 {
     const double q = x * inv;
     const double r = fma(fma(-q, d, x), inv, q);
-    if (__builtin_expect(r != r, 0))
+    if (__builtin_expect(!(fabs(r) > 0.0), 0))
         return x / d;
     return r;
 }

@@ -913,7 +913,8 @@ class LBLSpectrum:
         self.itop = itop
         self.maxdepth = case['maxdepth']
         # (resolution mode reads the reference layout only: keep_flat = 2 keeps no second copy)
-        if g.get('resolution') is not None and not keep_flat:
+        interpolate = g.get('resolution') is not None or bool(g.get('interpolate'))
+        if interpolate and not keep_flat:
             keep_flat = 2
         self.voigt = voigt or VoigtTable.build(vg['lorentz'], vg['doppler'], vg['size'],
                                                g['ownstep'], g['wnosamp'], keep_flat)
@@ -921,7 +922,7 @@ class LBLSpectrum:
                                        len(iso['isomass']), g['own'])
         # a constant-resolving-power (or constant-wavelength-step) output grid: the kept samples
         # are interpolated from the dynamic grid (_extcoeff.c:320-326) and ACCUMULATED into ec
-        self.resolution = g.get('resolution') is not None
+        self.resolution = interpolate
         self.lbl = LBL(self.voigt, self.lines, g['wn'], g['divisors'], atm['mol_radius'],
                        atm['mol_mass'], iso['isoimol'], iso['isomass'], iso['isoratio'],
                        iso['isoiext'], vg['cutoff'], case['ethresh'],
@@ -977,7 +978,7 @@ class LBLSpectrum:
     @classmethod
     def from_tli(cls, tlifiles, atm, grid, *, nlor=100, ndop=50, extent=300.0, cutoff=25.0,
                  dlratio=0.1, lorentz=None, doppler=None, tmin=100.0, tmax=3000.0,
-                 ethresh=1e-30, maxdepth=10.0, skip_species=(), **kw):
+                 ethresh=1e-30, maxdepth=10.0, skip_species=(), iso_numbering='file', **kw):
         """TLI file(s) + atmosphere + spectral grid -> a model ready to run(): what
         Line_By_Line.__init__ / Voigt.__init__ assemble before the reference's first extinction
         call (pyratbay/pyrat/line_by_line.py:120-200, pyrat/voigt.py:20-149), with nothing taken
@@ -986,20 +987,39 @@ class LBLSpectrum:
         name, Z_i(T_layer) by tli's restatement of the reference's interp1d, Voigt width grids
         from the atmosphere (or given: the reference's voigt_dmin/dmax/lmin/lmax keys).
 
+        iso_numbering: how the lines of a file with SEVERAL databases find their isotope.  The
+        file stores each line's isotope index relative to its own database (lread.py:181-209,
+        309).  'file' (default): numbered over the file's databases, i.e. every line gets its own
+        isotope.  'reference': as Line_By_Line does (line_by_line.py:114-119: the stored index +
+        the isotope count of the previous FILES) -- in a multi-database file the lines of the
+        second database then use the first database's isotope data; kept to reproduce a
+        reference run on such a file bit for bit (fixture G16, run `onefile`).  One database per
+        file, the layout of the reference's own configurations, is the same either way.
+
         atm: dict with temp[L], dens[L, nspecies] (cm-3), radius[L], press[L] (bar; for the width
         grids), species (names), mol_mass, mol_radius (cm), rstar.  grid: synth.spectral_grid /
-        resolution_grid (wn, own, ownstep, onwave, wnosamp, divisors)."""
+        resolution_grid / wlstep_grid (wn, own, ownstep, onwave, wnosamp, divisors, wnlow,
+        wnhigh)."""
         from . import synth, tli
         paths = [tlifiles] if isinstance(tlifiles, (str, bytes, os.PathLike)) else list(tlifiles)
         species = list(atm['species'])
         dbs, lwn, gf, elow, lid = [], [], [], [], []
         niso = 0
+        # the reference selects the lines of [spec.wnlow, spec.wnhigh] (pyrat/opacity.py:46-47,
+        # 105): the CONFIGURED boundaries -- wnhigh can lie up to one step above wn[-1], and a line
+        # in between still throws its wing onto the grid
+        wn_lo = float(grid.get('wnlow', grid['wn'][0]))
+        wn_hi = float(grid.get('wnhigh', grid['wn'][-1]))
         for path in paths:
-            d, wn_, gf_, el_, _, meta = tli.read_tli(path, float(grid['wn'][0]),
-                                                      float(grid['wn'][-1]))
+            d, wn_, gf_, el_, stored, meta = tli.read_tli(path, wn_lo, wn_hi)
             dbs += d
             lwn.append(wn_); gf.append(gf_); elow.append(el_)
-            lid.append(meta['iso_global'].astype(np.int32) + niso)
+            if iso_numbering == 'reference':
+                lid.append(stored.astype(np.int32) + niso)
+            elif iso_numbering == 'file':
+                lid.append(meta['iso_global'].astype(np.int32) + niso)
+            else:
+                raise ValueError("iso_numbering: 'file' or 'reference'")
             niso += sum(len(db['isotopes']) for db in d)
         isoimol, isomass, isoratio = [], [], []
         for db in dbs:

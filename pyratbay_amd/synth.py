@@ -48,7 +48,9 @@ def divisors(number):
 
 
 def spectral_grid(wnlow, wnhigh, wnstep, wnosamp=None):
-    """Constant-step output grid wn and fine grid own (spectrum.py:182-228)."""
+    """Constant-step output grid wn and fine grid own (spectrum.py:182-228).  wnlow / wnhigh are
+    kept in the result: the reference selects the lines of [spec.wnlow, spec.wnhigh]
+    (pyrat/opacity.py:46-47, 105), and wnhigh is the configured boundary, not wn[-1]."""
     if wnosamp is None:
         wnosamp = int(HCN[wnstep / HCN <= 0.0004][0])
     nwave = int((wnhigh - wnlow) / wnstep) + 1
@@ -57,7 +59,8 @@ def spectral_grid(wnlow, wnhigh, wnstep, wnosamp=None):
     onwave = int(np.ceil((wn[-1] - wnlow) / ownstep)) + 1
     own = wnlow + np.arange(onwave) * ownstep
     return dict(wn=wn, own=own, wnstep=wnstep, ownstep=ownstep, nwave=nwave,
-                onwave=onwave, wnosamp=int(wnosamp), divisors=divisors(wnosamp))
+                onwave=onwave, wnosamp=int(wnosamp), divisors=divisors(wnosamp),
+                wnlow=float(wnlow), wnhigh=float(wnhigh))
 
 
 def resolution_grid(wnlow, wnhigh, resolution, wnstep=1.0, wnosamp=None):
@@ -74,7 +77,27 @@ def resolution_grid(wnlow, wnhigh, resolution, wnstep=1.0, wnosamp=None):
     onwave = int(np.ceil((wn[-1] - wnlow) / ownstep)) + 1
     own = wnlow + np.arange(onwave) * ownstep
     return dict(wn=wn, own=own, wnstep=wnstep, ownstep=ownstep, nwave=nwave, onwave=onwave,
-                wnosamp=int(wnosamp), divisors=divisors(wnosamp), resolution=float(resolution))
+                wnosamp=int(wnosamp), divisors=divisors(wnosamp), resolution=float(resolution),
+                wnlow=float(wnlow), wnhigh=float(wnhigh))
+
+
+def wlstep_grid(wl_low, wl_high, wlstep, wnstep=1.0, wnosamp=None):
+    """Constant-wavelength-step output grid (the reference's `wlstep` mode, spectrum.py:205-210:
+    wl = arange(wl_low, wl_high, wlstep), wn = 1 / flip(wl), wnlow = wn[0]; all three in cm) over
+    the constant-step fine grid of step wnstep / wnosamp, like resolution_grid.  The extinction
+    is interpolated onto it from the layers' dynamic grids exactly as in `resolution` mode
+    (extinction.py:163: interpolate = resolution is not None or wlstep is not None)."""
+    if wnosamp is None:
+        wnosamp = int(HCN[wnstep / HCN <= 0.0004][0])
+    wl = np.arange(wl_low, wl_high, wlstep)
+    wn = 1.0 / np.flip(wl)
+    wnlow = wn[0]
+    ownstep = wnstep / wnosamp
+    onwave = int(np.ceil((wn[-1] - wnlow) / ownstep)) + 1
+    own = wnlow + np.arange(onwave) * ownstep
+    return dict(wn=wn, own=own, wnstep=wnstep, ownstep=ownstep, nwave=len(wn), onwave=onwave,
+                wnosamp=int(wnosamp), divisors=divisors(wnosamp), wlstep=float(wlstep),
+                interpolate=True, wnlow=float(wnlow), wnhigh=1.0 / wl_low)
 
 
 def voigt_widths(wn, press_bar, masses, radii_cm, nlor, ndop, tmin=100.0, tmax=3000.0):

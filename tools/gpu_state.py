@@ -64,12 +64,33 @@ def sample(card):
     return s
 
 
-class Sampler:
-    """with Sampler() as st: <timed region>;  st.summary() -> dict or None."""
+def current_pci():
+    """'dddd:bb:dd' of torch's current HIP device (None when torch cannot say): the sysfs card
+    whose PCI address starts with it is the one this process runs on."""
+    try:
+        import torch
+        p = torch.cuda.get_device_properties(torch.cuda.current_device())
+        return f'{p.pci_domain_id:04x}:{p.pci_bus_id:02x}:{p.pci_device_id:02x}'
+    except Exception:                                            # noqa: BLE001
+        return None
 
-    def __init__(self, period=0.05):
+
+class Sampler:
+    """with Sampler() as st: <timed region>;  st.summary() -> dict or None.  pci: PCI address
+    prefix of the card to report (default: torch's current device when it can be identified in
+    sysfs, else every card, the one drawing most power first)."""
+
+    def __init__(self, period=0.05, pci='auto'):
         self.period = period
         self.cards = cards()
+        self.pci = current_pci() if pci == 'auto' else pci
+        if self.pci:
+            mine = [c for c in self.cards
+                    if os.path.basename(os.path.realpath(c[0])).startswith(self.pci)]
+            if mine:
+                self.cards = mine
+            else:
+                self.pci = None
         self.rows = [[] for _ in self.cards]
         self._stop = threading.Event()
         self._thread = None
@@ -108,8 +129,8 @@ class Sampler:
         if not out:
             return None
         out.sort(key=lambda c: -((c['power_w'] or {}).get('mean') or 0.0))
-        return {'source': 'sysfs (amdgpu pp_dpm_*, hwmon)', 'cards': out[:2],
-                'cards_seen': len(out)}
+        return {'source': 'sysfs (amdgpu pp_dpm_*, hwmon)', 'pci': self.pci, 'cards': out[:2],
+                'identified': bool(self.pci)}
 
 
 if __name__ == '__main__':
