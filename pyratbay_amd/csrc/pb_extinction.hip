@@ -2388,6 +2388,16 @@ int pb_lines_create(pb_lines **out, const double *lwn_h, const double *elow_h,
     };
     std::vector<Group> groups;
     groups.reserve((size_t)nlines);
+    // The lines of ONE isotope must come in ascending wavenumber order (isotopes may interleave).
+    // The reference's Doppler-width index is a one-way search from the isotope's previous line
+    // (_extcoeff.c:278, utils.h:45-72: `if (value < array[lo]) return lo`): on a list that steps
+    // back within an isotope it keeps a stale index, a result that depends on the list order and
+    // on which lines the layer's threshold skipped.  The kernels evaluate the nearest index
+    // statelessly -- the same thing on an ordered list, NOT on such a one: refuse it loudly.
+    // (Every TLI reader output is ordered; the reference itself produces an unordered list only
+    // from a TLI FILE holding several databases, whose isotope ids it confuses:
+    // line_by_line.py:114-119, fixture G16 `onefile`.)
+    std::vector<double> last_wn((size_t)niso, -HUGE_VAL);
     for (int64_t ln = 0; ln < nlines; ln++) {
         const int i = lid_h[ln];
         if (i < 0 || i >= niso) {
@@ -2399,6 +2409,16 @@ int pb_lines_create(pb_lines **out, const double *lwn_h, const double *elow_h,
         const double v = lwn_h[ln];
         if (v < lo || v > hi)
             continue;
+        if (v < last_wn[(size_t)i]) {
+            pb::set_error("pb_lines_create: line %lld (%.6f cm-1) of isotope %d comes after a "
+                          "line at %.6f cm-1: the lines of an isotope must be in ascending "
+                          "wavenumber order (the reference's Doppler-index search is one-way, "
+                          "_extcoeff.c:278; its result on such a list is order-dependent)",
+                          (long long)ln, v, i, last_wn[(size_t)i]);
+            pb_lines_destroy(l);
+            return PB_ERR_ARG;
+        }
+        last_wn[(size_t)i] = v;
         l->ninrange++;
         // nearest fine-grid index (_extcoeff.c:243-245)
         int64_t iown = (int64_t)((v - lo) / step);
@@ -2410,6 +2430,7 @@ int pb_lines_create(pb_lines **out, const double *lwn_h, const double *elow_h,
         while (ln + 1 != nlines && lid_h[ln + 1] == i && lwn_h[ln + 1] <= hi) {
             if (fabs(lwn_h[ln + 1] - centre) < step) {
                 ln++;
+                last_wn[(size_t)i] = std::max(last_wn[(size_t)i], lwn_h[ln]);
                 g.count++;
                 l->nadd++;
                 l->ninrange++;

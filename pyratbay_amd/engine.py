@@ -992,9 +992,11 @@ class LBLSpectrum:
         309).  'file' (default): numbered over the file's databases, i.e. every line gets its own
         isotope.  'reference': as Line_By_Line does (line_by_line.py:114-119: the stored index +
         the isotope count of the previous FILES) -- in a multi-database file the lines of the
-        second database then use the first database's isotope data; kept to reproduce a
-        reference run on such a file bit for bit (fixture G16, run `onefile`).  One database per
-        file, the layout of the reference's own configurations, is the same either way.
+        second database then use the first database's isotope data, and the list steps back in
+        wavenumber within an isotope id, which pb_lines_create refuses (the reference's result
+        on such a list depends on its one-way Doppler-index search; fixture G16, run `onefile`,
+        pins it against the oracle only).  One database per file, the layout of the reference's
+        own configurations, is the same either way.
 
         atm: dict with temp[L], dens[L, nspecies] (cm-3), radius[L], press[L] (bar; for the width
         grids), species (names), mol_mass, mol_radius (cm), rstar.  grid: synth.spectral_grid /

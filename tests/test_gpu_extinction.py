@@ -490,12 +490,48 @@ def test_device_grouping_equals_reference_pass(eng, monkeypatch, kind):
         assert dev_ll.nadd > 10000 and np.max(want[1]) >= 4
 
 
-def test_unsorted_lines_fall_back_to_host_grouping(eng):
+def test_unsorted_lines_fall_back_to_host_grouping(eng, orc):
+    """Isotopes may interleave in the list as long as each isotope's own lines ascend (the host
+    loop groups them; the result equals the oracle's sequential pass).  A list that steps BACK
+    within an isotope is refused: the reference's Doppler-index search is one-way
+    (_extcoeff.c:278, utils.h:45-72), its result on such a list depends on the order, and the
+    kernels evaluate the nearest index statelessly."""
+    from pyratbay_amd import _capi, synth
+    case = synth.lbl_case(3001, 4, 3000, wnosamp=24, nlor=14, ndop=7, extent=60.0, cutoff=3.0,
+                          niso=2, seed=13)
+    g, atm, ln, iso, vg = (case[k] for k in ('grid', 'atm', 'lines', 'iso', 'voigt'))
+    # interleave the two isotopes: ascending wavenumber overall
+    o = np.argsort(ln['lwn'], kind='stable')
+    mixed = {k: np.ascontiguousarray(ln[k][o]) for k in ('lwn', 'elow', 'gf', 'lid')}
+    assert np.any(np.diff(mixed['lid']) < 0)
+    vt = eng.VoigtTable.build(vg['lorentz'], vg['doppler'], vg['size'], g['ownstep'],
+                              g['wnosamp'])
+    ll = eng.LineList(mixed['lwn'], mixed['elow'], mixed['gf'], mixed['lid'], 2, g['own'])
+    assert not ll.grouped_on_device
+    lbl = eng.LBL(vt, ll, g['wn'], g['divisors'], atm['mol_radius'], atm['mol_mass'],
+                  iso['isoimol'], iso['isomass'], iso['isoratio'], iso['isoiext'], vg['cutoff'],
+                  case['ethresh'], max_layers=4)
+    ext = host(lbl.extinction(eng.dev(atm['temp']), eng.dev(atm['dens']), eng.dev(iso['isoz'])))
+    profile = vt.flat()
+    for layer in range(4):
+        want = np.zeros((1, g['nwave']))
+        orc.extinction(want, profile, vt.size, vt.index, vg['lorentz'], vg['doppler'], g['wn'],
+                       g['own'], g['divisors'], atm['dens'][layer], atm['mol_radius'],
+                       atm['mol_mass'], iso['isoimol'], iso['isomass'], iso['isoratio'],
+                       iso['isoz'][:, layer].copy(), iso['isoiext'], mixed['lwn'], mixed['elow'],
+                       mixed['gf'], mixed['lid'], vg['cutoff'], case['ethresh'],
+                       atm['temp'][layer], 0, 1, 0)
+        assert np.array_equal(ext[layer] == 0, want == 0)
+        np.testing.assert_allclose(ext[layer], want, rtol=RTOL)
     rng = np.random.default_rng(3)
     own = 5000.0 + np.arange(20001) * 0.005
-    lwn = rng.uniform(5000, 5100, 500)                    # not sorted
-    ll = eng.LineList(lwn, np.ones(500), np.ones(500), np.zeros(500, np.int32), 1, own)
-    assert not ll.grouped_on_device and ll.ninrange == 500
+    lwn = rng.uniform(5000, 5100, 500)                    # one isotope, not sorted
+    with pytest.raises(_capi.PbError, match='ascending wavenumber order'):
+        eng.LineList(lwn, np.ones(500), np.ones(500), np.zeros(500, np.int32), 1, own)
+    # (lines outside the fine grid are never evaluated: their order does not matter)
+    lwn = np.concatenate([[6000.0, 4000.0], np.sort(lwn)])
+    ll = eng.LineList(lwn, np.ones(502), np.ones(502), np.zeros(502, np.int32), 1, own)
+    assert ll.ninrange == 500
 
 
 @pytest.mark.parametrize('gather', ['staged', 'global', 'rounds'])

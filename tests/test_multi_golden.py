@@ -170,7 +170,35 @@ GATHERS = {'wnstep': ('auto', 'staged', 'global'), 'resolution': ('dynamic', 'au
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('name', RUNS)
+def test_one_file_with_several_databases(g16):
+    """The `onefile` run: ONE TLI file holding the three databases.  The reference indexes its
+    isotope tables with the database-local ids the file stores (line_by_line.py:114-119), so the
+    CO2 and CH4 lines are computed with H2O's isotope data AND the list it walks steps back in
+    wavenumber within an isotope id -- where its one-way Doppler-index search keeps stale indices
+    (the oracle reproduces that run, test_oracle_reproduces_multi_runs[onefile_transit]).  The
+    HIP path refuses such a list loudly instead of computing something else
+    (iso_numbering='reference'); with its default numbering -- every line its own isotope -- the
+    one-file model equals the three-file model bit for bit."""
+    from pyratbay_amd import _capi, engine
+    engine.require_gpu()
+    r = Run(g16, 'onefile_transit')
+    grid = r.grid()
+    kw = dict(ethresh=float(r['ethresh']), maxdepth=float(r['maxdepth']), itop=int(r['rtop']),
+              extent=float(r['extent']), cutoff=float(r['cutoff']), dlratio=float(r['dlratio']),
+              lorentz=r['lorentz'], doppler=r['doppler'])
+    with pytest.raises(_capi.PbError, match='ascending wavenumber order'):
+        engine.LBLSpectrum.from_tli(ONEFILE, r.atm(), grid, iso_numbering='reference', **kw)
+    one = engine.LBLSpectrum.from_tli(ONEFILE, r.atm(), grid, **kw)
+    three = engine.LBLSpectrum.from_tli(THREE, r.atm(), grid, **kw)
+    assert np.array_equal(one.case['lines']['lid'], three.case['lines']['lid'])
+    s1, s3 = one.run().cpu().numpy(), three.run().cpu().numpy()
+    assert np.array_equal(s1, s3) and np.array_equal(one.ec.cpu().numpy(), three.ec.cpu().numpy())
+    # ... which is NOT what the reference computed from the one file (up to 25 % in ec)
+    assert np.max(np.abs(one.ec.view(*r['ec'].shape).cpu().numpy() - r['ec'])) > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('name', [n for n in RUNS if not n.startswith('onefile')])
 def test_hip_reproduces_multi_runs_from_the_tli_file(g16, name):
     from pyratbay_amd import engine
     engine.require_gpu()
@@ -181,9 +209,7 @@ def test_hip_reproduces_multi_runs_from_the_tli_file(g16, name):
     if rt == 'emission':
         mu, w = engine.gauss_quadrature(int(r['quadrature']))
         kw = dict(quadrature_mu=mu, quadrature_weights=w)
-    numbering = 'reference' if name.startswith('onefile') else 'file'
     m = engine.LBLSpectrum.from_tli(tli_files(name), r.atm(), grid, ethresh=float(r['ethresh']),
-                                    iso_numbering=numbering,
                                     maxdepth=float(r['maxdepth']), rt_path=rt,
                                     itop=int(r['rtop']), extent=float(r['extent']),
                                     cutoff=float(r['cutoff']), dlratio=float(r['dlratio']),
