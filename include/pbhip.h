@@ -143,11 +143,8 @@ int pb_lbl_set_ethresh(pb_lbl *p, double ethresh);
  *       share a phase row of a tile, else the global gather;
  *   1 = global gather only, 2 = LDS-staged only (falls back to 1 when a phase row does not
  *       fit in LDS), 3 = resident-profile kernel where it applies + global gather,
- *   7 = the LDS-staged kernel + the wave-autonomous kernel (pb_wave.hip) for the layers whose
- *       phase rows are at most 384 samples long (the Doppler-core layers of an atmosphere):
- *       wavefronts split a tile's phase rows between them instead of its samples, no workgroup
- *       barrier per row.  Opt-in: at BASELINE config 2 the pair is slower than the staged kernel
- *       alone (1.20 against 1.05 ms per extinction, profiles/r04_gather_wave.md).
+ *   4, 5, 7 = measured dead ends (scatter, rounds, wave: see "Experiments" at the end of this
+ *       header): refused by libpbhip.so, selectable in libpbhip_exp.so.
  * All sum the same terms; only the order differs (global, resident: isotope, position;
  * staged: isotope, phase, position).  In mode 0 the choice depends on the size of the launch
  * (layers x samples); with a fixed mode every tiling and sharding adds the same terms in the
@@ -166,7 +163,7 @@ int pb_lbl_set_ethresh(pb_lbl *p, double ethresh);
  * Two-phase shard calls of such a plan use the direct gather.
  * last_gather_mode reports what the last call ran: 1 global, 2 staged, 3 resolution mode (direct
  * gather), 6 resolution mode through dynamic grids, plus 8 when the resident-profile kernel ran
- * as well, plus 16 when the wave-autonomous kernel took the short-row layers. */
+ * as well. */
 int pb_lbl_set_gather_mode(pb_lbl *p, int mode);
 int pb_lbl_last_gather_mode(const pb_lbl *p, int *mode);
 /* Hint: the caller keeps n independent calls in flight on n streams (the reference's callers
@@ -203,23 +200,6 @@ int pb_lbl_last_state(pb_lbl *p, int32_t *ofactor_h, double *kmax_h, int nlayers
  * profile block each layer can select (block_h[nlayers]).  Synchronises the stream. */
 int pb_lbl_last_layer_kinds(pb_lbl *p, int32_t *resident_h, int32_t *block_h, int nlayers,
                             void *stream);
-/* Which layers of the last call the wave-autonomous kernel computed (wave_h[nlayers], 0/1: the
- * layers whose longest phase row is at most 384 samples; all 0 when that kernel was off).
- * Synchronises the stream. */
-int pb_lbl_last_wave_layers(pb_lbl *p, int32_t *wave_h, int nlayers, void *stream);
-/* `resolution` plans in gather mode 6 (per-layer dynamic grids, _extcoeff.c:185-195, 320-326): the
- * run plan of a call -- which layers share an oversampling factor, which Lorentz rows of the re-cut
- * tables they read -- needs the layers' factors on the host: one stream synchronisation per call.
- * pb_lbl_set_dyn_predict(plan, 1) removes it: from the second call on the plan is taken from the
- * last read-back (asynchronous), a device check marks the layers it fits and the direct gather
- * computes the others, so the result is right whatever the prediction (to the direct gather's
- * 1e-12 of the dynamic grids; bit for bit while the prediction fits, i.e. always for a steady
- * atmosphere), and such calls can be captured into a HIP graph.  A read-back that contradicts its
- * prediction makes the next 8 calls synchronous.  Default off (PB_RES_DYN_PREDICT=1: on).
- * stats = {calls planned from a prediction, synchronous calls, read-backs that contradicted their
- * prediction}. */
-int pb_lbl_set_dyn_predict(pb_lbl *p, int on);
-int pb_lbl_dyn_stats(pb_lbl *p, int64_t stats[3]);
 /* The same call in two halves, for wavenumber shards on several GPUs.  _begin derives the layer
  * state and the records of the groups within reach of the shard, with the per-row maxima
  * (_extcoeff.c:203-226) over THOSE groups only -- 1/N of the exp() work; the caller then
@@ -490,25 +470,6 @@ int pb_transit_spectrum_ordered(double *spectrum_d, const double *ec_d, const do
                                 const double *radius_d, const int32_t *column_d, double rstar,
                                 int itop, int ibottom, double maxdepth, int nlayers, int nwave,
                                 int nwalkers, void *work_d, void *stream);
-/* interp_ec + optical depth + transmission of a batch in ONE pass (the retrieval inner loop,
- * pyrat_obj.py:225-385: opacity/line_sampling.py:394-463 -> _extcoeff.c:367-418, then
- * opacity/optic_depth.py:103-112 and spectrum/radiative_transfer.py:57-71, no cloud deck):
- * etable_d[nmol,ntemp,nlayers,nwave], temps_d[nwalkers,nlayers], density_d[nwalkers,nlayers,nmol],
- * raypath_d[nwalkers, n(n-1)/2], radius_d[nwalkers,nlayers] -> spectrum_d[nwalkers,nwave].
- * The interpolated extinction is formed in registers as the operand of the FP64 matrix products
- * and never stored.  From two walkers on, neighbours in an order of the walkers by their table
- * brackets share a wavefront and one set of table loads (decided on the device; a batch whose
- * pairs bracket different temperatures in more than a fifth of the layers runs one walker per
- * wavefront).  pb_table_transit_supported(...) != 0 says whether the shape has this form
- * (2..128 impact parameters, nwave >= 2, one species' block of the table below 4 GiB); work_d: pb_table_transit_work_doubles(...) doubles. */
-int pb_table_transit_supported(int nmol, int ntemp, int nlayers, int itop, int ibottom,
-                               int nwave);
-int64_t pb_table_transit_work_doubles(int nmol, int nlayers, int itop, int ibottom, int nwalkers);
-int pb_table_transit_batch(double *spectrum_d, const double *etable_d, const double *ttable_d,
-                           const double *temps_d, const double *density_d,
-                           const double *raypath_d, const double *radius_d, double rstar,
-                           int itop, int ibottom, double maxdepth, int nmol, int ntemp,
-                           int nlayers, int nwave, int nwalkers, void *work_d, void *stream);
 /* Emission geometry for a batch: plane_parallel_optical_depth (src_c/_trapezoid.c:175-213) +
  * blackbody + intensity + quadrature sum (pyrat/spectrum.py:366-377) in one pass, no cloud deck:
  * ec_d[nwalkers,nlayers,nwave], intervals_d[nwalkers,nlayers-1], temp_d[nwalkers,nlayers] ->
@@ -538,6 +499,53 @@ int pb_band_integrate_batch(double *bandflux_d, const double *spectrum_d, const 
  * [tmin, tmax] get bandflux = +inf. */
 int pb_reject_walkers(double *bandflux_d, const double *temps_d, double tmin, double tmax,
                       int nlayers, int nbands, int nwalkers, void *stream);
+
+/* =========================================================================
+ * Experiments -- NOT in libpbhip.so.  `make -C pyratbay_amd/csrc EXPERIMENTS=1` builds
+ * libpbhip_exp.so (compiled with -DPB_EXPERIMENTS) = the product library + the variants that were
+ * built, verified and measured SLOWER than the default path (profiles/notes_r0*.md): gather modes
+ * 4 (scatter), 5 (rounds), 7 (wave) of pb_lbl_set_gather_mode, the layers-outer and the one-pass
+ * matrix transit kernels, the LDS-tile transit kernel, predicted run plans of the `resolution`
+ * mode.  Their entry points:
+ * ========================================================================= */
+#ifdef PB_EXPERIMENTS
+/* Which layers of the last call the wave-autonomous kernel computed (wave_h[nlayers], 0/1: the
+ * layers whose longest phase row is at most 384 samples; all 0 when that kernel was off).
+ * Synchronises the stream. */
+int pb_lbl_last_wave_layers(pb_lbl *p, int32_t *wave_h, int nlayers, void *stream);
+/* `resolution` plans in gather mode 6 (per-layer dynamic grids, _extcoeff.c:185-195, 320-326): the
+ * run plan of a call -- which layers share an oversampling factor, which Lorentz rows of the re-cut
+ * tables they read -- needs the layers' factors on the host: one stream synchronisation per call.
+ * pb_lbl_set_dyn_predict(plan, 1) removes it: from the second call on the plan is taken from the
+ * last read-back (asynchronous), a device check marks the layers it fits and the direct gather
+ * computes the others, so the result is right whatever the prediction (to the direct gather's
+ * 1e-12 of the dynamic grids; bit for bit while the prediction fits, i.e. always for a steady
+ * atmosphere), and such calls can be captured into a HIP graph.  A read-back that contradicts its
+ * prediction makes the next 8 calls synchronous.  Default off (PB_RES_DYN_PREDICT=1: on).
+ * stats = {calls planned from a prediction, synchronous calls, read-backs that contradicted their
+ * prediction}. */
+int pb_lbl_set_dyn_predict(pb_lbl *p, int on);
+int pb_lbl_dyn_stats(pb_lbl *p, int64_t stats[3]);
+/* interp_ec + optical depth + transmission of a batch in ONE pass (the retrieval inner loop,
+ * pyrat_obj.py:225-385: opacity/line_sampling.py:394-463 -> _extcoeff.c:367-418, then
+ * opacity/optic_depth.py:103-112 and spectrum/radiative_transfer.py:57-71, no cloud deck):
+ * etable_d[nmol,ntemp,nlayers,nwave], temps_d[nwalkers,nlayers], density_d[nwalkers,nlayers,nmol],
+ * raypath_d[nwalkers, n(n-1)/2], radius_d[nwalkers,nlayers] -> spectrum_d[nwalkers,nwave].
+ * The interpolated extinction is formed in registers as the operand of the FP64 matrix products
+ * and never stored.  From two walkers on, neighbours in an order of the walkers by their table
+ * brackets share a wavefront and one set of table loads (decided on the device; a batch whose
+ * pairs bracket different temperatures in more than a fifth of the layers runs one walker per
+ * wavefront).  pb_table_transit_supported(...) != 0 says whether the shape has this form
+ * (2..128 impact parameters, nwave >= 2, one species' block of the table below 4 GiB); work_d: pb_table_transit_work_doubles(...) doubles. */
+int pb_table_transit_supported(int nmol, int ntemp, int nlayers, int itop, int ibottom,
+                               int nwave);
+int64_t pb_table_transit_work_doubles(int nmol, int nlayers, int itop, int ibottom, int nwalkers);
+int pb_table_transit_batch(double *spectrum_d, const double *etable_d, const double *ttable_d,
+                           const double *temps_d, const double *density_d,
+                           const double *raypath_d, const double *radius_d, double rstar,
+                           int itop, int ibottom, double maxdepth, int nmol, int ntemp,
+                           int nlayers, int nwave, int nwalkers, void *work_d, void *stream);
+#endif /* PB_EXPERIMENTS */
 
 #ifdef __cplusplus
 }

@@ -9,7 +9,9 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIBPATH = os.path.join(_HERE, 'libpbhip.so')
+# PB_LIBPBHIP=<path>: another build of the library -- libpbhip_exp.so (`make EXPERIMENTS=1`: the
+# product + the measured dead ends) or one of the debug builds of tools/debug/
+LIBPATH = os.environ.get('PB_LIBPBHIP') or os.path.join(_HERE, 'libpbhip.so')
 
 PB_OK = 0
 
@@ -63,9 +65,6 @@ _PROTOS = {
     'pb_lbl_extinction_end': [vp, vp],
     'pb_lbl_last_state': [vp, vp, vp, i32, i32, vp],
     'pb_lbl_last_layer_kinds': [vp, vp, vp, i32, vp],
-    'pb_lbl_last_wave_layers': [vp, vp, i32, vp],
-    'pb_lbl_dyn_stats': [vp, vp],
-    'pb_lbl_set_dyn_predict': [vp, i32],
     'pb_lbl_last_work': [vp, C.POINTER(i64 * 3), vp],
     'pb_lbl_last_table_samples': [vp, C.POINTER(i64), vp],
     'pb_lbl_timing_begin': [vp, i32],
@@ -81,10 +80,6 @@ _PROTOS = {
     'pb_transit_work_doubles': [i32, i32, i32, i32, i32],
     'pb_transit_spectrum_batch': [vp, vp, vp, vp, vp, vp, f64, i32, i32, f64, i32, i32, i32, vp, vp],
     'pb_transit_spectrum_ordered': [vp, vp, vp, vp, vp, f64, i32, i32, f64, i32, i32, i32, vp, vp],
-    'pb_table_transit_supported': [i32, i32, i32, i32, i32, i32],
-    'pb_table_transit_work_doubles': [i32, i32, i32, i32, i32],
-    'pb_table_transit_batch': [vp, vp, vp, vp, vp, vp, vp, f64, i32, i32, f64, i32, i32, i32, i32,
-                               i32, vp, vp],
     'pb_emission_flux_batch': [vp, vp, vp, vp, vp, vp, vp, i32, f64, i32, i32, i32, i32, i32, vp],
     'pb_emission_flux_ordered': [vp, vp, vp, vp, vp, vp, vp, vp, i32, f64, i32, i32, i32, i32, i32, vp],
     'pb_band_integrate_batch': [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp],
@@ -111,6 +106,16 @@ _PROTOS = {
     'pb_ediff': [vp, vp, i32, vp],
     'pb_band_integrate': [vp, vp, vp, vp, vp, vp, vp, i32, i64, i64, vp],
 }
+# entries of libpbhip_exp.so only (include/pbhip.h, "Experiments"): bound when the loaded library has them
+_EXP_PROTOS = {
+    'pb_lbl_last_wave_layers': [vp, vp, i32, vp],
+    'pb_lbl_dyn_stats': [vp, vp],
+    'pb_lbl_set_dyn_predict': [vp, i32],
+    'pb_table_transit_supported': [i32, i32, i32, i32, i32, i32],
+    'pb_table_transit_work_doubles': [i32, i32, i32, i32, i32],
+    'pb_table_transit_batch': [vp, vp, vp, vp, vp, vp, vp, f64, i32, i32, f64, i32, i32, i32, i32,
+                               i32, vp, vp],
+}
 _RESTYPES = {'pb_transit_work_doubles': C.c_int64, 'pb_table_transit_work_doubles': C.c_int64,
              'pb_table_transit_supported': C.c_int, 'pb_voigt_destroy': None, 'pb_lines_destroy': None, 'pb_lbl_destroy': None,
              'pb_voigt_device_bytes': i64, 'pb_timer_destroy': None}
@@ -119,6 +124,11 @@ _NO_CHECK = set(_RESTYPES) | {'pb_version', 'pb_roctx_available'}
 
 def exported_names():
     return sorted(list(_PROTOS) + ['pb_last_error'])
+
+
+def experiments():
+    """True when the loaded library is the experiments build (libpbhip_exp.so)."""
+    return hasattr(lib(), 'pb_table_transit_batch')
 
 
 def _preload_torch_hip_runtime():
@@ -149,6 +159,11 @@ def lib():
             fn = getattr(handle, name)
             fn.argtypes = args
             fn.restype = _RESTYPES.get(name, C.c_int)
+        for name, args in _EXP_PROTOS.items():
+            fn = getattr(handle, name, None)
+            if fn is not None:
+                fn.argtypes = args
+                fn.restype = _RESTYPES.get(name, C.c_int)
         _lib = handle
         global _owner_pid
         _owner_pid = os.getpid()
@@ -166,7 +181,11 @@ def call(name, *args):
         raise PbError(f'{name}: called in a forked child (pid {os.getpid()}) of the process '
                       f'that initialised the GPU (pid {_owner_pid}); the HIP path needs '
                       'ncpu = 1 -- it batches all layers in one call instead of forking')
-    fn = getattr(lib(), name)
+    fn = getattr(lib(), name, None)
+    if fn is None:
+        raise PbError(f'{name} is an experiment that libpbhip.so does not carry: build '
+                      '`make -C pyratbay_amd/csrc EXPERIMENTS=1` and set '
+                      'PB_LIBPBHIP=pyratbay_amd/libpbhip_exp.so')
     rc = fn(*args)
     if name not in _NO_CHECK and rc != PB_OK:
         raise PbError(f'{name} failed ({rc}): {lib().pb_last_error().decode()}')

@@ -689,6 +689,7 @@ __device__ __forceinline__ void stage_qblocks(double *s_q, const double *q, int 
         }
 }
 
+#ifdef PB_EXPERIMENTS   // the layers-outer matrix kernel of round 3 (replaced by k_transit_mfma_rows)
 // A wavefront owns 32 columns = two 16-column tiles (the even and the odd columns of its range:
 // one 16-byte load per lane fetches both) and all MT row tiles: 2 x MT accumulators stay in
 // registers while the layers stream past once, four K-steps (16 layers) in flight ahead of the
@@ -766,6 +767,8 @@ __global__ __launch_bounds__(TB, WPS) void k_transit_mfma(
     mfma_transit_epilogue<MT>(C, s_rad, spectrum + (int64_t)w * nwave, col0, ok, lane, nimpact,
                               maxdepth, rstar);
 }
+
+#endif  // PB_EXPERIMENTS
 
 // The same products ROW TILE BY ROW TILE, with the reference's early exit at tile granularity
 // (_trapezoid.c:259-273: a column is finished at the first row whose optical depth exceeds
@@ -980,6 +983,7 @@ __global__ __launch_bounds__(TB, WPS) void k_transit_mfma_rows(
     }
 }
 
+#ifdef PB_EXPERIMENTS   // one-pass table transit (slower than the two passes at C5; opt-in)
 // a wave-uniform flag written by an earlier kernel, by a scalar load
 __device__ __forceinline__ int uniform_flag(const int32_t *p)
 {
@@ -1407,6 +1411,9 @@ __global__ __launch_bounds__(TB, WPS) void k_table_transit_pair(
                                    ok && haveb, lane, nimpact, maxdepth, rstar);
 }
 
+#endif  // PB_EXPERIMENTS
+
+#ifdef PB_EXPERIMENTS   // LDS column tile of the fused transit kernel (5x slower; A/B only)
 // ---------------------------------------------------------------------------
 // The same pass with the column tile in LDS: workgroup = 64 columns x NB wavefronts, wavefront b
 // owning the impact parameters 16b .. 16b+15.  The tile of s_i = ec[i+1] + ec[i] (64 columns x all
@@ -1542,6 +1549,8 @@ __global__ __launch_bounds__(1024) void k_transit_tile(
         }
     }
 }
+
+#endif  // PB_EXPERIMENTS
 
 // ---------------------------------------------------------------------------
 // PassBand.integrate for a batch of spectra: grid (band, walker); fixed-order tree sum.
@@ -1684,6 +1693,7 @@ int pb_transit_fused_launch(double *depth_d, int32_t *ideep_d, double *spectrum_
 {
     const int nrow = nlayers - itop;
     const int nimpact = std::min(ibottom, nlayers) - itop;
+#ifdef PB_EXPERIMENTS
     // PB_TRANSIT_TILE=1: the LDS-tile form (measured slower: 10.3 ms against 4.5 ms per 64-walker
     // batch at C5's shape -- five wavefronts of uneven length per 70 KB of LDS); kept for A/B
     {
@@ -1705,7 +1715,8 @@ int pb_transit_fused_launch(double *depth_d, int32_t *ideep_d, double *spectrum_
             return PB_OK;
         }
     }
-    // the retrieval batch (spectrum only, no deck) on the matrix cores: k_transit_mfma
+#endif  // PB_EXPERIMENTS
+    // the retrieval batch (spectrum only, no deck) on the matrix cores: k_transit_mfma_rows
     {
         // (read per call: the tests switch it inside one process)
         const char *mode = getenv("PB_TRANSIT_MFMA");
@@ -1722,6 +1733,7 @@ int pb_transit_fused_launch(double *depth_d, int32_t *ideep_d, double *spectrum_
             k_path_qblocks<<<qgrid, kBlock, 0, s>>>(work_d, raypath_d, npath, nblk, nimpact);
             PB_LAUNCH_CHECK();
             const size_t lds = ((size_t)nblk * 64 + (size_t)mt * 16) * 8;
+#ifdef PB_EXPERIMENTS
 #define PB_MFMA(M, W, T)                                                                         \
     do {                                                                                         \
         if (lds > 64 * 1024)                                                                     \
@@ -1732,13 +1744,17 @@ int pb_transit_fused_launch(double *depth_d, int32_t *ideep_d, double *spectrum_
                                                      rstar, itop, ibottom, maxdepth, nlayers,    \
                                                      nwave);                                     \
     } while (0)
+#endif  // PB_EXPERIMENTS
             // threads per workgroup: a workgroup stages its walker's Q blocks (30 KB at 80
             // layers) once for TB / 64 x 32 columns
             const int tb = getenv("PB_MFMA_TB") ? atoi(getenv("PB_MFMA_TB")) : 512;
             // row tile by row tile with the early exit (the default: 1.48 against 1.59 ms per 64
             // walkers at C5's shape with the columns in grid order, 1.16 with ordered columns);
-            // PB_TRANSIT_MFMA=4: the layers-outer kernel it replaced, for A/B
-            if (scatter_d || !(mode && atoi(mode) == 4)) {
+            // PB_TRANSIT_MFMA=4 (experiments build): the layers-outer kernel it replaced, for A/B
+#ifdef PB_EXPERIMENTS
+            if (scatter_d || !(mode && atoi(mode) == 4))
+#endif
+            {
 #define PB_MFMA_ROWS(M, W, T)                                                                    \
     do {                                                                                         \
         if (lds > 64 * 1024)                                                                     \
@@ -1774,6 +1790,7 @@ int pb_transit_fused_launch(double *depth_d, int32_t *ideep_d, double *spectrum_
                 PB_LAUNCH_CHECK();
                 return PB_OK;
             }
+#ifdef PB_EXPERIMENTS
             switch (mt) {
             case 1: PB_MFMA(1, 4, 256); break;
             case 2: PB_MFMA(2, 4, 256); break;
@@ -1794,6 +1811,7 @@ int pb_transit_fused_launch(double *depth_d, int32_t *ideep_d, double *spectrum_
 #undef PB_MFMA
             PB_LAUNCH_CHECK();
             return PB_OK;
+#endif  // PB_EXPERIMENTS
         }
     }
     static const bool no_scalar = getenv("PB_TRANSIT_SCALAR") && atoi(getenv("PB_TRANSIT_SCALAR")) == 0;
@@ -2056,6 +2074,7 @@ int pb_transit_spectrum_ordered(double *spectrum_d, const double *ec_d, const do
                                    column_d);
 }
 
+#ifdef PB_EXPERIMENTS
 int pb_table_transit_supported(int nmol, int ntemp, int nlayers, int itop, int ibottom, int nwave)
 {
     if (nmol < 1 || nmol > 8 || nlayers < 1 || itop < 0 || itop >= nlayers || ibottom > nlayers ||
@@ -2216,6 +2235,7 @@ int pb_table_transit_batch(double *spectrum_d, const double *etable_d, const dou
     PB_LAUNCH_CHECK();
     return PB_OK;
 }
+#endif  // PB_EXPERIMENTS
 
 int pb_band_integrate_batch(double *bandflux_d, const double *spectrum_d, const double *wn_d,
                             const int32_t *band_start_d, const int32_t *band_count_d,

@@ -41,6 +41,15 @@
 #include "pb_internal.h"
 #include "pb_ext_args.h"
 
+// `make EXPERIMENTS=1` (libpbhip_exp.so) keeps the measured dead ends selectable: gather modes 4
+// (scatter), 5 (rounds: pb_rounds.hip) and 7 (wave: pb_wave.hip), the predicted run plans of the
+// `resolution` mode.  The default library compiles none of them.
+#ifdef PB_EXPERIMENTS
+constexpr bool kExp = true;
+#else
+constexpr bool kExp = false;
+#endif
+
 using namespace pbx;
 
 namespace {
@@ -1704,6 +1713,7 @@ __global__ __launch_bounds__(kResThreads) void k_ext_resident(LblArgs a)
     }
 }
 
+#ifdef PB_EXPERIMENTS   // gather mode 4 (4x slower than the staged kernel)
 // ---------------------------------------------------------------------------
 // 3s. Scatter kernel (constant-step grid): ONE wavefront owns a tile of T output samples
 // held in LDS and walks, in (isotope, position) order, the records whose window reaches the
@@ -1859,6 +1869,8 @@ __global__ __launch_bounds__(64) void k_ext_scatter(LblArgs a)
     for (int i = lane; i < tlen; i += 64)
         out[i] = s_tile[i];
 }
+
+#endif  // PB_EXPERIMENTS
 
 // ext += part[0] + part[1] + ... in that order (the phase splits of a small staged launch).
 // skip[layer] != 0: a layer another kernel computed whole (the resident-profile kernel): the
@@ -2587,8 +2599,10 @@ int pb_lbl_create(pb_lbl **out, pb_voigt *voigt, pb_lines *lines, const double *
     p->ndivs = ndivs;
     p->max_layers = max_layers;
     p->resolution = resolution ? 1 : 0;
+#ifdef PB_EXPERIMENTS
     if (const char *e = getenv("PB_RES_DYN_PREDICT"))
         p->dyn_predict = resolution && atoi(e) == 1 ? 1 : 0;
+#endif
     p->cutoff = cutoff;
     p->ethresh = ethresh;
     p->wnstep = wnstep;
@@ -2774,10 +2788,12 @@ int pb_lbl_create(pb_lbl **out, pb_voigt *voigt, pb_lines *lines, const double *
             p->gather_mode = 2;
         else if (e && !strcmp(e, "resident"))
             p->gather_mode = 3;
+#ifdef PB_EXPERIMENTS
         else if (e && !strcmp(e, "scatter"))
             p->gather_mode = 4;
         else if (e && !strcmp(e, "rounds"))
             p->gather_mode = 5;
+#endif
         const char *t = getenv("PB_STAGE_THRESHOLD");
         if (t)
             p->stage_threshold = atof(t);
@@ -2805,6 +2821,12 @@ int pb_lbl_set_isoiext(pb_lbl *p, const int32_t *isoiext_h)
 int pb_lbl_set_gather_mode(pb_lbl *p, int mode)
 {
     PB_REQUIRE(p && mode >= 0 && mode <= 7, "pb_lbl_set_gather_mode: mode must be 0..7");
+#ifndef PB_EXPERIMENTS
+    PB_REQUIRE(mode != 4 && mode != 5 && mode != 7,
+               "pb_lbl_set_gather_mode: mode %d (scatter / rounds / wave) is a measured dead end "
+               "kept out of libpbhip.so: `make -C pyratbay_amd/csrc EXPERIMENTS=1` builds "
+               "libpbhip_exp.so with it", mode);
+#endif
     PB_REQUIRE(mode != 6 || p->resolution,
                "pb_lbl_set_gather_mode: mode 6 (per-layer dynamic grids) is for `resolution` plans");
     p->gather_mode = mode;
@@ -3087,14 +3109,14 @@ static int lbl_extinction(pb_lbl *p, double *ext_d, int64_t wbegin, int64_t wcou
     const bool enough_blocks = pb::div_up(wcount, S * sub) * (int64_t)nlayers * nsplit *
                                    (shared_chip ? p->concurrency : 1) >= 750;
     // round-staged kernel (pb_rounds.hip): rows of one piece (<= 1024 samples), packed records
-    const bool rounds = can_stage && a.nch_max == 1 && packable && p->gather_mode == 5;
+    const bool rounds = kExp && can_stage && a.nch_max == 1 && packable && p->gather_mode == 5;
     const bool staged = can_stage && (p->gather_mode == 2 || p->gather_mode == 7 || rounds ||
                                       (p->gather_mode == 0 && enough_blocks &&
                                        per_phase >= p->stage_threshold));
     const bool use_records = !p->resolution && l->ngroups > 0;
     // layers with narrow profiles go to the resident-profile kernel (decided per layer on
     // the device, from the layer alone); the kernel chosen above computes the others
-    const bool scatter = use_records && p->gs_start && p->gather_mode == 4;
+    const bool scatter = kExp && use_records && p->gs_start && p->gather_mode == 4;
     bool resident = use_records && !scatter && p->res_cap > 0 && p->gs_start &&
                     (p->gather_mode == 0 || p->gather_mode == 3);
     bool res_look = false;            // read the layers' decision back after this call
@@ -3202,6 +3224,7 @@ static int lbl_extinction(pb_lbl *p, double *ext_d, int64_t wbegin, int64_t wcou
     // staged kernel computes the others.  Mode 7 selects the pair; modes 0 and 2 keep to the staged
     // kernel alone.  Chunked line lists continue running sums in the staged kernel's order and
     // keep to it.
+#ifdef PB_EXPERIMENTS
     {
         // (measured at C2, round 4: the pair takes 1.20 ms per extinction against 1.05 ms for the
         // staged kernel alone -- profiles/r04_gather_wave.md -- so mode 0 does not use it unless
@@ -3214,11 +3237,13 @@ static int lbl_extinction(pb_lbl *p, double *ext_d, int64_t wbegin, int64_t wcou
         if (wave_on && wave_lds(a) <= 160 * 1024)
             a.wave_cap = kWvRowMax;
     }
+#endif  // PB_EXPERIMENTS
     a.nsplit = 1;
     a.part = nullptr;
     a.wm_lo[0] = a.wm_lo[1] = a.wm_off[0] = a.wm_off[1] = nullptr;
     a.wm_n[0] = a.wm_n[1] = 0;
     a.wm_total[0] = a.wm_total[1] = 0;
+#ifdef PB_EXPERIMENTS
     if (scatter) {
         if (!p->rec32) {
             const size_t n = (size_t)p->max_layers * (size_t)l->ngroups;
@@ -3234,6 +3259,7 @@ static int lbl_extinction(pb_lbl *p, double *ext_d, int64_t wbegin, int64_t wcou
         }
         a.rec32 = p->rec32;
     }
+#endif  // PB_EXPERIMENTS
     if (chunked)
         a.res_cap = 0;                   // every layer through the staged gather
     // the SoA records serve the global gather, the resident layers and PB_REC_SOA
@@ -3460,6 +3486,7 @@ static int lbl_extinction(pb_lbl *p, double *ext_d, int64_t wbegin, int64_t wcou
     p->last_gather = dyn_fall ? 6 : scatter ? 4
                              : (p->resolution ? 3 : rounds ? 5 : staged ? 2 : 1) +
                                    (resident ? 8 : 0) + (a.wave_cap > 0 ? 16 : 0);
+#ifdef PB_EXPERIMENTS
     if (scatter) {
         int T = 512;
         if (const char *e = getenv("PB_SCATTER_T"))
@@ -3474,7 +3501,9 @@ static int lbl_extinction(pb_lbl *p, double *ext_d, int64_t wbegin, int64_t wcou
         else
             k_ext_scatter<512><<<grid, 64, 0, s>>>(a);
         PB_LAUNCH_CHECK();
-    } else if (resident) {
+    } else
+#endif  // PB_EXPERIMENTS
+    if (resident) {
         a.ntiles = pb::div_up(wcount, kResTile);
         dim3 grid((unsigned)(8 * a.ntiles * layer_groups), a.nrows);
         const size_t rlds = ((size_t)a.res_cap + 2) * 8 + (size_t)kResThreads * (16 + 4) +
@@ -3491,7 +3520,9 @@ static int lbl_extinction(pb_lbl *p, double *ext_d, int64_t wbegin, int64_t wcou
         a.ntiles = pb::div_up(wcount, kBlock);
         dim3 grid((unsigned)(8 * a.ntiles * layer_groups), a.nrows);
         k_ext_linterp<<<grid, kBlock, 0, s>>>(a);
-    } else if (rounds) {
+    }
+#ifdef PB_EXPERIMENTS
+    else if (rounds) {
         // geometry: 16 wavefronts x 2 spans of 256 samples (tile 8192, two LDS buffers of 8192
         // samples, one workgroup per CU) or 8 x 2 (tile 4096, buffers of 4096, two per CU)
         int geom = 2;
@@ -3607,7 +3638,9 @@ static int lbl_extinction(pb_lbl *p, double *ext_d, int64_t wbegin, int64_t wcou
             k_combine_parts<<<(unsigned)pb::div_up(n, kBlock), kBlock, 0, s>>>(
                 ext_d, p->part, rsplit - 1, n, nullptr, (int64_t)a.nrows * wcount);
         }
-    } else if (staged) {
+    }
+#endif  // PB_EXPERIMENTS
+    else if (staged) {
         // Per-layer split.  A launch ends when its slowest workgroup does, and the slowest are the
         // tiles of the deepest layers (cutoff-limited windows of ~1000 samples against 200-300
         // higher up: 0.7-0.9 ms of a 0.88-ms C2 launch, profiles/r02_gather_ab.md), which the
@@ -3794,12 +3827,14 @@ static int lbl_extinction(pb_lbl *p, double *ext_d, int64_t wbegin, int64_t wcou
         if (lds > 64 * 1024)
             PB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+#ifdef PB_EXPERIMENTS
         if (a.wave_cap > 0) {
             // the short-row layers first: many short workgroups, then the staged kernel's long ones
             const int rc = wave_launch(a, nunits, s);
             if (rc != PB_OK)
                 return rc;
         }
+#endif
         kern<<<grid, kStagedThreads, lds, s>>>(a);
         if (deep > 0) {
             PB_LAUNCH_CHECK();
@@ -3953,7 +3988,9 @@ static int lbl_resolution_dyn(pb_lbl *p, LblArgs &a, double *ext_d, int64_t wbeg
         (void)hipGetLastError();                          // (hipErrorNotReady is not an error)
     }
     // (a captured call cannot synchronise: it is planned from the prediction or not at all)
-    const bool spec = p->dyn_predict && p->pred_layers == nlayers &&
+    // (the default library has no switch for it: pb_lbl_set_dyn_predict exists in the experiments
+    // build only -- measured no faster)
+    const bool spec = kExp && p->dyn_predict && p->pred_layers == nlayers &&
                       (capturing != hipStreamCaptureStatusNone || p->dyn_hold == 0);
     PB_REQUIRE(spec || capturing == hipStreamCaptureStatusNone,
                "pb_lbl_extinction: a `resolution` plan in gather mode 6 can be captured into a "
@@ -4319,6 +4356,7 @@ int pb_lbl_last_layer_kinds(pb_lbl *p, int32_t *resident_h, int32_t *block_h, in
     return PB_OK;
 }
 
+#ifdef PB_EXPERIMENTS
 int pb_lbl_last_wave_layers(pb_lbl *p, int32_t *wave_h, int nlayers, void *stream)
 {
     PB_REQUIRE(p && wave_h, "pb_lbl_last_wave_layers: null pointer");
@@ -4347,6 +4385,7 @@ int pb_lbl_dyn_stats(pb_lbl *p, int64_t stats[3])
     stats[2] = p->dyn_mispredicted;
     return PB_OK;
 }
+#endif  // PB_EXPERIMENTS
 
 int pb_lbl_last_work(pb_lbl *p, int64_t work[3], void *stream)
 {

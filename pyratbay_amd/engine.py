@@ -325,9 +325,10 @@ class LBL:
               'dynamic': 6, 'wave': 7}
 
     def set_gather_mode(self, mode):
-        """'auto' | 'global' | 'staged' | 'resident' | 'wave' (the staged kernel + the
-        wave-autonomous kernel for the layers of short phase rows); 'dynamic' (`resolution`
-        plans: the layers' dynamic grids through constant-step sub-plans).  See pbhip.h:
+        """'auto' | 'global' | 'staged' | 'resident'; 'dynamic' (`resolution` plans: the layers'
+        dynamic grids through constant-step sub-plans).  'scatter', 'rounds' and 'wave' are
+        measured dead ends that only the experiments build of the library carries
+        (libpbhip_exp.so, _capi.experiments()); the default library refuses them.  See pbhip.h:
         pb_lbl_set_gather_mode."""
         call('pb_lbl_set_gather_mode', self._h, self.GATHER[mode])
         self.gather_mode = mode
@@ -563,7 +564,10 @@ def transit_spectrum_ordered(ec, raypath, radius, column, rstar, itop, ibottom, 
 
 
 def table_transit_supported(nmol, ntemp, nlayers, itop, ibottom, nwave):
-    """Whether the one-pass form (table_transit_batch) exists for this shape."""
+    """Whether the one-pass form (table_transit_batch) exists for this shape -- never in the
+    default library (an experiment: libpbhip_exp.so)."""
+    if not _capi.experiments():
+        return False
     return bool(_capi.lib().pb_table_transit_supported(int(nmol), int(ntemp), int(nlayers),
                                                        int(itop), int(ibottom), int(nwave)))
 
@@ -571,7 +575,8 @@ def table_transit_supported(nmol, ntemp, nlayers, itop, ibottom, nwave):
 def table_transit_batch(etable, ttable, temps, dens, raypath, radius, rstar, itop, ibottom,
                         maxdepth):
     """interp_ec + optical depth + transmission of a batch of walkers in ONE pass
-    (pb_table_transit_batch): etable[S, T, L, W], temps[nw, L], dens[nw, L, S],
+    (pb_table_transit_batch; experiments build of the library only): etable[S, T, L, W],
+    temps[nw, L], dens[nw, L, S],
     raypath[nw, npath], radius[nw, L] -> spectrum[nw, W].  The interpolated extinction is
     the operand of the matrix products and is never stored."""
     nmol, ntemp, nlayers, nwave = etable.shape
@@ -579,6 +584,8 @@ def table_transit_batch(etable, ttable, temps, dens, raypath, radius, rstar, ito
     assert temps.shape == (nw, nlayers) and dens.shape == (nw, nlayers, nmol)
     assert radius.shape == (nw, nlayers) and raypath.shape[0] == nw
     spectrum = torch.empty((nw, nwave), dtype=torch.float64, device=etable.device)
+    if not _capi.experiments():
+        call('pb_table_transit_batch')                     # (raises: not in libpbhip.so)
     nwork = _capi.lib().pb_table_transit_work_doubles(nmol, nlayers, int(itop), int(ibottom), nw)
     work = torch.empty(max(nwork, 8), dtype=torch.float64, device=etable.device)
     call('pb_table_transit_batch', _ptr(spectrum), _ptr(etable), _ptr(ttable),
@@ -995,7 +1002,7 @@ class LBLSpectrum:
         second database then use the first database's isotope data, and the list steps back in
         wavenumber within an isotope id, which pb_lines_create refuses (the reference's result
         on such a list depends on its one-way Doppler-index search; fixture G16, run `onefile`,
-        pins it against the oracle only).  One database per file, the layout of the reference's
+        is pinned by the CPU-side checker only).  One database per file, the layout of the reference's
         own configurations, is the same either way.
 
         atm: dict with temp[L], dens[L, nspecies] (cm-3), radius[L], press[L] (bar; for the width

@@ -1,9 +1,34 @@
 """Seeded small inputs shared by the golden-vector generator and the parity tests.
 
 Pure NumPy; nothing here computes expected values."""
+import os
+
 import numpy as np
+import pytest
 
 from pyratbay_amd import synth
+
+# The measured dead ends (gather modes scatter / rounds / wave, the one-pass and layers-outer
+# matrix transit kernels, predicted `resolution` run plans) live in libpbhip_exp.so only
+# (`make -C pyratbay_amd/csrc EXPERIMENTS=1`, PB_LIBPBHIP=pyratbay_amd/libpbhip_exp.so); their
+# tests carry the marker `gpu_experiments` and are deselected otherwise (tests/conftest.py).
+EXPERIMENTS = os.environ.get('PB_LIBPBHIP', '').endswith('libpbhip_exp.so')
+EXPERIMENTAL_GATHERS = ('scatter', 'rounds', 'wave')
+
+
+def exp(*values):
+    """pytest.param(...) marked gpu_experiments."""
+    return pytest.param(*values, marks=pytest.mark.gpu_experiments)
+
+
+def gathers(*modes):
+    """Parametrisation over gather modes: the experimental ones marked gpu_experiments."""
+    return [exp(m) if m in EXPERIMENTAL_GATHERS else m for m in modes]
+
+
+def live(*modes):
+    """The gather modes of a loop inside a test that the loaded library carries."""
+    return tuple(m for m in modes if EXPERIMENTS or m not in EXPERIMENTAL_GATHERS)
 
 
 def voigt_case():

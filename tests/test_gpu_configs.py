@@ -21,6 +21,8 @@ import time
 import numpy as np
 import pytest
 
+import cases
+
 pytestmark = pytest.mark.gpu
 RTOL = 1e-10
 
@@ -76,7 +78,8 @@ def check(got, want, what):
 # ---------------------------------------------------------------------------
 # C4's structure, reduced size
 # ---------------------------------------------------------------------------
-@pytest.mark.parametrize('gather', ['global', 'staged', 'resident', 'scatter', 'rounds', 'auto'])
+@pytest.mark.parametrize('gather', cases.gathers('global', 'staged', 'resident', 'scatter',
+                                                  'rounds', 'auto'))
 @pytest.mark.parametrize('ethresh', [1e-30, 1e-4])
 def test_four_species_vs_oracle(eng, orc, gather, ethresh):
     from pyratbay_amd import synth
@@ -116,7 +119,7 @@ def test_four_species_shards_and_rows(eng, orc):
     iso, atm = case['iso'], case['atm']
     vt, ll, lbl = plan(eng, case, 4)
     t, d, z = eng.dev(atm['temp']), eng.dev(atm['dens']), eng.dev(iso['isoz'])
-    for gather in ('staged', 'global', 'rounds'):
+    for gather in cases.live('staged', 'global', 'rounds'):
         lbl.set_isoiext(iso['isoiext'])
         lbl.set_gather_mode(gather)
         full = host(lbl.extinction(t, d, z, add=False))

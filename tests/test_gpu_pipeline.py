@@ -482,6 +482,7 @@ def test_shard_pipeline_single_process(eng, case):
         hinted.lbl.set_concurrency(0)
 
 
+@pytest.mark.gpu_experiments
 def test_resolution_mode_predicted_runs(eng, monkeypatch):
     """`resolution` mode with the run plan taken from the last read-back of the layers' factors
     (LBLSpectrum(predict_runs=True), pb_lbl_set_dyn_predict) instead of a stream synchronisation

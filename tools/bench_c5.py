@@ -219,7 +219,9 @@ def main(args):
     # transmission in one kernel, ec never stored; two walkers per wavefront where the batch allows)
     # -- reported beside `value`, which stays the default path's
     one_pass = None
-    if world == 1 and rt == 'transit':
+    from pyratbay_amd import _capi
+    if world == 1 and rt == 'transit' and _capi.experiments():
+        # (experiments build of the library only: PB_LIBPBHIP=pyratbay_amd/libpbhip_exp.so)
         default_flux = out.clone()
         model.one_pass = True
         n1p = max(8, min(steps, 40))

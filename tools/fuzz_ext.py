@@ -78,7 +78,10 @@ def one(eng, ref, rng, seed):
                            iso['isoz'][:, k].copy(), isoiext, ln['lwn'], ln['elow'], ln['gf'],
                            ln['lid'], vg['cutoff'], ethresh, float(atm['temp'][k]), 0, int(add),
                            1)
-    modes = ['auto'] if resolution else ['auto', 'global', 'staged', 'resident', 'scatter', 'rounds']
+    modes = ['auto'] if resolution else ['auto', 'global', 'staged', 'resident']
+    from pyratbay_amd import _capi
+    if not resolution and _capi.experiments():            # (libpbhip_exp.so: the dead ends too)
+        modes += ['scatter', 'rounds']
     for mode in modes:
         lbl.set_gather_mode(mode)
         got = host(lbl.extinction(t, d, z, add=add))

@@ -99,7 +99,8 @@ def ext_case(eng, ref, rng, seed):
     staged = lbl.extinction(t, d, z, add=add).clone()
     ok_staged = lbl.last_gather_kernel == 'k_ext_staged'
     check('staged', staged)
-    if ok_staged:
+    from pyratbay_amd import _capi
+    if ok_staged and _capi.experiments():                 # (the wave kernel: libpbhip_exp.so only)
         lbl.set_gather_mode('wave')
         wv = lbl.extinction(t, d, z, add=add).clone()
         info['wave'] = int(lbl.last_wave_layers(nlayers).sum())
@@ -257,9 +258,11 @@ def main():
                     partition_case(eng, rng)
                 for _ in range(3):
                     ordered_case(eng, rng)
-                sp, mi = predicted_case(eng, rng, seed)
-                npred += sp
-                nmiss += mi
+                from pyratbay_amd import _capi
+                if _capi.experiments():                   # (predicted run plans: libpbhip_exp.so only)
+                    sp, mi = predicted_case(eng, rng, seed)
+                    npred += sp
+                    nmiss += mi
             else:
                 info = ext_case(eng, ref, rng, seed)
                 nwave_layers += info['wave']

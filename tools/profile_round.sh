@@ -11,9 +11,7 @@
 #   <tag>_bench_c2_driverflags.json   --steps 20 --warmup 5
 #   <tag>_kernel_stats.csv            rocprofv3 --kernel-trace --stats of the default bench, one at a time
 #   <tag>_bench_{c2res,c3,c4,c5,c5em,c2bands,c3bands}.json   the other workloads
-#   <tag>_bench_c2res_predict.json    c2-res with the run plans predicted (PB_RES_DYN_PREDICT=1)
 #   <tag>_kernel_stats_{c5,c5em}.csv  rocprofv3 kernel stats of the retrieval batches
-#   <tag>_gather_wave.log             staged kernel alone against staged + wave-autonomous kernel (C2, 1e6 lines)
 #   <tag>_wshard.log, <tag>_rank_rccl.log   per-rank times of the wavenumber decomposition
 #   <tag>_ordered.log                 retrieval batch: transit kernels in grid / depth order, c5 and c5-emission with the ordering off and on
 #   <tag>_tile_times_c2bands.log      per-tile time spread of a band-structured list (tools/tile_times.py)
@@ -21,7 +19,7 @@
 #   <tag>_write_size_probe.csv        WRITE_SIZE of 8- and 16-byte-per-lane stores (tools/write_size_probe.hip)
 #   pmc_traffic.json                  FETCH_SIZE / WRITE_SIZE of the dominant kernels, every workload
 #   <tag>_fuzz_all.log                (with `fuzz`) the randomised parity campaign
-tag=${1:-r04}
+tag=${1:-r05}
 part=${2:-a}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
@@ -43,13 +41,11 @@ echo "kernel stats done"
 python bench.py --workload c5 > gpurun_out/${tag}_bench_c5.json 2> gpurun_out/${tag}_bench_c5.err || exit 1
 python bench.py --workload c5-emission --steps 40 > gpurun_out/${tag}_bench_c5em.json 2> gpurun_out/${tag}_bench_c5em.err || exit 1
 python bench.py --workload c2-res > gpurun_out/${tag}_bench_c2res.json 2> gpurun_out/${tag}_bench_c2res.err || exit 1
-PB_RES_DYN_PREDICT=1 python bench.py --workload c2-res --no-cpu-baseline > gpurun_out/${tag}_bench_c2res_predict.json 2> gpurun_out/${tag}_bench_c2res_predict.err || exit 1
 python bench.py --workload c2-bands --no-north-star > gpurun_out/${tag}_bench_c2bands.json 2> gpurun_out/${tag}_bench_c2bands.err || exit 1
 python bench.py --workload c3 --steps 5 --warmup 2 --cpu-layers 4 > gpurun_out/${tag}_bench_c3.json 2> gpurun_out/${tag}_bench_c3.err || exit 1
 python bench.py --workload c3-bands --steps 5 --warmup 2 --cpu-layers 4 > gpurun_out/${tag}_bench_c3bands.json 2> gpurun_out/${tag}_bench_c3bands.err || exit 1
 python bench.py --workload c4 --steps 3 --warmup 1 --cpu-layers 2 > gpurun_out/${tag}_bench_c4.json 2> gpurun_out/${tag}_bench_c4.err || exit 1
 echo "other workloads done"
-{ for w in c2 c2-1e6 c2-bands; do for m in auto wave; do echo "gather mode $m:"; PB_BENCH_GATHER=$m python tools/bench_stages.py $w 10; done; done; } 2>&1 | grep -v amdgpu.ids > gpurun_out/${tag}_gather_wave.log
 { for n in 2 4 8; do python tools/bench_wshard.py $n c2 3; done; python tools/bench_wshard.py 8 c2-1e6 3; } 2>&1 | grep shard > gpurun_out/${tag}_wshard.log
 { python tools/bench_rank_rccl.py 8 c2 3; python tools/bench_rank_rccl.py 4 c2 3; python tools/bench_rank_rccl.py 2 c2 3; python tools/bench_rank_rccl.py 8 c2-1e6 3; } 2>&1 | grep "rank " > gpurun_out/${tag}_rank_rccl.log
 python tools/bench_dropin.py 2>&1 | grep drop-in > gpurun_out/${tag}_dropin.log
