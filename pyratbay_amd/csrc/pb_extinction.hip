@@ -792,7 +792,19 @@ __global__ __launch_bounds__(kBlock) void k_records(LblArgs a)
 //     16-byte LDS reads at the 16-byte-aligned address at or below the one it needs (what a
 //     second, 8-byte-shifted image of the row would make legal) instead of four 8-byte reads;
 // 2 = the same with 2 consecutive samples per lane in each half of the span;
-// 3 = (valid results) the remainder records of a visit loop software-pipelined.
+// 3 = (valid results) the remainder records of a visit loop software-pipelined;
+// 4 = (valid results) the CYCLE ACCOUNT of a segment step: every
+//     wavefront stamps s_memtime around the parts of its work and adds the differences, per layer,
+//     to a.probe[layer * 16 + c]:  c = 0 candidate search and scans of an isotope, 1 record
+//     fetch + decode of a batch (with its barriers), 2 segment detection + segment table (three
+//     barriers), 3 find_hits (two bisections for 64 segments at once), 4 issue of a row's LDS-DMA
+//     (the one wavefront whose turn it is), 5 the walk (hit decode, record broadcasts, row reads,
+//     FMAs -- up to the last LDS value consumed), 6 s_waitcnt vmcnt(0) for the DMA, 7 the barrier
+//     that ends the step, 8 pipeline fill of a batch (first row + barrier), 9 the wavefront's
+//     lifetime, 10 segment steps, 11 batches, 12 (record, sub-tile) visits of this wavefront,
+//     13 steps in which it visited anything, 14 accumulator read / write-back.
+//     A stamp is s_memtime + s_waitcnt lgkmcnt(0): it also drains the LDS queue, which is why
+//     the probe is not the product kernel (profiles/r05_step_account.md gives both times).
 template <int NW, int S, bool kDma, int kProbe = 0>
 __global__ __launch_bounds__(NW * 64, 8) void k_ext_staged(LblArgs a)
 {
@@ -861,6 +873,13 @@ __global__ __launch_bounds__(NW * 64, 8) void k_ext_staged(LblArgs a)
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    unsigned long long pc[15] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    auto tick = [&]() -> unsigned long long {
+        if constexpr (kProbe == 4)
+            return (unsigned long long)__builtin_amdgcn_s_memtime();
+        return 0ull;
+    };
+    const unsigned long long t_birth = tick();
 
     const int64_t t0 = a.wbegin + (int64_t)tile * kT;
     const int64_t tend = min(t0 + kT, a.wbegin + a.wcount);
@@ -982,12 +1001,14 @@ __global__ __launch_bounds__(NW * 64, 8) void k_ext_staged(LblArgs a)
         }
     };
 
+    pc[14] += tick() - t_birth;
     for (int iso = 0; iso < a.niso; iso++) {
         const int iext = a.isoiext[iso];
         if (iext < 0 || (a.add ? 0 : iext) != row)
             continue;
         if ((iso + 1) * osamp <= a.key_lo || iso * osamp >= a.key_hi)
             continue;                              // no key of this isotope in the chunk
+        const unsigned long long t_iso = tick();
         const int64_t li = (int64_t)layer * a.niso + iso;
         const double dens = a.li_dens[li];
         int64_t reach = a.li_hmax[li];
@@ -1084,9 +1105,12 @@ __global__ __launch_bounds__(NW * 64, 8) void k_ext_staged(LblArgs a)
         if (tid == 0)
             s_cum[nvirt] = total;
         __syncthreads();
+        pc[0] += tick() - t_iso;
 
         for (int x0 = 0; x0 < total; x0 += kThreads) {
             const int nrec = min(kThreads, total - x0);
+            const unsigned long long t_batch = tick();
+            pc[11] += 1;
             __syncthreads();
             // ---- one record per lane, in (phase, iown) order, from k_records ----
             long long src = -1;                        // phase row of my record (table element)
@@ -1164,6 +1188,8 @@ __global__ __launch_bounds__(NW * 64, 8) void k_ext_staged(LblArgs a)
                 s_m[tid] = mwin;
             }
             __syncthreads();
+            const unsigned long long t_seg = tick();
+            pc[1] += t_seg - t_batch;
             // ---- segments: runs of equal (cell, phase, row window); live ones are listed ----
             bool start = false;
             {
@@ -1212,6 +1238,7 @@ __global__ __launch_bounds__(NW * 64, 8) void k_ext_staged(LblArgs a)
                 }
             }
             __syncthreads();
+            pc[2] += tick() - t_seg;
             if (nseg == 0)
                 continue;
             // ---- rows are double-buffered in LDS and fetched two segments ahead: segment
@@ -1250,8 +1277,12 @@ __global__ __launch_bounds__(NW * 64, 8) void k_ext_staged(LblArgs a)
                 }
             };
             auto walk = [&](int sg, int buf) {
-                if ((sg & 63) == 0)
+                if ((sg & 63) == 0) {
+                    const unsigned long long tf = tick();
                     find_hits(sg);
+                    pc[3] += tick() - tf;
+                }
+                bool any = false;
                 // byte address of this lane's first sample in the staged row
                 const char *rowp = reinterpret_cast<const char *>(
                     s_row + kStagePad + buf * rowspan + rlo + lane);
@@ -1260,6 +1291,10 @@ __global__ __launch_bounds__(NW * 64, 8) void k_ext_staged(LblArgs a)
                     const unsigned h = (unsigned)__builtin_amdgcn_readlane((int)hits[u], sg & 63);
                     if (h < 0x10000u)
                         continue;
+                    if constexpr (kProbe == 4) {
+                        pc[12] += h >> 16;
+                        any = true;
+                    }
                     const int first = (int)(h & 0xffff);
                     const int last = first + (int)(h >> 16);
                     // per record: ONE 16-byte broadcast read of {k, offset, window}, four
@@ -1319,6 +1354,8 @@ __global__ __launch_bounds__(NW * 64, 8) void k_ext_staged(LblArgs a)
                             visit(recs[r]);
                     }
                 }
+                if constexpr (kProbe == 4)
+                    pc[13] += any ? 1 : 0;
             };
             // Software pipeline over the segments.  Segment j lives in register set j % D;
             // its loads are issued D steps before its row is written to LDS buffer j % 2
@@ -1364,13 +1401,37 @@ __global__ __launch_bounds__(NW * 64, 8) void k_ext_staged(LblArgs a)
                 // while sg is walked, and has landed before the barrier that ends the step.
                 // (Three buffers and a request two steps ahead measured slower, 1.22 vs 1.14 ms
                 // at C2: 48 KB of LDS leave three workgroups per CU.)
+                unsigned long long ta = tick();
                 if (wave == 0)
                     dma_row(0, 0);
                 __builtin_amdgcn_s_waitcnt(0x0f70);           // vmcnt(0)
                 __syncthreads();
+                if constexpr (kProbe == 4) {
+                    const unsigned long long tb = tick();
+                    pc[8] += tb - ta;
+                    ta = tb;
+                }
                 for (int sg = 0; sg < nseg; sg++) {
                     if (sg + 1 < nseg && wave == ((sg + 1) & (NW - 1)))
                         dma_row(sg + 1, (sg + 1) & 1);
+                    if constexpr (kProbe == 4) {
+                        const unsigned long long tb = tick();
+                        pc[4] += tb - ta;
+                        ta = tb;
+                        const unsigned long long f0 = pc[3];
+                        walk(sg, sg & 1);
+                        // (every LDS value of the walk has been consumed by its FMA: lgkmcnt(0))
+                        const unsigned long long tc = tick();
+                        pc[5] += (tc - ta) - (pc[3] - f0);
+                        __builtin_amdgcn_s_waitcnt(0x0f70);
+                        const unsigned long long td = tick();
+                        pc[6] += td - tc;
+                        __syncthreads();
+                        ta = tick();
+                        pc[7] += ta - td;
+                        pc[10] += 1;
+                        continue;
+                    }
                     walk(sg, sg & 1);
                     __builtin_amdgcn_s_waitcnt(0x0f70);       // the row of sg+1 has landed
                     __syncthreads();
@@ -1381,6 +1442,7 @@ __global__ __launch_bounds__(NW * 64, 8) void k_ext_staged(LblArgs a)
         }
     }
 
+    const unsigned long long t_out = tick();
 #pragma unroll
     for (int u = 0; u < S; u++) {
 #pragma unroll
@@ -1389,6 +1451,14 @@ __global__ __launch_bounds__(NW * 64, 8) void k_ext_staged(LblArgs a)
             if (j < tlen)
                 dst[j] = acc[u][c];
         }
+    }
+    if constexpr (kProbe == 4) {
+        const unsigned long long t_end = tick();
+        pc[14] += t_end - t_out;
+        pc[9] = t_end - t_birth;
+        if (lane == 0 && a.probe)
+            for (int i = 0; i < 15; i++)
+                atomicAdd(&a.probe[(int64_t)layer * 16 + i], pc[i]);
     }
 }
 
@@ -3017,6 +3087,7 @@ static int lbl_extinction(pb_lbl *p, double *ext_d, int64_t wbegin, int64_t wcou
     {
         const char *e = getenv("PB_EXPERIMENT");
         a.experiment = e ? atoi(e) : 0;
+        a.probe = nullptr;
     }
 
     // Kernel choice (constant-step grids): the LDS-staged kernel when several groups share
@@ -3819,11 +3890,21 @@ static int lbl_extinction(pb_lbl *p, double *ext_d, int64_t wbegin, int64_t wcou
                 : (S == 4   ? k_ext_staged<kStagedWaves, 4, false>
                    : S == 2 ? k_ext_staged<kStagedWaves, 2, false>
                             : k_ext_staged<kStagedWaves, 1, false>);
-        if (const char *e = getenv("PB_STAGE_PROBE"))
+#ifdef PB_EXPERIMENTS
+        unsigned long long *probe_d = nullptr;
+        if (const char *e = getenv("PB_STAGE_PROBE")) {
             if (atoi(e) >= 1 && atoi(e) <= 3 && S == 2 && dma)    // 1, 2: timing probes, wrong sums
                 kern = atoi(e) == 1   ? k_ext_staged<kStagedWaves, 2, true, 1>
                        : atoi(e) == 2 ? k_ext_staged<kStagedWaves, 2, true, 2>
                                       : k_ext_staged<kStagedWaves, 2, true, 3>;
+            if (atoi(e) == 4 && S == 2 && dma) {                  // the cycle account (valid sums)
+                kern = k_ext_staged<kStagedWaves, 2, true, 4>;
+                PB_HIP(hipMalloc(&probe_d, (size_t)nlayers * 16 * 8));
+                PB_HIP(hipMemsetAsync(probe_d, 0, (size_t)nlayers * 16 * 8, s));
+                a.probe = probe_d;
+            }
+        }
+#endif
         if (lds > 64 * 1024)
             PB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -3836,6 +3917,26 @@ static int lbl_extinction(pb_lbl *p, double *ext_d, int64_t wbegin, int64_t wcou
         }
 #endif
         kern<<<grid, kStagedThreads, lds, s>>>(a);
+#ifdef PB_EXPERIMENTS
+        if (probe_d) {
+            // one line per layer on stderr: layer, rowmax of its first isotope, then the 15 sums
+            std::vector<unsigned long long> h((size_t)nlayers * 16);
+            PB_HIP(hipMemcpyAsync(h.data(), probe_d, h.size() * 8, hipMemcpyDeviceToHost, s));
+            std::vector<int32_t> rowmax((size_t)nlayers * a.niso);
+            PB_HIP(hipMemcpyAsync(rowmax.data(), a.li_rowmax, rowmax.size() * 4,
+                                  hipMemcpyDeviceToHost, s));
+            PB_HIP(hipStreamSynchronize(s));
+            (void)hipFree(probe_d);
+            a.probe = nullptr;
+            for (int layer = 0; layer < nlayers; layer++) {
+                fprintf(stderr, "STAGE_PROBE layer %d rowmax %d :", layer,
+                        rowmax[(size_t)layer * a.niso]);
+                for (int i = 0; i < 15; i++)
+                    fprintf(stderr, " %llu", h[(size_t)layer * 16 + i]);
+                fprintf(stderr, "\n");
+            }
+        }
+#endif
         if (deep > 0) {
             PB_LAUNCH_CHECK();
             const int64_t per_layer = (int64_t)a.nrows * wcount;
