@@ -795,14 +795,16 @@ __global__ __launch_bounds__(kBlock) void k_records(LblArgs a)
 // 3 = (valid results) the remainder records of a visit loop software-pipelined;
 // 4 = (valid results) the CYCLE ACCOUNT of a segment step: every
 //     wavefront stamps s_memtime around the parts of its work and adds the differences, per layer,
-//     to a.probe[layer * 16 + c]:  c = 0 candidate search and scans of an isotope, 1 record
+//     to a.probe[layer * 20 + c]:  c = 0 candidate search and scans of an isotope, 1 record
 //     fetch + decode of a batch (with its barriers), 2 segment detection + segment table (three
 //     barriers), 3 find_hits (two bisections for 64 segments at once), 4 issue of a row's LDS-DMA
 //     (the one wavefront whose turn it is), 5 the walk (hit decode, record broadcasts, row reads,
 //     FMAs -- up to the last LDS value consumed), 6 s_waitcnt vmcnt(0) for the DMA, 7 the barrier
 //     that ends the step, 8 pipeline fill of a batch (first row + barrier), 9 the wavefront's
 //     lifetime, 10 segment steps, 11 batches, 12 (record, sub-tile) visits of this wavefront,
-//     13 steps in which it visited anything, 14 accumulator read / write-back.
+//     13 steps in which it visited anything, 14 accumulator read / write-back; calibration:
+//     15 the lifetime on the 100-MHz wall clock (s_memrealtime), 16 two back-to-back stamp
+//     intervals with an empty LDS queue, 17 wavefronts.
 //     A stamp is s_memtime + s_waitcnt lgkmcnt(0): it also drains the LDS queue, which is why
 //     the probe is not the product kernel (profiles/r05_step_account.md gives both times).
 template <int NW, int S, bool kDma, int kProbe = 0>
@@ -873,12 +875,23 @@ __global__ __launch_bounds__(NW * 64, 8) void k_ext_staged(LblArgs a)
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    unsigned long long pc[15] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long pc[18] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     auto tick = [&]() -> unsigned long long {
         if constexpr (kProbe == 4)
             return (unsigned long long)__builtin_amdgcn_s_memtime();
         return 0ull;
     };
+    unsigned long long real_birth = 0;
+    if constexpr (kProbe == 4) {
+        // calibration: the cost of a stamp with an empty LDS queue (16 = three stamps in a row,
+        // i.e. two intervals; 17 = 1) and the 100-MHz wall clock beside s_memtime (15)
+        real_birth = (unsigned long long)__builtin_amdgcn_s_memrealtime();
+        const unsigned long long c0 = tick();
+        const unsigned long long c1 = tick();
+        const unsigned long long c2 = tick();
+        pc[16] = (c2 - c0) + 0 * c1;
+        pc[17] = 1;
+    }
     const unsigned long long t_birth = tick();
 
     const int64_t t0 = a.wbegin + (int64_t)tile * kT;
@@ -1456,9 +1469,10 @@ __global__ __launch_bounds__(NW * 64, 8) void k_ext_staged(LblArgs a)
         const unsigned long long t_end = tick();
         pc[14] += t_end - t_out;
         pc[9] = t_end - t_birth;
+        pc[15] = (unsigned long long)__builtin_amdgcn_s_memrealtime() - real_birth;
         if (lane == 0 && a.probe)
-            for (int i = 0; i < 15; i++)
-                atomicAdd(&a.probe[(int64_t)layer * 16 + i], pc[i]);
+            for (int i = 0; i < 18; i++)
+                atomicAdd(&a.probe[(int64_t)layer * 20 + i], pc[i]);
     }
 }
 
@@ -3899,8 +3913,8 @@ static int lbl_extinction(pb_lbl *p, double *ext_d, int64_t wbegin, int64_t wcou
                                       : k_ext_staged<kStagedWaves, 2, true, 3>;
             if (atoi(e) == 4 && S == 2 && dma) {                  // the cycle account (valid sums)
                 kern = k_ext_staged<kStagedWaves, 2, true, 4>;
-                PB_HIP(hipMalloc(&probe_d, (size_t)nlayers * 16 * 8));
-                PB_HIP(hipMemsetAsync(probe_d, 0, (size_t)nlayers * 16 * 8, s));
+                PB_HIP(hipMalloc(&probe_d, (size_t)nlayers * 20 * 8));
+                PB_HIP(hipMemsetAsync(probe_d, 0, (size_t)nlayers * 20 * 8, s));
                 a.probe = probe_d;
             }
         }
@@ -3920,7 +3934,7 @@ static int lbl_extinction(pb_lbl *p, double *ext_d, int64_t wbegin, int64_t wcou
 #ifdef PB_EXPERIMENTS
         if (probe_d) {
             // one line per layer on stderr: layer, rowmax of its first isotope, then the 15 sums
-            std::vector<unsigned long long> h((size_t)nlayers * 16);
+            std::vector<unsigned long long> h((size_t)nlayers * 20);
             PB_HIP(hipMemcpyAsync(h.data(), probe_d, h.size() * 8, hipMemcpyDeviceToHost, s));
             std::vector<int32_t> rowmax((size_t)nlayers * a.niso);
             PB_HIP(hipMemcpyAsync(rowmax.data(), a.li_rowmax, rowmax.size() * 4,
@@ -3931,8 +3945,8 @@ static int lbl_extinction(pb_lbl *p, double *ext_d, int64_t wbegin, int64_t wcou
             for (int layer = 0; layer < nlayers; layer++) {
                 fprintf(stderr, "STAGE_PROBE layer %d rowmax %d :", layer,
                         rowmax[(size_t)layer * a.niso]);
-                for (int i = 0; i < 15; i++)
-                    fprintf(stderr, " %llu", h[(size_t)layer * 16 + i]);
+                for (int i = 0; i < 18; i++)
+                    fprintf(stderr, " %llu", h[(size_t)layer * 20 + i]);
                 fprintf(stderr, "\n");
             }
         }

@@ -80,25 +80,31 @@ def main():
     info, rows = run_child(name, steps, True)
     nl = info['nlayers']
     import numpy as np
-    data = np.zeros((nl, 15))
+    data = np.zeros((nl, 18))
     rowmax = np.zeros(nl, int)
     for r in rows:                       # STAGE_PROBE layer L rowmax R : v0 ... v14  (summed over launches)
         layer = int(r[2])
         rowmax[layer] = int(r[4])
-        data[layer] += np.array([float(x) for x in r[6:21]])
+        data[layer] += np.array([float(x) for x in r[6:24]])
     data /= steps
-    # ticks -> core cycles: the wavefronts' summed lifetime against the kernel's wall time.
-    # 8 wavefronts x workgroups in flight: calibrate instead on the tick rate = 100 MHz (s_memtime
-    # on gfx950 counts the constant reference clock) and the shader clock the run held
-    tick_ns = 10.0
+    # calibration from the probe itself: s_memtime ticks per 10-ns tick of the 100-MHz wall clock
+    # (s_memrealtime), both taken over every wavefront's lifetime; the cost of one stamp with an
+    # empty LDS queue (two back-to-back intervals per wavefront)
+    ticks_per_10ns = data[:, 9].sum() / data[:, 15].sum()
+    tick_ns = 10.0 / ticks_per_10ns
+    ghz = float(os.environ.get('PB_SCLK_GHZ', '2.4'))
+    cyc = tick_ns * ghz                                   # shader cycles per s_memtime tick
+    stamp = data[:, 16].sum() / (2 * data[:, 17].sum())   # ticks per stamp
     classes = [('rows <= 384 samples', rowmax <= 384), ('rows 385 ... 768', (rowmax > 384) & (rowmax <= 768)),
                ('rows > 768', rowmax > 768), ('all layers', rowmax >= 0)]
     print(f'# Cycle account of `k_ext_staged`, workload {name}\n')
     print(f'* un-instrumented kernel: {plain["gather_ms"]:.3f} ms per launch ({plain["kernel"]}); '
           f'with the probe (stamps drain the LDS queue): {info["gather_ms"]:.3f} ms')
-    print(f'* s_memtime ticks of {tick_ns:.0f} ns (100 MHz reference clock); at the 2.4 GHz the '
-          'run held one tick = 24 shader cycles.  All figures are sums over the wavefronts of a '
-          'launch, averaged over the launches.')
+    print(f'* clock: {ticks_per_10ns:.3f} s_memtime ticks per 10 ns of s_memrealtime = one tick is '
+          f'{tick_ns:.3f} ns = {cyc:.2f} shader cycles at {ghz} GHz.  One stamp (s_memtime + '
+          f's_waitcnt lgkmcnt(0)) with an empty LDS queue costs {stamp:.1f} ticks = '
+          f'{stamp * cyc:.0f} cycles; every category of a step below CONTAINS one stamp.  All '
+          'figures are sums over the wavefronts of a launch, averaged over the launches.')
     w = info.get('work') or {}
     if w:
         print(f"* work of the launch: {w['live_records']} live records, "
@@ -121,18 +127,25 @@ def main():
         cells.append(f'{100 * rest / life:.1f} %' if life > 0 else '-')
     print('| not stamped (loop control, stamps themselves) | ' + ' | '.join(cells) + ' |')
     print()
-    print('| per segment step and wavefront | ' + ' | '.join(c for c, _ in classes) + ' |')
+    print('| per segment step and wavefront (one stamp subtracted from each line) | ' +
+          ' | '.join(c for c, _ in classes) + ' |')
     print('|---|' + '---|' * len(classes))
 
     def per_step(c, m):
         st = data[m, 10].sum()
-        return data[m, c].sum() / st * tick_ns * 2.4 if st > 0 else float('nan')
+        return (data[m, c].sum() / st - stamp) * cyc if st > 0 else float('nan')
     for label, c in (('walk, cycles', 5), ('barrier wait, cycles', 7), ('DMA wait, cycles', 6),
-                     ('DMA issue (averaged over the 8 wavefronts), cycles', 4),
-                     ('find_hits (amortised), cycles', 3)):
+                     ('DMA issue (averaged over the 8 wavefronts: one of them issues), cycles', 4)):
         print(f'| {label} | ' + ' | '.join(f'{per_step(c, m):.0f}' for _, m in classes) + ' |')
-    print('| whole step (the four above + find_hits), cycles | ' +
-          ' | '.join(f'{sum(per_step(c, m) for c in (3, 4, 5, 6, 7)):.0f}' for _, m in classes) + ' |')
+    print('| find_hits (amortised over its 64 steps), cycles | ' +
+          ' | '.join(f'{data[m, 3].sum() / max(data[m, 10].sum(), 1) * cyc:.0f}' for _, m in classes) + ' |')
+    print('| whole step without the stamps, cycles | ' +
+          ' | '.join(f'{sum(per_step(c, m) for c in (4, 5, 6, 7)) + data[m, 3].sum() / max(data[m, 10].sum(), 1) * cyc:.0f}'
+                     for _, m in classes) + ' |')
+    print('| un-instrumented: kernel time x wavefront slots / steps, cycles | ' +
+          ' | '.join('-' if i < len(classes) - 1 else
+                     f'{plain["gather_ms"] * 1e-3 * 256 * 32 * ghz * 1e9 / max(data[:, 10].sum(), 1):.0f} (slots 100 % busy)'
+                     for i in range(len(classes))) + ' |')
     print('| layers | ' + ' | '.join(str(int(m.sum())) for _, m in classes) + ' |')
     print('| steps per (tile, wavefront) launch-wide: steps | ' +
           ' | '.join(f'{data[m, 10].sum():.3g}' for _, m in classes) + ' |')
@@ -143,7 +156,7 @@ def main():
     print('| records per batch of 512 slots: batches | ' +
           ' | '.join(f'{data[m, 11].sum() / 8:.3g}' for _, m in classes) + ' |')
     print()
-    print('Raw per-layer sums (ticks per launch): layer, rowmax, ' + ', '.join(str(i) for i in range(15)))
+    print('Raw per-layer sums (ticks per launch): layer, rowmax, ' + ', '.join(str(i) for i in range(18)))
     for layer in range(nl):
         print(f'    {layer} {rowmax[layer]} ' + ' '.join(f'{v:.0f}' for v in data[layer]))
 
