@@ -181,7 +181,7 @@ struct LblArgs {
     int ntiles;
     int experiment;      // diagnostics only (PB_EXPERIMENT): 1 = every record reads one slice
     // cycle account of the staged kernel (experiments build, PB_STAGE_PROBE=4): s_memtime ticks per
-    // category and layer, probe[layer * 20 + category] (see k_ext_staged); null otherwise
+    // category and layer, probe[layer * 24 + category] (see k_ext_staged); null otherwise
     unsigned long long *probe;
     double *ext;
     // round-staged gather (pb_rounds.hip): tile and LDS row buffer (samples), the largest

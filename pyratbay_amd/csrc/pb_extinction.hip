@@ -795,7 +795,7 @@ __global__ __launch_bounds__(kBlock) void k_records(LblArgs a)
 // 3 = (valid results) the remainder records of a visit loop software-pipelined;
 // 4 = (valid results) the CYCLE ACCOUNT of a segment step: every
 //     wavefront stamps s_memtime around the parts of its work and adds the differences, per layer,
-//     to a.probe[layer * 20 + c]:  c = 0 candidate search and scans of an isotope, 1 record
+//     to a.probe[layer * 24 + c]:  c = 0 candidate search and scans of an isotope, 1 record
 //     fetch + decode of a batch (with its barriers), 2 segment detection + segment table (three
 //     barriers), 3 find_hits (two bisections for 64 segments at once), 4 issue of a row's LDS-DMA
 //     (the one wavefront whose turn it is), 5 the walk (hit decode, record broadcasts, row reads,
@@ -804,10 +804,18 @@ __global__ __launch_bounds__(kBlock) void k_records(LblArgs a)
 //     lifetime, 10 segment steps, 11 batches, 12 (record, sub-tile) visits of this wavefront,
 //     13 steps in which it visited anything, 14 accumulator read / write-back; calibration:
 //     15 the lifetime on the 100-MHz wall clock (s_memrealtime), 16 two back-to-back stamp
-//     intervals with an empty LDS queue, 17 wavefronts.
+//     intervals with an empty LDS queue, 17 wavefronts, 18 the interval of category 4 in the
+//     wavefronts that did NOT request a row (a stamp right after a barrier release), 19 rows
+//     requested, 20 the part of category 4 up to the first load (descriptor read + decode).
 //     A stamp is s_memtime + s_waitcnt lgkmcnt(0): it also drains the LDS queue, which is why
 //     the probe is not the product kernel (profiles/r05_step_account.md gives both times).
-template <int NW, int S, bool kDma, int kProbe = 0>
+// kIssue (kDma only): who requests a row's LDS-DMA.  0 = ONE wavefront per segment, the wavefronts
+// taking turns, descriptor read and decoded at the time of the request (rounds 2-4); 1 = the same
+// with the wavefront's NEXT descriptor fetched from LDS one turn (8 steps) ahead; 2 = EVERY
+// wavefront requests its own 128-sample slice of the row (one load each), from a descriptor it
+// fetched one step ahead.  Why: the cycle account (profiles/r05_step_account.md) shows the
+// requesting wavefront ~700 cycles behind its peers in every step, who wait for it at the barrier.
+template <int NW, int S, bool kDma, int kProbe = 0, int kIssue = 0>
 __global__ __launch_bounds__(NW * 64, 8) void k_ext_staged(LblArgs a)
 {
     constexpr int kThreads = NW * 64;
@@ -875,7 +883,7 @@ __global__ __launch_bounds__(NW * 64, 8) void k_ext_staged(LblArgs a)
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    unsigned long long pc[18] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long pc[21] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     auto tick = [&]() -> unsigned long long {
         if constexpr (kProbe == 4)
             return (unsigned long long)__builtin_amdgcn_s_memtime();
@@ -944,8 +952,14 @@ __global__ __launch_bounds__(NW * 64, 8) void k_ext_staged(LblArgs a)
     // records' offsets account for -- and no lane straddles the lower edge).  The
     // instruction is issued from inline asm: the compiler would otherwise drain it
     // (vmcnt(0)) before the next LDS read; the wait before the barrier is explicit.
-    auto dma_row = [&](int sg, int buf) {
-        const unsigned long long d = s_desc[sg];
+    // LDS byte address of row buffer 0 (taken once: the flat -> LDS cast of a pointer the compiler
+    // cannot prove non-null costs a compare per use, and trips a register-class bug of this
+    // compiler when the lambda below is instantiated for several call sites)
+    const unsigned row_lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char *)(
+        reinterpret_cast<char *>(s_row + kStagePad));
+    // (tref, probe 4: the stamp that opened the step -- the descriptor chain is timed against it)
+    auto dma_desc = [&](unsigned long long d, int buf, int c_lo, int c_hi,
+                        unsigned long long tref = 0) {
         const unsigned dlo = (unsigned)__builtin_amdgcn_readfirstlane((int)d);
         const unsigned dhi = (unsigned)__builtin_amdgcn_readfirstlane((int)(d >> 32));
         const long long first = ((long long)(dhi & 0xffu) << 32) | dlo;
@@ -958,10 +972,14 @@ __global__ __launch_bounds__(NW * 64, 8) void k_ext_staged(LblArgs a)
         rsrc.z = __builtin_amdgcn_readfirstlane(len * 8);
         rsrc.w = 0x00020000;
         int voff = (2 * lane - (mlo & ~1)) * 8;
-        unsigned dst = (unsigned)(size_t)(__attribute__((address_space(3))) char *)(
-            reinterpret_cast<char *>(s_row + kStagePad + buf * rowspan));
-        dst = (unsigned)__builtin_amdgcn_readfirstlane((int)dst);
-        for (int c = 0; c * 128 < rowlim; c++) {
+        unsigned dst = (unsigned)__builtin_amdgcn_readfirstlane((int)(row_lds0 + buf * rowspan * 8));
+        if constexpr (kProbe == 4) {
+            if (tref)
+                pc[20] += tick() - tref;
+        }
+        voff += 1024 * c_lo;
+        dst += 1024 * (unsigned)c_lo;
+        for (int c = c_lo; c < c_hi && c * 128 < rowlim; c++) {
             unsigned keep;
             asm volatile("s_nop 4\n\t"
                          "s_mov_b32 %0, m0\n\t"
@@ -975,6 +993,9 @@ __global__ __launch_bounds__(NW * 64, 8) void k_ext_staged(LblArgs a)
             voff += 1024;
             dst += 1024;
         }
+    };
+    auto dma_row = [&](int sg, int buf, unsigned long long tref = 0) {
+        dma_desc(s_desc[sg], buf, 0, 1 << 20, tref);
     };
     // out-of-window lanes fall outside the buffer descriptor and read 0 (no predicate)
     auto load_row = [&](int sg, auto Rc, double *reg) {
@@ -1414,6 +1435,43 @@ __global__ __launch_bounds__(NW * 64, 8) void k_ext_staged(LblArgs a)
                 // while sg is walked, and has landed before the barrier that ends the step.
                 // (Three buffers and a request two steps ahead measured slower, 1.22 vs 1.14 ms
                 // at C2: 48 KB of LDS leave three workgroups per CU.)
+                if constexpr (kIssue == 1) {
+                    // the turn-taking requester with its next descriptor fetched a turn ahead
+                    unsigned long long dn = s_desc[min(nseg - 1, wave == 0 ? NW : wave)];
+                    if (wave == 0)
+                        dma_row(0, 0);
+                    __builtin_amdgcn_s_waitcnt(0x0f70);
+                    __syncthreads();
+                    for (int sg = 0; sg < nseg; sg++) {
+                        if (sg + 1 < nseg && wave == ((sg + 1) & (NW - 1))) {
+                            dma_desc(dn, (sg + 1) & 1, 0, 1 << 20);
+                            dn = s_desc[min(nseg - 1, sg + 1 + NW)];
+                        }
+                        walk(sg, sg & 1);
+                        __builtin_amdgcn_s_waitcnt(0x0f70);
+                        __syncthreads();
+                    }
+                    continue;
+                }
+                if constexpr (kIssue == 2) {
+                    // every wavefront requests its own slices of the row (8 slices of 128 samples
+                    // over NW wavefronts) from a descriptor it fetched one step ahead
+                    constexpr int kPer = (8 + NW - 1) / NW;
+                    unsigned long long dn = s_desc[min(nseg - 1, 1)];
+                    dma_desc(s_desc[0], 0, wave * kPer, wave * kPer + kPer);
+                    __builtin_amdgcn_s_waitcnt(0x0f70);
+                    __syncthreads();
+                    for (int sg = 0; sg < nseg; sg++) {
+                        const unsigned long long dcur = dn;
+                        dn = s_desc[min(nseg - 1, sg + 2)];
+                        if (sg + 1 < nseg)
+                            dma_desc(dcur, (sg + 1) & 1, wave * kPer, wave * kPer + kPer);
+                        walk(sg, sg & 1);
+                        __builtin_amdgcn_s_waitcnt(0x0f70);
+                        __syncthreads();
+                    }
+                    continue;
+                }
                 unsigned long long ta = tick();
                 if (wave == 0)
                     dma_row(0, 0);
@@ -1426,10 +1484,17 @@ __global__ __launch_bounds__(NW * 64, 8) void k_ext_staged(LblArgs a)
                 }
                 for (int sg = 0; sg < nseg; sg++) {
                     if (sg + 1 < nseg && wave == ((sg + 1) & (NW - 1)))
-                        dma_row(sg + 1, (sg + 1) & 1);
+                        dma_row(sg + 1, (sg + 1) & 1, ta);
                     if constexpr (kProbe == 4) {
                         const unsigned long long tb = tick();
-                        pc[4] += tb - ta;
+                        // (4: the wavefront whose turn it was to request the row; 18: the others,
+                        // i.e. the cost of the stamp itself right after a barrier release)
+                        if (sg + 1 < nseg && wave == ((sg + 1) & (NW - 1))) {
+                            pc[4] += tb - ta;
+                            pc[19] += 1;
+                        } else {
+                            pc[18] += tb - ta;
+                        }
                         ta = tb;
                         const unsigned long long f0 = pc[3];
                         walk(sg, sg & 1);
@@ -1471,8 +1536,8 @@ __global__ __launch_bounds__(NW * 64, 8) void k_ext_staged(LblArgs a)
         pc[9] = t_end - t_birth;
         pc[15] = (unsigned long long)__builtin_amdgcn_s_memrealtime() - real_birth;
         if (lane == 0 && a.probe)
-            for (int i = 0; i < 18; i++)
-                atomicAdd(&a.probe[(int64_t)layer * 20 + i], pc[i]);
+            for (int i = 0; i < 21; i++)
+                atomicAdd(&a.probe[(int64_t)layer * 24 + i], pc[i]);
     }
 }
 
@@ -3911,10 +3976,13 @@ static int lbl_extinction(pb_lbl *p, double *ext_d, int64_t wbegin, int64_t wcou
                 kern = atoi(e) == 1   ? k_ext_staged<kStagedWaves, 2, true, 1>
                        : atoi(e) == 2 ? k_ext_staged<kStagedWaves, 2, true, 2>
                                       : k_ext_staged<kStagedWaves, 2, true, 3>;
+            if (atoi(e) >= 11 && atoi(e) <= 12 && S == 2 && dma)  // 11, 12: who requests the row DMA
+                kern = atoi(e) == 11 ? k_ext_staged<kStagedWaves, 2, true, 0, 1>
+                                     : k_ext_staged<kStagedWaves, 2, true, 0, 2>;
             if (atoi(e) == 4 && S == 2 && dma) {                  // the cycle account (valid sums)
                 kern = k_ext_staged<kStagedWaves, 2, true, 4>;
-                PB_HIP(hipMalloc(&probe_d, (size_t)nlayers * 20 * 8));
-                PB_HIP(hipMemsetAsync(probe_d, 0, (size_t)nlayers * 20 * 8, s));
+                PB_HIP(hipMalloc(&probe_d, (size_t)nlayers * 24 * 8));
+                PB_HIP(hipMemsetAsync(probe_d, 0, (size_t)nlayers * 24 * 8, s));
                 a.probe = probe_d;
             }
         }
@@ -3934,7 +4002,7 @@ static int lbl_extinction(pb_lbl *p, double *ext_d, int64_t wbegin, int64_t wcou
 #ifdef PB_EXPERIMENTS
         if (probe_d) {
             // one line per layer on stderr: layer, rowmax of its first isotope, then the 15 sums
-            std::vector<unsigned long long> h((size_t)nlayers * 20);
+            std::vector<unsigned long long> h((size_t)nlayers * 24);
             PB_HIP(hipMemcpyAsync(h.data(), probe_d, h.size() * 8, hipMemcpyDeviceToHost, s));
             std::vector<int32_t> rowmax((size_t)nlayers * a.niso);
             PB_HIP(hipMemcpyAsync(rowmax.data(), a.li_rowmax, rowmax.size() * 4,
@@ -3945,8 +4013,8 @@ static int lbl_extinction(pb_lbl *p, double *ext_d, int64_t wbegin, int64_t wcou
             for (int layer = 0; layer < nlayers; layer++) {
                 fprintf(stderr, "STAGE_PROBE layer %d rowmax %d :", layer,
                         rowmax[(size_t)layer * a.niso]);
-                for (int i = 0; i < 18; i++)
-                    fprintf(stderr, " %llu", h[(size_t)layer * 20 + i]);
+                for (int i = 0; i < 21; i++)
+                    fprintf(stderr, " %llu", h[(size_t)layer * 24 + i]);
                 fprintf(stderr, "\n");
             }
         }

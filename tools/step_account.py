@@ -80,12 +80,12 @@ def main():
     info, rows = run_child(name, steps, True)
     nl = info['nlayers']
     import numpy as np
-    data = np.zeros((nl, 18))
+    data = np.zeros((nl, 21))
     rowmax = np.zeros(nl, int)
     for r in rows:                       # STAGE_PROBE layer L rowmax R : v0 ... v14  (summed over launches)
         layer = int(r[2])
         rowmax[layer] = int(r[4])
-        data[layer] += np.array([float(x) for x in r[6:24]])
+        data[layer] += np.array([float(x) for x in r[6:27]])
     data /= steps
     # calibration from the probe itself: s_memtime ticks per 10-ns tick of the 100-MHz wall clock
     # (s_memrealtime), both taken over every wavefront's lifetime; the cost of one stamp with an
@@ -113,6 +113,7 @@ def main():
     hdr = '| part of a wavefront\'s lifetime | ' + ' | '.join(c for c, _ in classes) + ' |'
     print(hdr)
     print('|---|' + '---|' * len(classes))
+    data[:, 4] += data[:, 18]            # (shares: requesting and non-requesting wavefronts together)
     order = [5, 7, 6, 4, 3, 1, 2, 8, 0, 14]
     for c in order:
         cells = []
@@ -135,8 +136,17 @@ def main():
         st = data[m, 10].sum()
         return (data[m, c].sum() / st - stamp) * cyc if st > 0 else float('nan')
     for label, c in (('walk, cycles', 5), ('barrier wait, cycles', 7), ('DMA wait, cycles', 6),
-                     ('DMA issue (averaged over the 8 wavefronts: one of them issues), cycles', 4)):
+                     ('DMA issue slot (all 8 wavefronts averaged), cycles', 4)):
         print(f'| {label} | ' + ' | '.join(f'{per_step(c, m):.0f}' for _, m in classes) + ' |')
+    # the requesting wavefront against the others (whose interval holds nothing but the stamp)
+    print('| ... of which: the wavefront that requests the row, cycles per request | ' +
+          ' | '.join(f'{((data[m, 4].sum() - data[m, 18].sum()) / max(data[m, 19].sum(), 1) - stamp) * cyc:.0f}'
+                     for _, m in classes) + ' |')
+    print('| ...... its descriptor chain (LDS read of the descriptor, readfirstlanes) up to the first load | ' +
+          ' | '.join(f'{(data[m, 20].sum() / max(data[m, 19].sum(), 1)) * cyc:.0f}' for _, m in classes) + ' |')
+    print('| ... the other seven (a stamp right after the barrier release), cycles | ' +
+          ' | '.join(f'{(data[m, 18].sum() / max(data[m, 10].sum() - data[m, 19].sum(), 1) - stamp) * cyc:.0f}'
+                     for _, m in classes) + ' |')
     print('| find_hits (amortised over its 64 steps), cycles | ' +
           ' | '.join(f'{data[m, 3].sum() / max(data[m, 10].sum(), 1) * cyc:.0f}' for _, m in classes) + ' |')
     print('| whole step without the stamps, cycles | ' +
@@ -156,7 +166,7 @@ def main():
     print('| records per batch of 512 slots: batches | ' +
           ' | '.join(f'{data[m, 11].sum() / 8:.3g}' for _, m in classes) + ' |')
     print()
-    print('Raw per-layer sums (ticks per launch): layer, rowmax, ' + ', '.join(str(i) for i in range(18)))
+    print('Raw per-layer sums (ticks per launch): layer, rowmax, ' + ', '.join(str(i) for i in range(21)))
     for layer in range(nl):
         print(f'    {layer} {rowmax[layer]} ' + ' '.join(f'{v:.0f}' for v in data[layer]))
 
