@@ -470,6 +470,33 @@ int pb_transit_spectrum_ordered(double *spectrum_d, const double *ec_d, const do
                                 const double *radius_d, const int32_t *column_d, double rstar,
                                 int itop, int ibottom, double maxdepth, int nlayers, int nwave,
                                 int nwalkers, void *work_d, void *stream);
+/* The same two passes without the layers nobody reads.  With the columns in the depth order of a
+ * base model, tile_limit_d[ceil(nwave / 256)] names for every block of 256 (ordered) columns the
+ * last ROW TILE (16 impact parameters; tile m = layers itop + 16 m ... itop + 16 m + 15) any of
+ * its columns is expected to need (the base model's deepest first crossing of maxdepth in the
+ * block, _trapezoid.c:259-273, plus a margin):
+ *   pb_interp_ec_batch_limited writes ec only for the layers row0 ... row0 + 16 (tile + 1) - 1 of
+ *     a block (row0 = itop; the other elements of ec_d are left as they are);
+ *   pb_transit_spectrum_limited stops a wavefront whose columns are still open beyond their
+ *     block's tile, leaves their spectrum samples unwritten and sets flags_d[walker] = 1 and
+ *     flags_d[nwalkers] = 1 (int32[nwalkers + 1], zeroed by the caller).
+ * Repair without a host round trip: the same two calls again with tile_limit_d = NULL and
+ *   gate_d = flags_d + nwalkers (interpolation: every workgroup returns at once unless *gate_d != 0;
+ *     the per-walker weights in work_d are those of the first call) resp.
+ *   gate_d = flags_d (transit: walker w is computed only if gate_d[w] != 0; the Q blocks in work_d
+ *     are those of the first call).
+ * The spectra are then bit-identical to pb_interp_ec_batch + pb_transit_spectrum_ordered whatever
+ * the limits were (tests/test_gpu_batch.py::test_tile_limited_batch). */
+int pb_interp_ec_batch_limited(double *ec_d, const double *etable_d, const double *ttable_d,
+                               const double *temps_d, const double *density_d, void *work_d,
+                               int nmol, int ntemp, int nlayers, int nwave, int nwalkers,
+                               const int32_t *tile_limit_d, int row0, const int32_t *gate_d,
+                               void *stream);
+int pb_transit_spectrum_limited(double *spectrum_d, const double *ec_d, const double *raypath_d,
+                                const double *radius_d, const int32_t *column_d, double rstar,
+                                int itop, int ibottom, double maxdepth, int nlayers, int nwave,
+                                int nwalkers, void *work_d, const int32_t *tile_limit_d,
+                                int32_t *flags_d, const int32_t *gate_d, void *stream);
 /* Emission geometry for a batch: plane_parallel_optical_depth (src_c/_trapezoid.c:175-213) +
  * blackbody + intensity + quadrature sum (pyrat/spectrum.py:366-377) in one pass, no cloud deck:
  * ec_d[nwalkers,nlayers,nwave], intervals_d[nwalkers,nlayers-1], temp_d[nwalkers,nlayers] ->

@@ -89,6 +89,47 @@ __global__ __launch_bounds__(kBlock) void k_iso_partition(
 }
 
 // ---------------------------------------------------------------------------
+// Layers nobody reads (round 5).  With the columns of a retrieval batch in the depth order of a base
+// model (TableSpectrum.order_columns) the row tile at which the transit kernel leaves a column is
+// known in advance to within a layer or two: tile[b] = the last ROW TILE (16 impact parameters)
+// the columns 256 b ... 256 b + 255 can need (base model's deepest crossing in the block + a
+// margin).  The interpolation then writes the layers row0 ... row0 + 16 (tile[b] + 1) - 1 only
+// (at C5's shape 80 % of ec: 0.8 GB of 4.1 GB per 64 walkers less), and the transit kernel, should
+// a walker's column still be open beyond that tile, raises flags[walker] and flags[nwalkers]
+// instead of reading what was never written.  `gate` (repair pass): a launch whose workgroups
+// return at once unless the flag it points to is set -- the full interpolation gated on
+// flags[nwalkers], the transit of walker w gated on flags[w] -- so the repair costs two nearly
+// empty launches when nothing was flagged, and no host synchronisation ever.
+// ---------------------------------------------------------------------------
+struct TileLimit {
+    const int32_t *tile;      // [ceil(nwave / 256)] last row tile available, or null: every layer
+    int row0;                 // itop: layers above it are not read by the transit pass either
+    const int32_t *gate;      // null, or: run only if *gate != 0 (interp) / gate[walker] != 0 (transit)
+};
+
+__device__ __forceinline__ int uniform_i32(const int32_t *p)
+{
+    typedef const int32_t __attribute__((address_space(4))) *cptr;
+    return *((cptr)(unsigned long long)p);
+}
+
+// is layer k of the samples [s0, s1) wanted?  (wave-uniform)
+__device__ __forceinline__ bool layer_wanted(const TileLimit &lim, int k, int s0, int s1, int nwave)
+{
+    if (lim.gate && uniform_i32(lim.gate) == 0)
+        return false;
+    if (!lim.tile)
+        return true;
+    if (k < lim.row0)
+        return false;
+    const int b1 = (min(s1, nwave) - 1) >> 8;
+    int t = 0;
+    for (int b = max(s0, 0) >> 8; b <= b1; b++)
+        t = max(t, uniform_i32(lim.tile + b));
+    return k <= lim.row0 + 16 * (t + 1) - 1;
+}
+
+// ---------------------------------------------------------------------------
 // interp_ec for a batch of walkers, assigning form.  Workgroup = (256 wavenumbers, layer,
 // chunk of walkers).  Walkers of a chunk that share a temperature bracket share its two table
 // slices: the brackets the chunk uses at this layer are walked in ascending order, the upper
@@ -126,8 +167,10 @@ __global__ __launch_bounds__(kBlock) void k_interp_weights(
 template <int kS, bool kFull>
 __global__ __launch_bounds__(kBlock) void k_interp_ec_batch(
     double *ec, const double *etable, const int32_t *tlo, const double *coef, int nmol,
-    int ntemp, int nlayers, int nwave, int nwalkers, int chunk)
+    int ntemp, int nlayers, int nwave, int nwalkers, int chunk, TileLimit lim)
 {
+    if (!layer_wanted(lim, blockIdx.y, blockIdx.x * kBlock, blockIdx.x * kBlock + kBlock, nwave))
+        return;
     // per-(walker, layer) brackets and coefficients are wave-uniform: through the constant
     // address space they are SCALAR loads (one s_load_dwordx16 per walker at four species)
     typedef const double __attribute__((address_space(4))) *ccoef_t;
@@ -184,8 +227,12 @@ __global__ __launch_bounds__(kBlock) void k_interp_ec_batch(
 template <int kS, bool kFull, int NP>
 __global__ __launch_bounds__(kBlock) void k_interp_ec_batch2(
     double *ec, const double *etable, const int32_t *tlo, const double *coef, int nmol,
-    int ntemp, int nlayers, int nwave, int nwalkers, int chunk)
+    int ntemp, int nlayers, int nwave, int nwalkers, int chunk, TileLimit lim)
 {
+    // (slots [x NP kBlock, (x + 1) NP kBlock) hold the samples 2 q - 1 ... 2 q + 1)
+    if (!layer_wanted(lim, blockIdx.y, 2 * (int)blockIdx.x * NP * kBlock - 1,
+                      2 * ((int)blockIdx.x + 1) * NP * kBlock + 1, nwave))
+        return;
     typedef const double __attribute__((address_space(4))) *ccoef_t;
     typedef const int32_t __attribute__((address_space(4))) *ctlo_t;
     typedef double d2 __attribute__((ext_vector_type(2)));
@@ -850,10 +897,12 @@ template <int MT, int WPS, int TB>
 __global__ __launch_bounds__(TB, WPS) void k_transit_mfma_rows(
     double *spectrum, const double *ec, const double *qblk, const double *radius, int nblk,
     double rstar, int itop, int ibottom, double maxdepth, int nlayers, int nwave,
-    const int32_t *scatter)
+    const int32_t *scatter, TileLimit lim, int32_t *flags)
 {
     extern __shared__ __align__(16) double s_q[];         // [nblk][64] | rad[16 MT]
     const int w = blockIdx.y;
+    if (lim.gate && uniform_i32(lim.gate + w) == 0)
+        return;                                           // (repair pass: walker w was not flagged)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nimpact = min(ibottom, nlayers) - itop;
     double *s_rad = s_q + (size_t)nblk * 64;
@@ -891,11 +940,19 @@ __global__ __launch_bounds__(TB, WPS) void k_transit_mfma_rows(
     double acc[2] = {0.0, 0.0}, carry[2] = {0.0, 0.0};
     const double *sq = s_q + lane;
     bool done = false;
+    // the last row tile whose layers were interpolated for these 32 columns (TileLimit)
+    const int mlim = lim.tile ? uniform_i32(lim.tile + (c0 >> 8)) : MT;
+    bool overrun = false;
     loadb(std::integral_constant<int, 0>{});
     auto tile = [&](auto mc) {
         constexpr int m = decltype(mc)::value;
         if (done || 4 * m >= KS)                          // uniform
             return;
+        if (m > mlim) {                                   // uniform: a column is still open beyond
+            overrun = true;                               // what was interpolated -> repair pass
+            done = true;
+            return;
+        }
         // the next tile's layers are requested before this tile's products (two tiles ahead:
         // measured slower, 1.27 against 1.16 ms at C5's shape -- the loads an exit wastes)
         if constexpr (m + 1 < MT)                         // (clamped rows: harmless past the end)
@@ -967,6 +1024,13 @@ __global__ __launch_bounds__(TB, WPS) void k_transit_mfma_rows(
     if constexpr (MT > 5) tile(std::integral_constant<int, 5>{});
     if constexpr (MT > 6) tile(std::integral_constant<int, 6>{});
     if constexpr (MT > 7) tile(std::integral_constant<int, 7>{});
+    if (overrun) {
+        if (lane == 0 && flags) {
+            flags[w] = 1;
+            flags[gridDim.y] = 1;                         // flags[nwalkers]: any walker
+        }
+        return;                                           // (the repair pass writes these columns)
+    }
 #pragma unroll
     for (int t = 0; t < 2; t++) {
         double a = acc[t];
@@ -1689,8 +1753,10 @@ int pb_transit_fused_launch(double *depth_d, int32_t *ideep_d, double *spectrum_
                             const double *ec_d, const double *raypath_d, const double *radius_d,
                             int64_t npath, double rstar, int itop, int ibottom, double maxdepth,
                             int nlayers, int nwave, int nwalkers, int deck_row, double rsurf,
-                            hipStream_t s, double *work_d, const int32_t *scatter_d)
+                            hipStream_t s, double *work_d, const int32_t *scatter_d,
+                            const int32_t *tile_limit_d, int32_t *flags_d, const int32_t *gate_d)
 {
+    const TileLimit lim{tile_limit_d, itop, gate_d};
     const int nrow = nlayers - itop;
     const int nimpact = std::min(ibottom, nlayers) - itop;
 #ifdef PB_EXPERIMENTS
@@ -1730,8 +1796,10 @@ int pb_transit_fused_launch(double *depth_d, int32_t *ideep_d, double *spectrum_
             nimpact > 1 && mt <= 8 && nwave >= 2 && nwalkers >= 1) {
             const int nblk = qblocks(mt);
             dim3 qgrid((unsigned)std::min(16, pb::div_up((int64_t)nblk * 64, kBlock)), nwalkers);
-            k_path_qblocks<<<qgrid, kBlock, 0, s>>>(work_d, raypath_d, npath, nblk, nimpact);
-            PB_LAUNCH_CHECK();
+            if (!gate_d) {      // (a gated repair pass re-uses the Q blocks of its first pass)
+                k_path_qblocks<<<qgrid, kBlock, 0, s>>>(work_d, raypath_d, npath, nblk, nimpact);
+                PB_LAUNCH_CHECK();
+            }
             const size_t lds = ((size_t)nblk * 64 + (size_t)mt * 16) * 8;
 #ifdef PB_EXPERIMENTS
 #define PB_MFMA(M, W, T)                                                                         \
@@ -1764,7 +1832,8 @@ int pb_transit_fused_launch(double *depth_d, int32_t *ideep_d, double *spectrum_
         dim3 mgrid(pb::div_up(nwave, (T / 64) * 32), nwalkers);                                  \
         k_transit_mfma_rows<M, W, T><<<mgrid, T, lds, s>>>(spectrum_d, ec_d, work_d, radius_d,   \
                                                           nblk, rstar, itop, ibottom, maxdepth,  \
-                                                          nlayers, nwave, scatter_d);            \
+                                                          nlayers, nwave, scatter_d, lim,        \
+                                                          flags_d);                              \
     } while (0)
                 switch (mt) {
                 case 1: PB_MFMA_ROWS(1, 4, 256); break;
@@ -1919,9 +1988,35 @@ int pb_iso_partition(double *z_d, int64_t z_iso_stride, int64_t z_t_stride,
     return PB_OK;
 }
 
+static int interp_ec_batch_launch(double *ec_d, const double *etable_d, const double *ttable_d,
+                                  const double *temps_d, const double *density_d, void *work_d,
+                                  int nmol, int ntemp, int nlayers, int nwave, int nwalkers,
+                                  TileLimit lim, void *stream);
+
 int pb_interp_ec_batch(double *ec_d, const double *etable_d, const double *ttable_d,
                        const double *temps_d, const double *density_d, void *work_d, int nmol,
                        int ntemp, int nlayers, int nwave, int nwalkers, void *stream)
+{
+    return interp_ec_batch_launch(ec_d, etable_d, ttable_d, temps_d, density_d, work_d, nmol, ntemp,
+                                  nlayers, nwave, nwalkers, TileLimit{nullptr, 0, nullptr}, stream);
+}
+
+int pb_interp_ec_batch_limited(double *ec_d, const double *etable_d, const double *ttable_d,
+                               const double *temps_d, const double *density_d, void *work_d,
+                               int nmol, int ntemp, int nlayers, int nwave, int nwalkers,
+                               const int32_t *tile_limit_d, int row0, const int32_t *gate_d,
+                               void *stream)
+{
+    PB_REQUIRE(row0 >= 0 && row0 < std::max(nlayers, 1), "pb_interp_ec_batch_limited: row0 out of range");
+    return interp_ec_batch_launch(ec_d, etable_d, ttable_d, temps_d, density_d, work_d, nmol, ntemp,
+                                  nlayers, nwave, nwalkers, TileLimit{tile_limit_d, row0, gate_d},
+                                  stream);
+}
+
+static int interp_ec_batch_launch(double *ec_d, const double *etable_d, const double *ttable_d,
+                                  const double *temps_d, const double *density_d, void *work_d,
+                                  int nmol, int ntemp, int nlayers, int nwave, int nwalkers,
+                                  TileLimit lim, void *stream)
 {
     PB_REQUIRE(nmol >= 1 && nmol <= 8 && ntemp >= 2 && nlayers >= 1 && nwave >= 0 &&
                    nwalkers >= 0,
@@ -1936,9 +2031,12 @@ int pb_interp_ec_batch(double *ec_d, const double *etable_d, const double *ttabl
     // workspace: coef[n][2*ncoef] doubles, then tlo[n] ints
     double *coef = reinterpret_cast<double *>(work_d);
     int32_t *tlo = reinterpret_cast<int32_t *>(coef + n * 2 * ncoef);
-    k_interp_weights<<<pb::div_up(n, kBlock), kBlock, 0, s>>>(tlo, coef, ttable_d, temps_d,
-                                                            density_d, nmol, ncoef, ntemp, n);
-    PB_LAUNCH_CHECK();
+    // (a gated repair pass runs on the workspace its first pass filled: same walkers, same weights)
+    if (!lim.gate) {
+        k_interp_weights<<<pb::div_up(n, kBlock), kBlock, 0, s>>>(tlo, coef, ttable_d, temps_d,
+                                                                density_d, nmol, ncoef, ntemp, n);
+        PB_LAUNCH_CHECK();
+    }
     // walkers per chunk: every chunk reads the table slices its walkers bracket again, so as many
     // as the launch can afford while it still fills the chip (C5, 64 walkers: 1.40 ms in chunks
     // of 16, 1.23 in one chunk, 1.11 with the species count a template constant)
@@ -1968,14 +2066,14 @@ int pb_interp_ec_batch(double *ec_d, const double *etable_d, const double *ttabl
         if (pairs && np == 2)                                                                  \
             k_interp_ec_batch2<S, FULL, 2><<<grid, kBlock, 0, s>>>(ec_d, etable_d, tlo, coef,  \
                                                                    nmol, ntemp, nlayers, nwave, \
-                                                                   nwalkers, chunk);           \
+                                                                   nwalkers, chunk, lim);      \
         else if (pairs)                                                                        \
             k_interp_ec_batch2<S, FULL, 1><<<grid, kBlock, 0, s>>>(ec_d, etable_d, tlo, coef,  \
                                                                    nmol, ntemp, nlayers, nwave, \
-                                                                   nwalkers, chunk);           \
+                                                                   nwalkers, chunk, lim);      \
         else                                                                                   \
             k_interp_ec_batch<S, FULL><<<grid, kBlock, 0, s>>>(ec_d, etable_d, tlo, coef, nmol,  \
-                                                               ntemp, nlayers, nwave, nwalkers, chunk); \
+                                                               ntemp, nlayers, nwave, nwalkers, chunk, lim); \
     } while (0)
     static const bool no_full = getenv("PB_INTERP_FULL") && atoi(getenv("PB_INTERP_FULL")) == 0;
     if (nmol == 4 && !no_full)
@@ -2051,7 +2149,7 @@ int pb_transit_spectrum_batch(double *spectrum_d, double *depth_d, int32_t *idee
     return pb_transit_fused_launch(depth_d, ideep_d, spectrum_d, ec_d, raypath_d, radius_d, npath,
                                    rstar, itop, ibottom, maxdepth, nlayers, nwave, nwalkers, -1,
                                    0.0, pb::as_stream(stream), reinterpret_cast<double *>(work_d),
-                                   nullptr);
+                                   nullptr, nullptr, nullptr, nullptr);
 }
 
 int pb_transit_spectrum_ordered(double *spectrum_d, const double *ec_d, const double *raypath_d,
@@ -2071,7 +2169,31 @@ int pb_transit_spectrum_ordered(double *spectrum_d, const double *ec_d, const do
     return pb_transit_fused_launch(nullptr, nullptr, spectrum_d, ec_d, raypath_d, radius_d, npath,
                                    rstar, itop, ibottom, maxdepth, nlayers, nwave, nwalkers, -1,
                                    0.0, pb::as_stream(stream), reinterpret_cast<double *>(work_d),
-                                   column_d);
+                                   column_d, nullptr, nullptr, nullptr);
+}
+
+int pb_transit_spectrum_limited(double *spectrum_d, const double *ec_d, const double *raypath_d,
+                                const double *radius_d, const int32_t *column_d, double rstar,
+                                int itop, int ibottom, double maxdepth, int nlayers, int nwave,
+                                int nwalkers, void *work_d, const int32_t *tile_limit_d,
+                                int32_t *flags_d, const int32_t *gate_d, void *stream)
+{
+    PB_REQUIRE(nlayers > 0 && nwave >= 0 && nwalkers >= 0, "pb_transit_spectrum_limited: bad shape");
+    PB_REQUIRE(itop >= 0 && itop < nlayers, "pb_transit_spectrum_limited: itop out of range");
+    PB_REQUIRE(ibottom <= nlayers, "pb_transit_spectrum_limited: ibottom > nlayers");
+    if (nwave == 0 || nwalkers == 0)
+        return PB_OK;
+    const int nrow = nlayers - itop;
+    PB_REQUIRE(spectrum_d && ec_d && radius_d && raypath_d && column_d && work_d,
+               "pb_transit_spectrum_limited: null pointer");
+    PB_REQUIRE(!tile_limit_d || flags_d,
+               "pb_transit_spectrum_limited: a tile limit needs flags[nwalkers + 1] to report the "
+               "walkers that ran past it");
+    const int64_t npath = ((int64_t)nrow * (nrow - 1)) / 2;
+    return pb_transit_fused_launch(nullptr, nullptr, spectrum_d, ec_d, raypath_d, radius_d, npath,
+                                   rstar, itop, ibottom, maxdepth, nlayers, nwave, nwalkers, -1,
+                                   0.0, pb::as_stream(stream), reinterpret_cast<double *>(work_d),
+                                   column_d, tile_limit_d, flags_d, gate_d);
 }
 
 #ifdef PB_EXPERIMENTS

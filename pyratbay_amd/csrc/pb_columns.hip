@@ -17,7 +17,9 @@ int pb_transit_fused_launch(double *depth_d, int32_t *ideep_d, double *spectrum_
                             const double *ec_d, const double *raypath_d, const double *radius_d,
                             int64_t npath, double rstar, int itop, int ibottom, double maxdepth,
                             int nlayers, int nwave, int nwalkers, int deck_row, double rsurf,
-                            hipStream_t s, double *work_d, const int32_t *scatter_d = nullptr);
+                            hipStream_t s, double *work_d, const int32_t *scatter_d = nullptr,
+                            const int32_t *tile_limit_d = nullptr, int32_t *flags_d = nullptr,
+                            const int32_t *gate_d = nullptr);
 int pb_path_blocks_launch(double **blocked_d, int64_t *len, const double *raypath_d, int64_t npath,
                           int rows, int nimpact, hipStream_t s);
 

@@ -517,17 +517,28 @@ def transit_path_device(radius, itop=0):
     return out if radius.dim() == 2 else out[0]
 
 
-def interp_ec_batch(etable, ttable, temps, dens, out=None):
+def interp_ec_batch(etable, ttable, temps, dens, out=None, tile_limit=None, row0=0, gate=None,
+                    work=None):
     """interp_ec for a batch of walkers (assigning): temps[nw, L], dens[nw, L, S] ->
-    ec[nw, L, W]; the table is read once per chunk of walkers."""
+    ec[nw, L, W]; the table is read once per chunk of walkers.  tile_limit (int32[ceil(W/256)],
+    device) / row0: only the layers a block of 256 columns can need are written
+    (pb_interp_ec_batch_limited); gate (int32[1], device): the launch does nothing unless the
+    flag is set, and runs on the `work` buffer its first pass filled."""
     nmol, ntemp, nlayers, nwave = etable.shape
     nw = temps.shape[0]
     assert temps.shape == (nw, nlayers) and dens.shape == (nw, nlayers, nmol)
     if out is None:
         out = torch.empty((nw, nlayers, nwave), dtype=torch.float64, device=etable.device)
-    work = torch.empty(nw * nlayers * 17 + 8, dtype=torch.float64, device=etable.device)
-    call('pb_interp_ec_batch', _ptr(out), _ptr(etable), _ptr(ttable), _ptr(temps.contiguous()),
-         _ptr(dens.contiguous()), _ptr(work), nmol, ntemp, nlayers, nwave, nw, _stream())
+    if work is None:
+        work = torch.empty(nw * nlayers * 17 + 8, dtype=torch.float64, device=etable.device)
+    if tile_limit is None and gate is None:
+        call('pb_interp_ec_batch', _ptr(out), _ptr(etable), _ptr(ttable),
+             _ptr(temps.contiguous()), _ptr(dens.contiguous()), _ptr(work), nmol, ntemp, nlayers,
+             nwave, nw, _stream())
+    else:
+        call('pb_interp_ec_batch_limited', _ptr(out), _ptr(etable), _ptr(ttable),
+             _ptr(temps.contiguous()), _ptr(dens.contiguous()), _ptr(work), nmol, ntemp, nlayers,
+             nwave, nw, _ptr(tile_limit), int(row0), _ptr(gate), _stream())
     return out
 
 
@@ -549,17 +560,26 @@ def transit_spectrum_batch(ec, raypath, radius, rstar, itop, ibottom, maxdepth,
     return (spectrum, depth, ideep) if want_depth else spectrum
 
 
-def transit_spectrum_ordered(ec, raypath, radius, column, rstar, itop, ibottom, maxdepth):
+def transit_spectrum_ordered(ec, raypath, radius, column, rstar, itop, ibottom, maxdepth,
+                             tile_limit=None, flags=None, gate=None, out=None, work=None):
     """transit_spectrum_batch for ec[nw, L, W] whose columns are in the order `column` (int32[W]:
     grid index of each column): spectrum[nw, W] in GRID order.  Wavefronts stop at the row tile in
-    which their 32 columns have all crossed maxdepth (pb_transit_spectrum_ordered)."""
+    which their 32 columns have all crossed maxdepth (pb_transit_spectrum_ordered).  With
+    tile_limit / flags / gate: pb_transit_spectrum_limited (see interp_ec_batch)."""
     nw, nlayers, nwave = ec.shape
-    spectrum = torch.empty((nw, nwave), dtype=torch.float64, device=ec.device)
-    nwork = _capi.lib().pb_transit_work_doubles(nlayers, int(itop), int(ibottom), nwave, nw)
-    work = torch.empty(nwork, dtype=torch.float64, device=ec.device)
-    call('pb_transit_spectrum_ordered', _ptr(spectrum), _ptr(ec), _ptr(raypath), _ptr(radius),
-         _ptr(column), float(rstar), int(itop), int(ibottom), float(maxdepth), nlayers, nwave, nw,
-         _ptr(work), _stream())
+    spectrum = out if out is not None else torch.empty((nw, nwave), dtype=torch.float64,
+                                                       device=ec.device)
+    if work is None:
+        nwork = _capi.lib().pb_transit_work_doubles(nlayers, int(itop), int(ibottom), nwave, nw)
+        work = torch.empty(nwork, dtype=torch.float64, device=ec.device)
+    if tile_limit is None and gate is None:
+        call('pb_transit_spectrum_ordered', _ptr(spectrum), _ptr(ec), _ptr(raypath), _ptr(radius),
+             _ptr(column), float(rstar), int(itop), int(ibottom), float(maxdepth), nlayers, nwave,
+             nw, _ptr(work), _stream())
+    else:
+        call('pb_transit_spectrum_limited', _ptr(spectrum), _ptr(ec), _ptr(raypath), _ptr(radius),
+             _ptr(column), float(rstar), int(itop), int(ibottom), float(maxdepth), nlayers, nwave,
+             nw, _ptr(work), _ptr(tile_limit), _ptr(flags), _ptr(gate), _stream())
     return spectrum
 
 
@@ -1317,6 +1337,10 @@ class TableSpectrum:
         # 'auto': taken from the first walker of the first batch; None: grid order
         self.column_order = None
         self.etable_ordered = None
+        # transit geometry, columns ordered by order_columns(): last row tile a block of 256
+        # ordered columns can need (int32, device) -- see _eval_chunk; None: every layer
+        self.tile_limit = None
+        self.tile_margin = int(os.environ.get('PB_C5_MARGIN', '4'))
         if isinstance(column_order, str) and column_order == 'auto' and \
                 os.environ.get('PB_COLUMN_ORDER', '1') == '0':
             column_order = None                       # (A/B switch: grid order)
@@ -1351,6 +1375,7 @@ class TableSpectrum:
         """Work the columns of eval_bands' batches in the order `order` (a permutation of
         range(nwave); None: back to grid order).  A second copy of the table is kept with its
         wavenumber axis in that order, so that every stage still streams contiguous columns."""
+        self.tile_limit = None
         if order is None:
             self.column_order = self.etable_ordered = None
             return
@@ -1391,7 +1416,25 @@ class TableSpectrum:
             _, ideep = plane_parallel_optical_depth(
                 ec[0], (rad[0, :-1] - rad[0, 1:]).contiguous(), self.itop, self.nlayers,
                 self.maxdepth)
-        self.set_column_order(torch.sort(ideep, stable=True).indices)
+        order = torch.sort(ideep, stable=True).indices
+        self.set_column_order(order)
+        if self.rt_path == 'transit' and self.tile_margin >= 0 and self._ordered_supported():
+            # The layers nobody reads: walkers of a retrieval cross maxdepth within a layer or two
+            # of the base model (measured at C5's shape: -1 ... +2 layers), so a block of 256
+            # ordered columns needs the row tiles up to the one holding its deepest base crossing
+            # + tile_margin layers -- the interpolation writes only those (80 % of ec at C5's
+            # shape), and a walker that does run past them is flagged on the device and repaired
+            # (see _eval_chunk): the spectra never depend on the limits.
+            sorted_ideep = ideep[order].to(torch.int64)
+            nblk = -(-self.nwave // 256)
+            pad = nblk * 256 - self.nwave
+            if pad:
+                sorted_ideep = torch.cat([sorted_ideep, sorted_ideep[-1:].expand(pad)])
+            bmax = sorted_ideep.view(nblk, 256).max(dim=1).values
+            ntiles = -(-(self.nlayers - self.itop) // 16)
+            tile = torch.clamp((bmax - self.itop + self.tile_margin) // 16, 0, ntiles - 1)
+            if bool((tile < ntiles - 1).any()):
+                self.tile_limit = tile.to(torch.int32).contiguous()
 
     def set_radius(self, radius):
         self.radius = dev(radius)
@@ -1553,8 +1596,21 @@ class TableSpectrum:
         # (an explicit order on a shape the ordered transit kernel does not take -- more than 128
         # impact parameters -- is worked in grid order: the spectra do not depend on the order)
         ordered = self.column_order is not None and self._ordered_supported()
-        ec = interp_ec_batch(self.etable_ordered if ordered else self.etable, self.ttable,
-                             temps[w0:w1], dens[w0:w1])
+        table = self.etable_ordered if ordered else self.etable
+        limited = ordered and self.rt_path == 'transit' and self.tile_limit is not None
+        if limited:
+            # (ec keeps whatever an earlier batch left in the layers that are not written: they are
+            # read by no one, or the walker is flagged and repaired)
+            flags = torch.zeros(n + 1, dtype=torch.int32, device=table.device)
+            iwork = torch.empty(n * self.nlayers * 17 + 8, dtype=torch.float64,
+                                device=table.device)
+            twork = torch.empty(_capi.lib().pb_transit_work_doubles(
+                self.nlayers, int(self.itop), int(self.nlayers), self.nwave, n),
+                dtype=torch.float64, device=table.device)
+            ec = interp_ec_batch(table, self.ttable, temps[w0:w1], dens[w0:w1],
+                                 tile_limit=self.tile_limit, row0=self.itop, work=iwork)
+        else:
+            ec = interp_ec_batch(table, self.ttable, temps[w0:w1], dens[w0:w1])
         if self.rt_path != 'transit':
             rad = radius.expand(n, -1) if shared_radius else radius[w0:w1]
             intervals = (rad[:, :-1] - rad[:, 1:]).contiguous()            # -diff(radius)
@@ -1570,7 +1626,19 @@ class TableSpectrum:
         else:
             rad = radius[w0:w1].contiguous()
             path = transit_path_device(rad, self.itop)
-        if ordered:
+        if ordered and limited:
+            spectra = transit_spectrum_ordered(ec, path, rad, self.column_order, self.rstar,
+                                               self.itop, self.nlayers, self.maxdepth,
+                                               tile_limit=self.tile_limit, flags=flags, work=twork)
+            # repair, gated on the device: the full interpolation if ANY walker ran past its
+            # limit, then the transit of the flagged walkers -- two launches of workgroups that
+            # return at once otherwise, no host round trip
+            interp_ec_batch(table, self.ttable, temps[w0:w1], dens[w0:w1], out=ec,
+                            gate=flags[n:n + 1], work=iwork)
+            transit_spectrum_ordered(ec, path, rad, self.column_order, self.rstar, self.itop,
+                                     self.nlayers, self.maxdepth, gate=flags, out=spectra,
+                                     work=twork)
+        elif ordered:
             # columns in depth order: wavefronts stop at the row tile where theirs have all crossed
             spectra = transit_spectrum_ordered(ec, path, rad, self.column_order, self.rstar,
                                                self.itop, self.nlayers, self.maxdepth)

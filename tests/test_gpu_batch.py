@@ -249,6 +249,108 @@ def test_eval_bands_beyond_the_ordered_kernel(eng, orc, L, itop):
         np.testing.assert_allclose(host(out['grid'][w])[0], want, rtol=1e-11)
 
 
+@pytest.mark.parametrize('L,itop,W', [(80, 0, 3000), (33, 2, 700), (128, 0, 515), (17, 0, 256)])
+def test_tile_limited_batch(eng, orc, L, itop, W):
+    """The layers nobody reads (pb_interp_ec_batch_limited + pb_transit_spectrum_limited + the
+    device-gated repair).  Limits that are right, limits that are far too low for some blocks
+    (every walker overruns: all flagged, all repaired) and limits too low for a few walkers only:
+    the spectra are bit for bit those of the unlimited ordered path; the interpolation leaves the
+    layers beyond a block's limit (and above itop) untouched; flags name exactly the walkers
+    whose columns ran past a limit."""
+    import torch
+    rng = np.random.default_rng(1000 + L + W)
+    nspec, ntemp, nw = 3, 6, 9
+    ttable = np.linspace(300.0, 3000.0, ntemp)
+    press = np.logspace(-6, 2, L)
+    etable = 10.0**rng.uniform(-27, -21, (nspec, ntemp, L, 1)) * \
+        10.0**rng.uniform(-3, 3, (nspec, 1, 1, W))
+    radius0 = np.linspace(8.0e9, 7.0e9, L)
+    temps = 1500.0 * (1 + 0.1 * rng.uniform(-1, 1, (nw, 1))) * np.linspace(0.8, 1.2, L)
+    dens = (press / temps)[:, :, None] * 7.2e21 * 10.0**rng.uniform(-7, -3, (nw, 1, nspec))
+    dens[3] *= 30.0                                   # one walker far more opaque ...
+    dens[5] /= 30.0                                   # ... and one far more transparent than the base
+    et, tt = eng.dev(etable), eng.dev(ttable)
+    td, dd = eng.dev(temps), eng.dev(dens)
+    rad = eng.dev(np.tile(radius0, (nw, 1)))
+    path = eng.transit_path_device(rad, itop)
+    # order by walker 0 and derive its exact per-column tiles
+    ec0 = eng.interp_ec_batch(et, tt, td, dd)
+    _, _, ideep = eng.transit_spectrum_batch(ec0, path, rad, 8.8e10, itop, L, 10.0, want_depth=True)
+    order = torch.sort(ideep[0], stable=True).indices
+    eto = et[..., order].contiguous()
+    col = order.to(torch.int32)
+    want = eng.transit_spectrum_ordered(eng.interp_ec_batch(eto, tt, td, dd), path, rad, col,
+                                        8.8e10, itop, L, 10.0)
+    nblk = -(-W // 256)
+    ntiles = -(-(L - itop) // 16)
+    need = torch.zeros(nblk * 256, dtype=torch.int64, device='cuda')
+    allw = ideep[:, order].max(dim=0).values.to(torch.int64)           # deepest over the walkers
+    need[:W] = allw
+    need[W:] = allw[-1]
+    exact = torch.clamp((need.view(nblk, 256).max(dim=1).values - itop) // 16, 0, ntiles - 1)
+    base = torch.zeros(nblk * 256, dtype=torch.int64, device='cuda')
+    base[:W] = ideep[0, order]
+    base[W:] = base[W - 1]
+    base_tile = torch.clamp((base.view(nblk, 256).max(dim=1).values - itop) // 16, 0, ntiles - 1)
+    for name, tile in (('exact', exact), ('base model, no margin', base_tile),
+                       ('far too low', torch.zeros_like(exact))):
+        tile = tile.to(torch.int32).contiguous()
+        flags = torch.zeros(nw + 1, dtype=torch.int32, device='cuda')
+        ec = torch.full((nw, L, W), -7.0, dtype=torch.float64, device='cuda')
+        iwork = torch.empty(nw * L * 17 + 8, dtype=torch.float64, device='cuda')
+        eng.interp_ec_batch(eto, tt, td, dd, out=ec, tile_limit=tile, row0=itop, work=iwork)
+        # what was written: exactly the layers itop ... itop + 16 (tile + 1) - 1 of each block
+        # (a workgroup covers several blocks: up to the largest limit among them)
+        full = eng.interp_ec_batch(eto, tt, td, dd)
+        written = ec != -7.0
+        lay = torch.arange(L, device='cuda')[None, :, None]
+        blk = (torch.arange(W, device='cuda') // 256)[None, None, :]
+        must = (lay >= itop) & (lay <= itop + 16 * (tile.to(torch.int64)[blk] + 1) - 1)
+        assert bool((written | ~must).all()), name            # every wanted layer is there
+        assert torch.equal(ec[written], full[written]), name  # ... with the right values
+        assert not bool(written[:, :itop].any()), name
+        if name == 'far too low' and ntiles > 1:
+            assert not bool(written.all())
+        twork = torch.empty(eng._capi.lib().pb_transit_work_doubles(L, itop, L, W, nw),
+                            dtype=torch.float64, device='cuda')
+        got = eng.transit_spectrum_ordered(ec, path, rad, col, 8.8e10, itop, L, 10.0,
+                                           tile_limit=tile, flags=flags, work=twork)
+        f = flags.cpu().numpy()
+        assert f[nw] == int(f[:nw].any())
+        # which walkers have a wavefront (32 ordered columns) still open beyond its block's tile
+        wtile = ((ideep[:, order].to(torch.int64) - itop) // 16).cpu().numpy()
+        lim_col = tile.cpu().numpy()[np.arange(W) // 256]
+        c32 = (np.arange(W) // 32)
+        over = np.zeros(nw, bool)
+        for w in range(nw):
+            wave_need = np.maximum.reduceat(wtile[w], np.flatnonzero(np.diff(c32, prepend=-1)))
+            wave_lim = lim_col[np.flatnonzero(np.diff(c32, prepend=-1))]
+            over[w] = np.any(wave_need > wave_lim)
+        assert np.array_equal(f[:nw] != 0, over), (name, f, over)
+        if name == 'exact':
+            assert not f.any() and torch.equal(got, want)
+        # the gated repair: full interpolation if any flag, transit of the flagged walkers
+        eng.interp_ec_batch(eto, tt, td, dd, out=ec, gate=flags[nw:nw + 1], work=iwork)
+        eng.transit_spectrum_ordered(ec, path, rad, col, 8.8e10, itop, L, 10.0, gate=flags,
+                                     out=got, work=twork)
+        assert torch.equal(got, want), name
+        if f[nw]:
+            assert torch.equal(ec, full)                      # (the repair rewrote every layer)
+    # the same through TableSpectrum.eval_bands (walker 0 is the base model of the auto order)
+    from pyratbay_amd import synth
+    g = synth.spectral_grid(4000.0, 4000.0 + (W - 1) * 0.05 + 0.01, 0.05, 12)
+    pb = eng.PassBands(g['wn'], [(1, np.ones(W - 2), 1.0)])
+    res = {}
+    for order_kw in (None, 'auto'):
+        model = eng.TableSpectrum(etable, ttable, g['wn'], radius0, 8.8e10, itop=itop,
+                                  column_order=order_kw)
+        model.tile_margin = 0
+        res[order_kw] = model.eval_bands(td, dd, pb).clone()
+        if order_kw == 'auto' and W >= 64 and ntiles > 1:
+            assert model.tile_limit is not None
+    assert torch.equal(res[None], res['auto'])
+
+
 def test_fused_transit_equals_split(eng):
     """The fused column kernel against the two-kernel form it replaced (a separate process so
     that PB_TRANSIT=split is read afresh): same depth, ideep, spectrum bits."""
