@@ -955,8 +955,11 @@ __global__ __launch_bounds__(TB, WPS) void k_transit_mfma_rows(
         }
         // the next tile's layers are requested before this tile's products (two tiles ahead:
         // measured slower, 1.27 against 1.16 ms at C5's shape -- the loads an exit wastes)
+        // (not beyond the tile limit: those layers were never interpolated and an open column
+        // there goes to the repair pass -- a fifth of the kernel's reads at C5's shape)
         if constexpr (m + 1 < MT)                         // (clamped rows: harmless past the end)
-            loadb(std::integral_constant<int, m + 1>{});
+            if (m + 1 <= mlim || lim.row0 < 0)            // uniform (row0 < 0: A/B switch)
+                loadb(std::integral_constant<int, m + 1>{});
         // Column tile 0's products; then column tile 1's with the exponentials of tile 0's rows
         // between them: a product holds the matrix pipe for 64 cycles, the slices issue meanwhile
         // (pinned by scheduling barriers: left alone, the compiler keeps the products together).
@@ -1756,7 +1759,9 @@ int pb_transit_fused_launch(double *depth_d, int32_t *ideep_d, double *spectrum_
                             hipStream_t s, double *work_d, const int32_t *scatter_d,
                             const int32_t *tile_limit_d, int32_t *flags_d, const int32_t *gate_d)
 {
-    const TileLimit lim{tile_limit_d, itop, gate_d};
+    // (PB_C5_PREFETCH_ALL=1: the next tile's layers are requested whatever the limit -- A/B)
+    static const bool prefetch_all = getenv("PB_C5_PREFETCH_ALL") && atoi(getenv("PB_C5_PREFETCH_ALL"));
+    const TileLimit lim{tile_limit_d, prefetch_all ? -1 : itop, gate_d};
     const int nrow = nlayers - itop;
     const int nimpact = std::min(ibottom, nlayers) - itop;
 #ifdef PB_EXPERIMENTS

@@ -261,9 +261,14 @@ def main(args):
         # (as eval_bands runs them: the columns in the depth order of the first walker it saw)
         ordered = model.column_order is not None
         table = model.etable_ordered if ordered else model.etable
-        interp_ms = timed(lambda: engine.interp_ec_batch(table, model.ttable, temps, dens))
+        # (transit geometry with ordered columns: the interpolation writes only the layers a block
+        # of columns can need, TableSpectrum.tile_limit; the kernels are timed as eval_bands runs them)
+        tile_limit = getattr(model, 'tile_limit', None) if rt == 'transit' else None
+        interp_ms = timed(lambda: engine.interp_ec_batch(table, model.ttable, temps, dens,
+                                                         tile_limit=tile_limit, row0=0))
         ec = engine.interp_ec_batch(table, model.ttable, temps, dens)
         grid_order_ms = None
+        flagged = 0
         if rt == 'emission':
             intervals = (radius[:, :-1] - radius[:, 1:]).contiguous()
             transit_ms = timed(lambda: engine.emission_flux_batch(
@@ -273,8 +278,11 @@ def main(args):
         else:
             path = engine.transit_path_device(radius, 0)
             if ordered:
+                tflags = torch.zeros(nloc + 1, dtype=torch.int32, device='cuda')
                 transit_ms = timed(lambda: engine.transit_spectrum_ordered(
-                    ec, path, radius, model.column_order, atm['rstar'], 0, nlayers, 10.0))
+                    ec, path, radius, model.column_order, atm['rstar'], 0, nlayers, 10.0,
+                    tile_limit=tile_limit, flags=tflags if tile_limit is not None else None))
+                flagged = int(tflags[:nloc].sum().item())
             else:
                 transit_ms = timed(lambda: engine.transit_spectrum_batch(
                     ec, path, radius, atm['rstar'], 0, nlayers, 10.0))
@@ -301,6 +309,13 @@ def main(args):
         tlo = np.clip(np.searchsorted(tt, th, 'right') - 1, 0, len(tt) - 2)      # [nloc, L]
         nodes = sum(len(np.union1d(tlo[:, k], tlo[:, k] + 1)) for k in range(nlayers))
         interp_bytes = 8.0 * NSPEC * nwave * nodes + 8.0 * nlayers * nwave * nloc
+        written_frac = 1.0
+        if tile_limit is not None:
+            # layers written per block of 256 ordered columns: 16 (tile + 1), table slices likewise
+            lay = np.minimum(16 * (tile_limit.cpu().numpy().astype(np.int64) + 1), nlayers)
+            cols = np.minimum(256, nwave - 256 * np.arange(len(lay)))
+            written_frac = float((lay * cols).sum()) / (nlayers * nwave)
+            interp_bytes *= written_frac
         transit_bytes = (8.0 * nlayers * nwave + 8.0 * nwave) * nloc
         if depth_rows is not None:
             # (transit: the rows down to every column's first crossing -- what the reference's
@@ -363,6 +378,11 @@ def main(args):
                                         'order_columns): spectra do not depend on it'
                                         if ordered else 'grid order'),
                        'rt_kernel_ms_grid_order': grid_order_ms,
+                       'layers_written': (None if tile_limit is None else
+                                          {'fraction_of_ec': written_frac,
+                                           'margin_layers': model.tile_margin,
+                                           'walkers_flagged_for_repair': flagged}),
+                       'box_reference': box_reference(),
                        'gpu_state': state.summary()},
             'roofline': {'bound': 'hbm', 'kernel': dom['kernel'], 'achieved': dom['achieved'],
                          'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': dom['frac'],
@@ -386,6 +406,29 @@ def main(args):
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def box_reference():
+    """What THIS box's HBM does on a plain stream, beside the bench line: fill (write-only) and
+    copy (read + write) of a 4-GiB buffer through torch, GB/s.  Box-to-box spreads of the C5 line
+    (26e3 ... 31e3 evals/s at equal sclk / mclk / fclk) follow these numbers."""
+    import torch
+    n = 1 << 29                                            # 4 GiB of doubles
+    a = torch.empty(n, dtype=torch.float64, device='cuda')
+    b = torch.empty(n, dtype=torch.float64, device='cuda')
+    out = {}
+    for name, fn, nbytes in (('fill_GBps', lambda: a.fill_(1.0), 8.0 * n),
+                             ('copy_GBps', lambda: b.copy_(a), 16.0 * n)):
+        fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        out[name] = round(5 * nbytes / (e0.elapsed_time(e1) * 1e-3) / 1e9, 1)
+    del a, b
+    return out
 
 
 def cpu_legs(inp, procs, gpu_flux_last, rt='transit'):

@@ -45,11 +45,15 @@ def cards():
 def sample(card):
     dev, hw = card
     s = {'sclk_mhz': _current_mhz(_read(os.path.join(dev, 'pp_dpm_sclk'))),
-         'mclk_mhz': _current_mhz(_read(os.path.join(dev, 'pp_dpm_mclk')))}
+         'mclk_mhz': _current_mhz(_read(os.path.join(dev, 'pp_dpm_mclk'))),
+         'fclk_mhz': _current_mhz(_read(os.path.join(dev, 'pp_dpm_fclk'))),
+         'socclk_mhz': _current_mhz(_read(os.path.join(dev, 'pp_dpm_socclk')))}
     if hw:
         for key, name, scale in (('power_w', 'power1_average', 1e-6),
                                  ('power_w', 'power1_input', 1e-6),
-                                 ('temp_c', 'temp1_input', 1e-3)):
+                                 ('power_cap_w', 'power1_cap', 1e-6),
+                                 ('temp_c', 'temp1_input', 1e-3),
+                                 ('temp_c', 'temp2_input', 1e-3)):
             if s.get(key) is None:
                 v = _read(os.path.join(hw, name))
                 try:
@@ -124,7 +128,8 @@ class Sampler:
             if not rows:
                 continue
             out.append({'card': os.path.basename(os.path.dirname(dev)), 'samples': len(rows),
-                        **{k: stat(rows, k) for k in ('sclk_mhz', 'mclk_mhz', 'power_w',
+                        **{k: stat(rows, k) for k in ('sclk_mhz', 'mclk_mhz', 'fclk_mhz',
+                                                      'socclk_mhz', 'power_w', 'power_cap_w',
                                                       'temp_c', 'busy_pct')}})
         if not out:
             return None
