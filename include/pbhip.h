@@ -497,6 +497,16 @@ int pb_transit_spectrum_limited(double *spectrum_d, const double *ec_d, const do
                                 int itop, int ibottom, double maxdepth, int nlayers, int nwave,
                                 int nwalkers, void *work_d, const int32_t *tile_limit_d,
                                 int32_t *flags_d, const int32_t *gate_d, void *stream);
+/* The emission counterpart (pb_emission_flux_ordered with the same limits: a column stops at the
+ * first layer whose plane-parallel depth reaches maxdepth, _trapezoid.c:199-209; one still open at
+ * layer itop + 16 (tile + 1) of its block is left unwritten and its walker flagged; gate_d as for
+ * the transit call). */
+int pb_emission_flux_limited(double *flux_d, const double *ec_d, const double *intervals_d,
+                             const double *wn_d, const double *temp_d, const double *mu_d,
+                             const double *weights_d, const int32_t *column_d, int nmu,
+                             double maxdepth, int itop, int ibottom, int nlayers, int nwave,
+                             int nwalkers, const int32_t *tile_limit_d, int32_t *flags_d,
+                             const int32_t *gate_d, void *stream);
 /* Emission geometry for a batch: plane_parallel_optical_depth (src_c/_trapezoid.c:175-213) +
  * blackbody + intensity + quadrature sum (pyrat/spectrum.py:366-377) in one pass, no cloud deck:
  * ec_d[nwalkers,nlayers,nwave], intervals_d[nwalkers,nlayers-1], temp_d[nwalkers,nlayers] ->

@@ -83,6 +83,8 @@ _PROTOS = {
     'pb_interp_ec_batch_limited': [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, i32, vp, vp],
     'pb_transit_spectrum_limited': [vp, vp, vp, vp, vp, f64, i32, i32, f64, i32, i32, i32, vp, vp,
                                     vp, vp, vp],
+    'pb_emission_flux_limited': [vp, vp, vp, vp, vp, vp, vp, vp, i32, f64, i32, i32, i32, i32, i32,
+                                 vp, vp, vp, vp],
     'pb_emission_flux_batch': [vp, vp, vp, vp, vp, vp, vp, i32, f64, i32, i32, i32, i32, i32, vp],
     'pb_emission_flux_ordered': [vp, vp, vp, vp, vp, vp, vp, vp, i32, f64, i32, i32, i32, i32, i32, vp],
     'pb_band_integrate_batch': [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp],

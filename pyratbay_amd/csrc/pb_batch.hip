@@ -101,33 +101,9 @@ __global__ __launch_bounds__(kBlock) void k_iso_partition(
 // flags[nwalkers], the transit of walker w gated on flags[w] -- so the repair costs two nearly
 // empty launches when nothing was flagged, and no host synchronisation ever.
 // ---------------------------------------------------------------------------
-struct TileLimit {
-    const int32_t *tile;      // [ceil(nwave / 256)] last row tile available, or null: every layer
-    int row0;                 // itop: layers above it are not read by the transit pass either
-    const int32_t *gate;      // null, or: run only if *gate != 0 (interp) / gate[walker] != 0 (transit)
-};
-
-__device__ __forceinline__ int uniform_i32(const int32_t *p)
-{
-    typedef const int32_t __attribute__((address_space(4))) *cptr;
-    return *((cptr)(unsigned long long)p);
-}
-
-// is layer k of the samples [s0, s1) wanted?  (wave-uniform)
-__device__ __forceinline__ bool layer_wanted(const TileLimit &lim, int k, int s0, int s1, int nwave)
-{
-    if (lim.gate && uniform_i32(lim.gate) == 0)
-        return false;
-    if (!lim.tile)
-        return true;
-    if (k < lim.row0)
-        return false;
-    const int b1 = (min(s1, nwave) - 1) >> 8;
-    int t = 0;
-    for (int b = max(s0, 0) >> 8; b <= b1; b++)
-        t = max(t, uniform_i32(lim.tile + b));
-    return k <= lim.row0 + 16 * (t + 1) - 1;
-}
+using pb::TileLimit;
+using pb::uniform_i32;
+using pb::layer_wanted;
 
 // ---------------------------------------------------------------------------
 // interp_ec for a batch of walkers, assigning form.  Workgroup = (256 wavenumbers, layer,

@@ -526,10 +526,13 @@ template <int MU>
 __global__ void k_emission_fused(double *flux, const double *ec, const double *intervals,
                                  const double *wn, const double *temp, const double *mu,
                                  const double *weights, int nmu, double maxdepth, int itop,
-                                 int ibottom, int nlayers, int nwave, const int32_t *scatter)
+                                 int ibottom, int nlayers, int nwave, const int32_t *scatter,
+                                 pb::TileLimit lim, int32_t *flags)
 {
     extern __shared__ double s_kt[];        // [2][nlayers]: kKB T of this walker and its reciprocal
     const int wk = blockIdx.y;
+    if (lim.gate && pb::uniform_i32(lim.gate + wk) == 0)
+        return;                             // (repair pass: walker wk was not flagged)
     planck_terms(s_kt, temp + (int64_t)wk * nlayers, nlayers, mu, nmu);
     const double *s_imu = s_kt + 2 * nlayers;
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
@@ -550,7 +553,17 @@ __global__ void k_emission_fused(double *flux, const double *ec, const double *i
     double depth = 0.0, tlast = 0.0;
     double prev = ec[(int64_t)itop * nwave + j];
     int last = rtop;                                          // deepest layer seen so far
+    // the last layer that was interpolated for this block of 256 (ordered) columns (TileLimit:
+    // workgroups are 256 columns wide, so the limit is uniform); a column still open beyond it
+    // goes to the repair pass
+    const int klim = lim.tile ? lim.row0 + 16 * (pb::uniform_i32(lim.tile + blockIdx.x) + 1) - 1
+                              : nlayers;
+    bool overrun = false;
     for (int k = itop + 1; k < nlayers; k++) {
+        if (k > klim) {
+            overrun = true;
+            break;
+        }
         const double cur = ec[(int64_t)k * nwave + j];
         depth += 0.5 * h[k - 1] * (cur + prev);
         prev = cur;
@@ -570,6 +583,13 @@ __global__ void k_emission_fused(double *flux, const double *ec, const double *i
         last = k;
         if (depth >= maxdepth || k == ibottom || k == nlayers - 1)
             break;
+    }
+    if (overrun) {
+        if (flags) {
+            flags[wk] = 1;
+            flags[gridDim.y] = 1;                             // flags[nwalkers]: any walker
+        }
+        return;                                               // (the repair pass writes this column)
     }
     // (itop == nlayers-1: no interval; the reference's loop then leaves ideep = nlayers, clipped)
     const double blast =
@@ -1148,7 +1168,8 @@ static int emission_batch(double *flux_d, const double *ec_d, const double *inte
                           const double *wn_d, const double *temp_d, const double *mu_d,
                           const double *weights_d, const int32_t *column_d, int nmu,
                           double maxdepth, int itop, int ibottom, int nlayers, int nwave,
-                          int nwalkers, void *stream);
+                          int nwalkers, void *stream, const int32_t *tile_limit_d = nullptr,
+                          int32_t *flags_d = nullptr, const int32_t *gate_d = nullptr);
 
 int pb_emission_flux_batch(double *flux_d, const double *ec_d, const double *intervals_d,
                            const double *wn_d, const double *temp_d, const double *mu_d,
@@ -1170,12 +1191,30 @@ int pb_emission_flux_ordered(double *flux_d, const double *ec_d, const double *i
                           maxdepth, itop, ibottom, nlayers, nwave, nwalkers, stream);
 }
 
+int pb_emission_flux_limited(double *flux_d, const double *ec_d, const double *intervals_d,
+                             const double *wn_d, const double *temp_d, const double *mu_d,
+                             const double *weights_d, const int32_t *column_d, int nmu,
+                             double maxdepth, int itop, int ibottom, int nlayers, int nwave,
+                             int nwalkers, const int32_t *tile_limit_d, int32_t *flags_d,
+                             const int32_t *gate_d, void *stream)
+{
+    PB_REQUIRE(column_d || nwave == 0, "pb_emission_flux_limited: null column index");
+    PB_REQUIRE(!tile_limit_d || flags_d,
+               "pb_emission_flux_limited: a tile limit needs flags[nwalkers + 1] to report the "
+               "walkers that ran past it");
+    return emission_batch(flux_d, ec_d, intervals_d, wn_d, temp_d, mu_d, weights_d, column_d, nmu,
+                          maxdepth, itop, ibottom, nlayers, nwave, nwalkers, stream, tile_limit_d,
+                          flags_d, gate_d);
+}
+
 static int emission_batch(double *flux_d, const double *ec_d, const double *intervals_d,
                           const double *wn_d, const double *temp_d, const double *mu_d,
                           const double *weights_d, const int32_t *column_d, int nmu,
                           double maxdepth, int itop, int ibottom, int nlayers, int nwave,
-                          int nwalkers, void *stream)
+                          int nwalkers, void *stream, const int32_t *tile_limit_d,
+                          int32_t *flags_d, const int32_t *gate_d)
 {
+    const pb::TileLimit lim{tile_limit_d, itop, gate_d};
     PB_REQUIRE(nlayers >= 1 && nwave >= 0 && nwalkers >= 0, "pb_emission_flux_batch: bad shape");
     PB_REQUIRE(nmu >= 1 && nmu <= kMaxMu, "pb_emission_flux_batch: nmu must be 1..%d", kMaxMu);
     PB_REQUIRE(itop >= 0 && itop < nlayers, "pb_emission_flux_batch: itop out of range");
@@ -1190,11 +1229,11 @@ static int emission_batch(double *flux_d, const double *ec_d, const double *inte
     if (nmu <= 8)
         k_emission_fused<8><<<grid, kBlock, ((size_t)2 * nlayers + kMaxMu) * 8, pb::as_stream(stream)>>>(
         flux_d, ec_d, intervals_d, wn_d, temp_d, mu_d, weights_d, nmu, maxdepth, itop, ibottom,
-        nlayers, nwave, column_d);
+        nlayers, nwave, column_d, lim, flags_d);
     else
         k_emission_fused<kMaxMu><<<grid, kBlock, ((size_t)2 * nlayers + kMaxMu) * 8, pb::as_stream(stream)>>>(
         flux_d, ec_d, intervals_d, wn_d, temp_d, mu_d, weights_d, nmu, maxdepth, itop, ibottom,
-        nlayers, nwave, column_d);
+        nlayers, nwave, column_d, lim, flags_d);
     PB_LAUNCH_CHECK();
     return PB_OK;
 }

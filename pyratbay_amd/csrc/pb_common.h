@@ -159,4 +159,35 @@ __device__ __forceinline__ double exp_s(double x)
     return x < -1075.0 ? 0.0 : v;
 }
 
+// The layers nobody reads of a retrieval batch with ordered columns (pb_batch.hip, above
+// k_interp_ec_batch): limits per block of 256 columns, the repair pass's gate.
+struct TileLimit {
+    const int32_t *tile;      // [ceil(nwave / 256)] last row tile available, or null: every layer
+    int row0;                 // itop: layers above it are not read by the transit pass either
+    const int32_t *gate;      // null, or: run only if *gate != 0 (interp) / gate[walker] != 0 (transit)
+};
+
+__device__ __forceinline__ int uniform_i32(const int32_t *p)
+{
+    typedef const int32_t __attribute__((address_space(4))) *cptr;
+    return *((cptr)(unsigned long long)p);
+}
+
+// is layer k of the samples [s0, s1) wanted?  (wave-uniform)
+__device__ __forceinline__ bool layer_wanted(const TileLimit &lim, int k, int s0, int s1, int nwave)
+{
+    if (lim.gate && uniform_i32(lim.gate) == 0)
+        return false;
+    if (!lim.tile)
+        return true;
+    if (k < lim.row0)
+        return false;
+    const int b1 = (min(s1, nwave) - 1) >> 8;
+    int t = 0;
+    for (int b = max(s0, 0) >> 8; b <= b1; b++)
+        t = max(t, uniform_i32(lim.tile + b));
+    return k <= lim.row0 + 16 * (t + 1) - 1;
+}
+
+
 }  // namespace pb

@@ -616,12 +616,21 @@ def table_transit_batch(etable, ttable, temps, dens, raypath, radius, rstar, ito
 
 
 def emission_flux_batch(ec, intervals, wn, temps, mu, weights, itop, ibottom, maxdepth,
-                        column=None):
+                        column=None, tile_limit=None, flags=None, gate=None, out=None):
     """plane-parallel optical depth + emission flux for a batch: ec[nw, L, W],
     intervals[nw, L-1], temps[nw, L] -> flux[nw, W] (no cloud deck).  With `column` (int32[W]) the
-    columns of ec and wn are in that order (grid index of each) and flux comes in grid order."""
+    columns of ec and wn are in that order (grid index of each) and flux comes in grid order.
+    tile_limit / flags / gate (ordered columns only): pb_emission_flux_limited, see
+    interp_ec_batch."""
     nw, nlayers, nwave = ec.shape
-    flux = torch.empty((nw, nwave), dtype=torch.float64, device=ec.device)
+    flux = out if out is not None else torch.empty((nw, nwave), dtype=torch.float64,
+                                                   device=ec.device)
+    if tile_limit is not None or gate is not None:
+        call('pb_emission_flux_limited', _ptr(flux), _ptr(ec), _ptr(intervals.contiguous()),
+             _ptr(wn), _ptr(temps.contiguous()), _ptr(mu), _ptr(weights), _ptr(column), len(mu),
+             float(maxdepth), int(itop), int(ibottom), nlayers, nwave, nw, _ptr(tile_limit),
+             _ptr(flags), _ptr(gate), _stream())
+        return flux
     if column is not None:
         call('pb_emission_flux_ordered', _ptr(flux), _ptr(ec), _ptr(intervals.contiguous()),
              _ptr(wn), _ptr(temps.contiguous()), _ptr(mu), _ptr(weights), _ptr(column), len(mu),
@@ -1418,13 +1427,14 @@ class TableSpectrum:
                 self.maxdepth)
         order = torch.sort(ideep, stable=True).indices
         self.set_column_order(order)
-        if self.rt_path == 'transit' and self.tile_margin >= 0 and self._ordered_supported():
+        if self.tile_margin >= 0 and self._ordered_supported():
             # The layers nobody reads: walkers of a retrieval cross maxdepth within a layer or two
             # of the base model (measured at C5's shape: -1 ... +2 layers), so a block of 256
-            # ordered columns needs the row tiles up to the one holding its deepest base crossing
-            # + tile_margin layers -- the interpolation writes only those (80 % of ec at C5's
-            # shape), and a walker that does run past them is flagged on the device and repaired
-            # (see _eval_chunk): the spectra never depend on the limits.
+            # ordered columns needs the row tiles (transit) / layers (emission) up to the one
+            # holding its deepest base crossing + tile_margin layers -- the interpolation writes
+            # only those (80 % of ec at C5's shape), and a walker that does run past them is
+            # flagged on the device and repaired (see _eval_chunk): the spectra never depend on
+            # the limits.
             sorted_ideep = ideep[order].to(torch.int64)
             nblk = -(-self.nwave // 256)
             pad = nblk * 256 - self.nwave
@@ -1597,16 +1607,18 @@ class TableSpectrum:
         # impact parameters -- is worked in grid order: the spectra do not depend on the order)
         ordered = self.column_order is not None and self._ordered_supported()
         table = self.etable_ordered if ordered else self.etable
-        limited = ordered and self.rt_path == 'transit' and self.tile_limit is not None
+        limited = ordered and self.tile_limit is not None
         if limited:
             # (ec keeps whatever an earlier batch left in the layers that are not written: they are
             # read by no one, or the walker is flagged and repaired)
             flags = torch.zeros(n + 1, dtype=torch.int32, device=table.device)
             iwork = torch.empty(n * self.nlayers * 17 + 8, dtype=torch.float64,
                                 device=table.device)
-            twork = torch.empty(_capi.lib().pb_transit_work_doubles(
-                self.nlayers, int(self.itop), int(self.nlayers), self.nwave, n),
-                dtype=torch.float64, device=table.device)
+            twork = None
+            if self.rt_path == 'transit':
+                twork = torch.empty(_capi.lib().pb_transit_work_doubles(
+                    self.nlayers, int(self.itop), int(self.nlayers), self.nwave, n),
+                    dtype=torch.float64, device=table.device)
             ec = interp_ec_batch(table, self.ttable, temps[w0:w1], dens[w0:w1],
                                  tile_limit=self.tile_limit, row0=self.itop, work=iwork)
         else:
@@ -1614,10 +1626,23 @@ class TableSpectrum:
         if self.rt_path != 'transit':
             rad = radius.expand(n, -1) if shared_radius else radius[w0:w1]
             intervals = (rad[:, :-1] - rad[:, 1:]).contiguous()            # -diff(radius)
-            spectra = emission_flux_batch(ec, intervals, self.wn_ordered if ordered else self.wn,
-                                          temps[w0:w1], self.mu, self.weights, self.itop,
-                                          self.nlayers, self.maxdepth,
-                                          self.column_order if ordered else None)
+            if limited:
+                spectra = emission_flux_batch(ec, intervals, self.wn_ordered, temps[w0:w1],
+                                              self.mu, self.weights, self.itop, self.nlayers,
+                                              self.maxdepth, self.column_order,
+                                              tile_limit=self.tile_limit, flags=flags)
+                # (device-gated repair, as in the transit branch below)
+                interp_ec_batch(table, self.ttable, temps[w0:w1], dens[w0:w1], out=ec,
+                                gate=flags[n:n + 1], work=iwork)
+                emission_flux_batch(ec, intervals, self.wn_ordered, temps[w0:w1], self.mu,
+                                    self.weights, self.itop, self.nlayers, self.maxdepth,
+                                    self.column_order, gate=flags, out=spectra)
+            else:
+                spectra = emission_flux_batch(ec, intervals,
+                                              self.wn_ordered if ordered else self.wn,
+                                              temps[w0:w1], self.mu, self.weights, self.itop,
+                                              self.nlayers, self.maxdepth,
+                                              self.column_order if ordered else None)
             bands.integrate_batch(spectra, out[w0:w1])
             return
         if shared_radius:

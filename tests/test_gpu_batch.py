@@ -251,8 +251,8 @@ def test_eval_bands_beyond_the_ordered_kernel(eng, orc, L, itop):
 
 @pytest.mark.parametrize('L,itop,W', [(80, 0, 3000), (33, 2, 700), (128, 0, 515), (17, 0, 256)])
 def test_tile_limited_batch(eng, orc, L, itop, W):
-    """The layers nobody reads (pb_interp_ec_batch_limited + pb_transit_spectrum_limited + the
-    device-gated repair).  Limits that are right, limits that are far too low for some blocks
+    """The layers nobody reads (pb_interp_ec_batch_limited + pb_transit_spectrum_limited /
+    pb_emission_flux_limited + the device-gated repair).  Limits that are right, limits that are far too low for some blocks
     (every walker overruns: all flagged, all repaired) and limits too low for a few walkers only:
     the spectra are bit for bit those of the unlimited ordered path; the interpolation leaves the
     layers beyond a block's limit (and above itop) untouched; flags name exactly the walkers
@@ -340,15 +340,17 @@ def test_tile_limited_batch(eng, orc, L, itop, W):
     from pyratbay_amd import synth
     g = synth.spectral_grid(4000.0, 4000.0 + (W - 1) * 0.05 + 0.01, 0.05, 12)
     pb = eng.PassBands(g['wn'], [(1, np.ones(W - 2), 1.0)])
-    res = {}
-    for order_kw in (None, 'auto'):
-        model = eng.TableSpectrum(etable, ttable, g['wn'], radius0, 8.8e10, itop=itop,
-                                  column_order=order_kw)
-        model.tile_margin = 0
-        res[order_kw] = model.eval_bands(td, dd, pb).clone()
-        if order_kw == 'auto' and W >= 64 and ntiles > 1:
-            assert model.tile_limit is not None
-    assert torch.equal(res[None], res['auto'])
+    for rt_path in ('transit', 'emission'):
+        res = {}
+        for order_kw in (None, 'auto'):
+            model = eng.TableSpectrum(etable, ttable, g['wn'], radius0, 8.8e10, itop=itop,
+                                      rt_path=rt_path, column_order=order_kw)
+            model.tile_margin = 0
+            res[order_kw] = model.eval_bands(td, dd, pb).clone()
+            if order_kw == 'auto' and W >= 64 and ntiles > 1 and rt_path == 'transit':
+                assert model.tile_limit is not None
+        assert torch.equal(res[None], res['auto']), rt_path
+        assert bool(torch.isfinite(res[None]).all())
 
 
 def test_fused_transit_equals_split(eng):
