@@ -404,6 +404,82 @@ class ExchangePipeline:
         return out
 
 
+class StackedShard:
+    """K atmospheres of ONE wavenumber shard per extinction call: their layers are stacked as
+    K x L layers of one plan (layer state, records, gather and combine launched once for all of
+    them, ONE all-reduce of the K x L x rows maxima), then K transit calls, each writing its shard
+    into a gather slot of its own.
+
+    Why: a 1/8 shard of C2 is a 0.17-ms gather launch over 7 tiles x 80
+    layers plus ~0.09 ms of small launches whose size does not shrink with the number of ranks;
+    with K atmospheres per call the gather launch is K times larger (a shorter tail per spectrum)
+    and the fixed launches are paid once per K spectra: 0.1543 -> 0.1486 / 0.1466 / 0.1454 ms per
+    spectrum for K = 2 / 3 / 4 (tools/stack_probe.py).  The callers this serves have the
+    atmospheres at hand: the walkers of a retrieval, the temperature loop of an opacity table.
+    Each atmosphere's spectrum equals LBLSpectrum.run()'s of the same atmosphere to rounding
+    (~1e-16: a larger launch may split the phases of a tile differently), bit for bit with the
+    split pinned (PB_STAGE_SPLIT)"""
+
+    def __init__(self, case, stack, wbegin=0, wcount=None, itop=0, voigt=None, lines=None):
+        from . import engine
+        self.engine = engine
+        g, atm, ln, iso, vg = (case[k] for k in ('grid', 'atm', 'lines', 'iso', 'voigt'))
+        assert g.get('resolution') is None and not g.get('interpolate'), \
+            'StackedShard: constant-step grids (the interpolating modes plan per layer)'
+        self.stack = int(stack)
+        self.nwave, self.nlayers, self.itop = g['nwave'], atm['nlayers'], itop
+        self.wbegin = wbegin
+        self.wcount = self.nwave - wbegin if wcount is None else wcount
+        self.maxdepth, self.rstar = case['maxdepth'], float(atm['rstar'])
+        self.voigt = voigt or engine.VoigtTable.build(vg['lorentz'], vg['doppler'], vg['size'],
+                                                      g['ownstep'], g['wnosamp'])
+        self.lines = lines or engine.LineList(ln['lwn'], ln['elow'], ln['gf'], ln['lid'],
+                                              len(iso['isomass']), g['own'])
+        K, L = self.stack, self.nlayers
+        self.lbl = engine.LBL(self.voigt, self.lines, g['wn'], g['divisors'], atm['mol_radius'],
+                              atm['mol_mass'], iso['isoimol'], iso['isomass'], iso['isoratio'],
+                              iso['isoiext'], vg['cutoff'], case['ethresh'], max_layers=K * L)
+        dev = engine.dev
+        self.temp = dev(np.concatenate([atm['temp']] * K))
+        self.dens = dev(np.concatenate([atm['dens']] * K))
+        self.isoz = dev(np.concatenate([iso['isoz']] * K, axis=1))
+        self.radius = [dev(atm['radius']) for _ in range(K)]
+        path = engine.pack_raypath(engine.transit_path(atm['radius'], itop), itop)
+        self.raypath = [dev(path) for _ in range(K)]
+        self.ec = torch.empty((K * L, 1, self.wcount), dtype=torch.float64, device='cuda')
+        self.spectrum_out = [None] * K      # gather slots ([wcount] tensors) or None
+        self.kmax_exchange = None           # dist.kmax_allreduce(): the two-phase shard form
+        self.spectra = [None] * K
+
+    def set_atmosphere(self, k, temp, dens, isoz, radius=None):
+        """Atmosphere k of the stack for the next run() (arguments as LBLSpectrum.set_atmosphere)."""
+        e, L = self.engine, self.nlayers
+        self.temp[k * L:(k + 1) * L].copy_(e.dev(temp))
+        self.dens[k * L:(k + 1) * L].copy_(e.dev(dens))
+        self.isoz[:, k * L:(k + 1) * L].copy_(e.dev(isoz))
+        if radius is not None:
+            self.radius[k].copy_(e.dev(radius))
+            self.raypath[k].copy_(e.dev(e.pack_raypath(e.transit_path(radius, self.itop),
+                                                       self.itop)))
+
+    def run(self):
+        """-> the K spectra (device tensors [wcount]; the gather slots when given)."""
+        e, K, L = self.engine, self.stack, self.nlayers
+        if self.kmax_exchange is not None:
+            self.lbl.extinction_begin(self.temp, self.dens, self.isoz, add=True, out=self.ec,
+                                      wbegin=self.wbegin, wcount=self.wcount)
+            self.kmax_exchange(self.lbl.kmax_tensor())
+            self.lbl.extinction_end()
+        else:
+            self.lbl.extinction(self.temp, self.dens, self.isoz, add=True, out=self.ec,
+                                wbegin=self.wbegin, wcount=self.wcount)
+        for k in range(K):
+            self.spectra[k], _, _ = e.transit_spectrum(
+                self.ec[k * L:(k + 1) * L].view(L, self.wcount), self.raypath[k], self.radius[k],
+                self.rstar, self.itop, L, self.maxdepth, out=self.spectrum_out[k])
+        return self.spectra
+
+
 class ShardPipeline:
     """Consecutive, independent spectra of a WAVENUMBER-sharded run kept in flight per rank:
     spectrum i+1's extinction runs on a second HIP stream while spectrum i waits for its
@@ -422,13 +498,40 @@ class ShardPipeline:
     collectives in the same order on one communicator -- all-reduce(i+1) BEFORE all-gather(i), see
     submit() -- so they pair up across the ranks.  submit() -> (full spectrum on every rank,
     event) of the PREVIOUS submission or None; flush() -> those of the last one, and joins the
-    caller's stream."""
+    caller's stream.
+
+    stack = K > 1 (transit geometry, constant-step grids): every context is a StackedShard -- K
+    atmospheres per extinction call, ONE all-reduce of their maxima, K all-gathers; submit()
+    then enqueues K spectra and returns ([K full spectra], event) of the previous submission."""
 
     def __init__(self, case, world, rank, depth=2, group=None, kmax_exchange=True,
-                 voigt=None, lines=None, rt_path='transit', **model_kw):
+                 voigt=None, lines=None, rt_path='transit', stack=1, **model_kw):
         from . import engine
         nwave = case['grid']['nwave']
         self.world, self.rank, self.group = world, rank, group
+        self.stack = int(stack)
+        if self.stack > 1:
+            assert rt_path == 'transit', 'stack > 1: transit geometry'
+            self.gathers = [[SpectrumGather(nwave, world, rank, 'cuda', group, uniform=True)
+                             for _ in range(self.stack)] for _ in range(depth)]
+            g0 = self.gathers[0][0]
+            first = StackedShard(case, self.stack, g0.wbegin, g0.wcount,
+                                 itop=model_kw.get('itop', 0), voigt=voigt, lines=lines)
+            self.models = [first] + [StackedShard(case, self.stack, g0.wbegin, g0.wcount,
+                                                  itop=model_kw.get('itop', 0),
+                                                  voigt=first.voigt, lines=first.lines)
+                                     for _ in range(depth - 1)]
+            for m, gs in zip(self.models, self.gathers):
+                m.lbl.set_concurrency(depth)
+                if kmax_exchange and world > 1:
+                    m.kmax_exchange = kmax_allreduce(group)
+                if world > 1:
+                    m.spectrum_out = [g.slot for g in gs]
+            self.streams = engine.side_streams(depth)
+            self.done = [None] * depth
+            self.count = 0
+            self.pending = None
+            return
         self.gathers = [SpectrumGather(nwave, world, rank, 'cuda', group, uniform=True)
                         for _ in range(depth)]
         g0 = self.gathers[0]
@@ -448,16 +551,26 @@ class ShardPipeline:
         self.pending = None          # (context, shard) whose all-gather has not been issued yet
 
     def set_atmosphere(self, *args, **kw):
+        """One atmosphere for every context (stack > 1: for every slot of every stack; use
+        models[j].set_atmosphere(k, ...) for distinct ones)."""
         for m in self.models:
-            m.set_atmosphere(*args, **kw)
+            if self.stack > 1:
+                for k in range(self.stack):
+                    m.set_atmosphere(k, *args, **kw)
+            else:
+                m.set_atmosphere(*args, **kw)
 
     def _close(self):
-        """Issue the all-gather of the pending spectrum on its own stream -> (full, event)."""
+        """Issue the all-gather(s) of the pending submission on its own stream -> (full, event);
+        stack > 1: ([K full spectra], event)."""
         j, local = self.pending
         self.pending = None
         stream = self.streams[j]
         with torch.cuda.stream(stream):
-            full = self.gathers[j](local)
+            if self.stack > 1:
+                full = [g(x) for g, x in zip(self.gathers[j], local)]
+            else:
+                full = self.gathers[j](local)
             event = torch.cuda.Event()
             event.record(stream)
         self.done[j] = event

@@ -482,6 +482,64 @@ def test_shard_pipeline_single_process(eng, case):
         hinted.lbl.set_concurrency(0)
 
 
+@pytest.mark.parametrize('stack', [2, 3])
+def test_shard_pipeline_stacked_atmospheres(eng, case, monkeypatch, stack):
+    """dist.ShardPipeline(stack=K): K atmospheres per extinction call (dist.StackedShard).  K
+    DIFFERENT atmospheres in one submission each equal LBLSpectrum.run() of that atmosphere on
+    the same shard (1e-12; bit for bit with the phase split pinned), over several submissions and
+    through flush(); the two-phase form (kmax exchange hook) included."""
+    import torch
+    from pyratbay_amd.dist import ShardPipeline
+    atm, iso = case['atm'], case['iso']
+    nwave = case['grid']['nwave']
+    a, b = nwave // 5, nwave // 5 + nwave // 3                # a shard in the middle
+    serial = eng.LBLSpectrum(case, rt_path='transit', wbegin=a, wcount=b - a)
+    atms = []
+    for k in range(stack):
+        temp = atm['temp'] * (1.0 + 0.04 * k) + 3.0 * k
+        dens = atm['dens'] * (atm['temp'] / temp)[:, None]
+        isoz = iso['isoz'] * (1.0 + 0.01 * k)
+        radius = atm['radius'] * (1.0 + 0.002 * k)
+        atms.append((temp, dens, isoz, radius))
+    want = []
+    for t in atms:
+        serial.set_atmosphere(*t)
+        want.append(serial.run().clone())
+    assert not torch.equal(want[0], want[1])
+    for pinned in (False, True):
+        if pinned:
+            monkeypatch.setenv('PB_STAGE_SPLIT', '2')
+            want = []
+            for t in atms:
+                serial.set_atmosphere(*t)
+                want.append(serial.run().clone())
+        pipe = ShardPipeline(case, 1, 0, depth=2, voigt=serial.voigt, lines=serial.lines,
+                             stack=stack)
+        # (world 1: the pipeline's shard is the whole grid; compare on the serial model's shard)
+        for m in pipe.models:
+            m.kmax_exchange = lambda t: None                  # the two-phase form, one rank
+            for k, t in enumerate(atms):
+                m.set_atmosphere(k, *t)
+        outs = []
+        for i in range(3):
+            r = pipe.submit()
+            assert (r is None) == (i == 0)
+            if r is not None:
+                r[1].synchronize()
+                outs.append([x.clone() for x in r[0]])
+        last = pipe.flush()
+        torch.cuda.synchronize()
+        outs.append([x.clone() for x in last[0]])
+        assert len(outs) == 3 and all(len(o) == stack for o in outs)
+        for o in outs:
+            for k in range(stack):
+                got = o[k][a:b]
+                if pinned:
+                    assert torch.equal(got, want[k]), k
+                np.testing.assert_allclose(got.cpu().numpy(), want[k].cpu().numpy(), rtol=1e-12)
+        del pipe
+
+
 @pytest.mark.gpu_experiments
 def test_resolution_mode_predicted_runs(eng, monkeypatch):
     """`resolution` mode with the run plan taken from the last read-back of the layers' factors

@@ -5,7 +5,7 @@ all-reduce(MAX) of the maxima and the closing all-gather issued exactly as dist.
 them (same tensors, same streams; the all-gather of this rank's padded shard into a buffer of its
 own size).  What it measures beyond tools/bench_wshard.py: the host's submission cost of a spectrum
 (library calls + torch ops + two collectives) against the 0.18 ms of GPU work of a 1/8 shard.
-usage: python tools/bench_rank_rccl.py <world> [workload] [streams]"""
+usage: python tools/bench_rank_rccl.py <world> [workload] [streams] [stack]"""
 import os
 import sys
 import time
@@ -43,25 +43,42 @@ class OneRankGather(pbdist.SpectrumGather):
 
 
 def measure(world, name='c2', streams=3, steps=200, voigt=None, lines=None, collectives=(True, False),
-            log=None, prime_seconds=0.3, keep=False):
+            log=None, prime_seconds=0.3, keep=False, stack=1):
     """ms per spectrum (and host submission ms) of rank world // 2 of `world`, `streams` spectra in
     flight, with the collectives through the (already initialised, one-rank) RCCL group and/or
     without them.  Returns {label: (ms_per_spectrum, host_ms_per_spectrum)}."""
     case = bench.make_case(bench.WORKLOADS[name])
     nwave = case['grid']['nwave']
     r = world // 2
-    pipe = pbdist.ShardPipeline(case, world, r, depth=streams, kmax_exchange=True, voigt=voigt,
-                                lines=lines,
-                                timestamps=os.environ.get('PB_TIMESTAMPS', '0') == '1')
-    pipe.gathers = [OneRankGather(nwave, world, r, 'cuda', uniform=True) for _ in range(streams)]
-    for m, g in zip(pipe.models, pipe.gathers):
-        m.spectrum_out = g.slot if g.uniform else None
+    if stack > 1:
+        # K atmospheres per extinction call (dist.StackedShard): K x streams spectra in flight
+        pipe = pbdist.ShardPipeline(case, world, r, depth=streams, kmax_exchange=True, voigt=voigt,
+                                    lines=lines, stack=stack)
+        pipe.gathers = [[OneRankGather(nwave, world, r, 'cuda', uniform=True)
+                         for _ in range(stack)] for _ in range(streams)]
+        for m, gs in zip(pipe.models, pipe.gathers):
+            m.spectrum_out = [g.slot for g in gs]
+    else:
+        pipe = pbdist.ShardPipeline(case, world, r, depth=streams, kmax_exchange=True, voigt=voigt,
+                                    lines=lines,
+                                    timestamps=os.environ.get('PB_TIMESTAMPS', '0') == '1')
+        pipe.gathers = [OneRankGather(nwave, world, r, 'cuda', uniform=True) for _ in range(streams)]
+        for m, g in zip(pipe.models, pipe.gathers):
+            m.spectrum_out = g.slot if g.uniform else None
     out = {}
     for coll in collectives:
         label = 'collectives through RCCL (one rank)' if coll else 'no collectives'
         for i, m in enumerate(pipe.models):
             m.kmax_exchange = pbdist.kmax_allreduce() if coll else (lambda t: None)
-        if not coll:
+        if not coll and stack > 1:
+            for m in pipe.models:
+                m.spectrum_out = [None] * stack
+            pipe.gathers = [[pbdist.SpectrumGather(nwave, 1, 0, 'cuda') for _ in range(stack)]
+                            for _ in range(streams)]
+            for gs, m in zip(pipe.gathers, pipe.models):
+                for g in gs:
+                    g.bounds = np.array([0, m.wcount])
+        elif not coll:
             for m in pipe.models:
                 m.spectrum_out = None
             pipe.gathers = [pbdist.SpectrumGather(nwave, 1, 0, 'cuda') for _ in range(streams)]
@@ -77,18 +94,20 @@ def measure(world, name='c2', streams=3, steps=200, voigt=None, lines=None, coll
             torch.cuda.synchronize()
             if time.perf_counter() - tw >= prime_seconds:
                 break
+        nsub = -(-steps // stack)
         t0 = time.perf_counter()
-        for _ in range(steps):
+        for _ in range(nsub):
             pipe.submit()
         t_submit = time.perf_counter() - t0
         pipe.flush()
         torch.cuda.synchronize()
         t_all = time.perf_counter() - t0
-        out[label] = (1e3 * t_all / steps, 1e3 * t_submit / steps)
+        done = nsub * stack
+        out[label] = (1e3 * t_all / done, 1e3 * t_submit / done)
         if log:
-            log(f'{name} rank {r}/{world}, {streams} in flight, {label}: '
-                f'{1e3 * t_all / steps:.3f} ms/spectrum, host submission '
-                f'{1e3 * t_submit / steps:.3f} ms/spectrum')
+            log(f'{name} rank {r}/{world}, {streams} x {stack} in flight, {label}: '
+                f'{1e3 * t_all / done:.4f} ms/spectrum, host submission '
+                f'{1e3 * t_submit / done:.3f} ms/spectrum')
     if keep:
         out['voigt'] = pipe.models[0].voigt
     return out
@@ -101,7 +120,8 @@ def main():
     steps = int(os.environ.get('PB_WSHARD_STEPS', '200'))
     torch.cuda.set_device(0)
     dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))
-    measure(world, name, streams, steps, log=lambda s: print(s, flush=True))
+    stack = int(sys.argv[4]) if len(sys.argv) > 4 else 1
+    measure(world, name, streams, steps, log=lambda s: print(s, flush=True), stack=stack)
     dist.destroy_process_group()
 
 
