@@ -650,6 +650,7 @@ def main():
         software-pipelined unless PB_PIPELINE=0)."""
         t0 = time.perf_counter()
         res = {'kind': kind}
+        per = 1                      # spectra per submission (> 1: dist.StackedShard)
         if kind == 'layers':
             sharded = LayerShardedTransit(case, world, rank, voigt=shared.get('voigt'),
                                           lines=shared.get('lines'))
@@ -679,13 +680,22 @@ def main():
             exchange = os.environ.get('PB_KMAX_EXCHANGE', '1') != '0'
             if streams > 1 and world > 1 and not replicas:
                 from pyratbay_amd.dist import ShardPipeline
+                # K atmospheres per extinction call (dist.StackedShard): a rank-size gather launch
+                # is short and the small launches around it do not shrink with N -- 0.159 -> 0.145
+                # ms per spectrum for a 1/8 shard of C2 at K = 3 (profiles/r05_rank_stack.log);
+                # PB_STACK=1: one atmosphere per call
+                if rt_path == 'transit' and not w.get('resolution'):
+                    per = max(1, int(os.environ.get('PB_STACK', '3')))
                 # (no stage timers in the rank loop: four library calls per spectrum less for the
                 # host, which at 8 ranks has ~0.18 ms per spectrum to submit everything)
+                kw_pipe = dict(stack=per) if per > 1 else dict(rt_path=rt_path, timestamps=False)
                 pipe = ShardPipeline(case, world, rank, depth=streams, kmax_exchange=exchange,
                                      voigt=shared.get('voigt'), lines=shared.get('lines'),
-                                     rt_path=rt_path, timestamps=False)
-                model, gather = pipe.models[0], pipe.gathers[0]
+                                     **kw_pipe)
+                model = pipe.models[0]
+                gather = pipe.gathers[0][0] if per > 1 else pipe.gathers[0]
                 res['streams'] = streams
+                res['stack'] = per
             elif streams > 1:
                 pipe = engine.SpectrumPipeline(case, depth=streams, rt_path=rt_path,
                                                voigt=shared.get('voigt'),
@@ -699,36 +709,42 @@ def main():
                 if world > 1 and not replicas and exchange:
                     from pyratbay_amd.dist import kmax_allreduce
                     model.kmax_exchange = kmax_allreduce()     # records of the shard's groups only
-            res.update(wcount=gather.wcount, nlayers_rank=nlayers)
+            res.update(wcount=gather.wcount, nlayers_rank=nlayers * per)
             pipelined = False
 
             def step():
                 # every rank computes its wavenumber shard, then the shards are re-assembled
                 # on every rank (RCCL all-gather over xGMI when world > 1)
+                if per > 1:
+                    return [g(x) for g, x in zip(pipe.gathers[0], model.run())][-1]
                 return gather(model.run())
             pipelined = streams > 1
         shared.setdefault('voigt', model.voigt)
         shared.setdefault('lines', model.lines)
+
+        def spectra_of(k):
+            """Spectra that run_steps(k) computes: k rounded up to whole submissions."""
+            return -(-k // per) * per
 
         def run_steps(k):
             if pipelined and kind != 'layers':
                 # (SpectrumPipeline.submit returns this spectrum; ShardPipeline.submit the previous
                 # one -- its all-gather is issued behind the next all-reduce -- and flush() the last)
                 out = None
-                for _ in range(k):
+                for _ in range(-(-k // per)):
                     r = pipe.submit()
                     if r is not None:
                         out = r[0]
                 last = pipe.flush()
                 if last is not None:
                     out = last[0]
-                return [out]
+                return [out[-1] if isinstance(out, list) else out]
             if pipelined:
                 for _ in range(k):
                     sharded.submit()
                 return sharded.flush()
             out = None
-            for _ in range(k):
+            for _ in range(-(-k // per)):
                 out = step()
             return [out]
 
@@ -786,21 +802,22 @@ def main():
                 torch.cuda.synchronize, dev_reduce)
         res['gpu_state'] = state.summary()
         # (replicas: every rank completed `steps` spectra of its own in that time)
+        nspec = spectra_of(args.steps)
         res.update(model=model, elapsed=elapsed, gather_ms=gather_ms, launches=launches,
-                   value=args.steps / elapsed * (world if kind == 'replicas' else 1),
-                   ms_per_step=1e3 * elapsed / args.steps,
+                   value=nspec / elapsed * (world if kind == 'replicas' else 1),
+                   ms_per_step=1e3 * elapsed / nspec, spectra_timed=nspec,
                    pipelined=pipelined, run_steps=run_steps)
         # the un-pipelined per-spectrum latency (one spectrum complete before the next starts)
         # beside the pipelined throughput, so that the one is not mistaken for the other
         if pipelined:
             def one_at_a_time(k):
                 out = None
-                for _ in range(k):
+                for _ in range(-(-k // per)):
                     out = step()
                 return [out]
             el2, g2, l2 = timed_steps(one_at_a_time, args.steps, 1, model.lbl, world, dist,
                                       torch.cuda.synchronize, dev_reduce)
-            res['unpipelined_ms_per_spectrum'] = 1e3 * el2 / args.steps
+            res['unpipelined_ms_per_spectrum'] = 1e3 * el2 / nspec
             if kind != 'layers':
                 # the gather kernel's own duration (roofline) is the one measured with nothing
                 # else on the chip, not the one stretched by the neighbouring stream
@@ -882,8 +899,8 @@ def main():
                 primary['run_steps'](3)[-1].cpu().numpy())
 
     if rank == 0:
-        ms_per_step = 1e3 * elapsed / args.steps
-        value = args.steps / elapsed
+        ms_per_step = primary['ms_per_step']
+        value = primary['value']
         n_lines = model.lines.nlines
         roof = roofline_block(model, gather_ms, launches, nlayers_rank, wcount, nlayers, nwave,
                               value, args.workload if world == 1 else None)
@@ -895,7 +912,8 @@ def main():
                    'all-gather' + (', consecutive spectra pipelined' if pipelined else ''))
         else:
             par = (f'wavenumber shards x{world} + all-reduce(MAX) of the line-strength maxima + '
-                   'all-gather' + (f", {primary['streams']} spectra in flight per rank"
+                   'all-gather' + (f", {primary['streams']} submissions of "
+                                   f"{primary.get('stack', 1)} atmospheres in flight per rank"
                                    if pipelined else ''))
         out = {
             'metric': metric_name(nwave, nlayers, w),
@@ -920,6 +938,8 @@ def main():
                 f'{st[0]} predicted / {st[1]} synchronous calls of this plan'
                 if os.environ.get('PB_RES_DYN_PREDICT') == '1' else
                 'one stream synchronisation per call (default)')
+        if primary.get('spectra_timed') != args.steps:
+            out['config']['spectra_timed'] = primary.get('spectra_timed')
         if latency_ms is not None:
             out['config']['unpipelined_ms_per_spectrum'] = latency_ms
         if primary.get('priming_spectra'):
@@ -935,7 +955,7 @@ def main():
             # both decompositions of the same run
             out['config']['value_from'] = primary['kind']
             out['config']['decompositions'] = [
-                {k: r[k] for k in ('kind', 'value', 'ms_per_step', 'pipelined', 'streams',
+                {k: r[k] for k in ('kind', 'value', 'ms_per_step', 'pipelined', 'streams', 'stack',
                                    'unpipelined_ms_per_spectrum', 'parity_vs_single_gpu',
                                    'init_seconds') if k in r}
                 for r in runs] + failed
@@ -1002,7 +1022,9 @@ def rank_worker():
     if not sys.stdin.readline().strip():
         return                                           # the parent went away
     proj = {'note': 'per-rank compute + collectives through a ONE-rank RCCL group on one GPU; '
-                    'no inter-GPU traffic is measured', 'ranks': {}}
+                    'no inter-GPU traffic is measured; a rank keeps 3 submissions of '
+                    '`atmospheres_per_call` atmospheres in flight (dist.StackedShard), the '
+                    'single-GPU step it is compared with keeps 2 spectra in flight', 'ranks': {}}
     with stdout_to_stderr():
         try:
             import torch
@@ -1017,12 +1039,20 @@ def rank_worker():
             voigt = None
             for name in ('c2', NORTH_STAR):
                 rows = {}
+                stack = max(1, int(os.environ.get('PB_STACK', '3')))
                 for world in (2, 4, 8):
-                    r = brr.measure(world, name, 3, 200, voigt=voigt, collectives=(True,),
-                                    keep=True)
+                    # as `bench.py --gpus N` runs a rank: 3 submissions of `stack` atmospheres in
+                    # flight (dist.StackedShard); and one atmosphere per call beside it
+                    r = brr.measure(world, name, 3, 240, voigt=voigt, collectives=(True,),
+                                    keep=True, stack=stack)
                     ms, host = r['collectives through RCCL (one rank)']
                     voigt = r['voigt']                   # same grid: one table for all of them
-                    rows[f'N={world}'] = {'ms_per_spectrum': ms, 'host_submission_ms': host}
+                    rows[f'N={world}'] = {'ms_per_spectrum': ms, 'host_submission_ms': host,
+                                          'atmospheres_per_call': stack}
+                    if stack > 1:
+                        r1 = brr.measure(world, name, 3, 200, voigt=voigt, collectives=(True,))
+                        rows[f'N={world}']['one_atmosphere_per_call_ms'] = \
+                            r1['collectives through RCCL (one rank)'][0]
                 proj['ranks'][name] = rows
             dist.destroy_process_group()
         except Exception as e:                           # noqa: BLE001
