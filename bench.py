@@ -930,14 +930,8 @@ def main():
             'roofline': roof,
         }
         if w.get('resolution'):
-            # (the `resolution` path reads the layers' factors back once per call unless the run
-            # plans are predicted: DESIGN.md section 6b)
-            st = model.lbl.dyn_stats()
-            out['config']['run_plans'] = (
-                'predicted from the last read-back (PB_RES_DYN_PREDICT=1): '
-                f'{st[0]} predicted / {st[1]} synchronous calls of this plan'
-                if os.environ.get('PB_RES_DYN_PREDICT') == '1' else
-                'one stream synchronisation per call (default)')
+            # (the `resolution` path reads the layers' factors back once per call: DESIGN.md 6b)
+            out['config']['run_plans'] = 'one stream synchronisation per call'
         if primary.get('spectra_timed') != args.steps:
             out['config']['spectra_timed'] = primary.get('spectra_timed')
         if latency_ms is not None:
