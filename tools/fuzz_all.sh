@@ -16,3 +16,4 @@ run tools/fuzz_opacity.py $((2000 * s))
 run tools/fuzz_r3.py $((3000 * s))
 run tools/fuzz_resdyn.py $((3000 * s))
 run tools/fuzz_r4.py $((400 * s))
+run tools/fuzz_r5.py $((300 * s))
