@@ -650,6 +650,7 @@ def main():
         software-pipelined unless PB_PIPELINE=0)."""
         t0 = time.perf_counter()
         res = {'kind': kind}
+        state = Sampler()            # (made here, entered around the timed regions: see gpu_state.py)
         per = 1                      # spectra per submission (> 1: dist.StackedShard)
         if kind == 'layers':
             sharded = LayerShardedTransit(case, world, rank, voigt=shared.get('voigt'),
@@ -796,7 +797,7 @@ def main():
         torch.cuda.synchronize()
         res['init_seconds'] = round(time.perf_counter() - t0, 3)
 
-        with Sampler() as state:
+        with state:
             elapsed, gather_ms, launches = timed_steps(
                 run_steps, args.steps, args.warmup, model.lbl, world, dist,
                 torch.cuda.synchronize, dev_reduce)
@@ -832,7 +833,7 @@ def main():
                 return [out]
             sus = {'seconds_target': args.sustain_seconds}
             n = max(args.steps, int(np.ceil(1.05 * args.sustain_seconds * args.steps / elapsed)))
-            with Sampler() as state:
+            with state:
                 el, _, _ = timed_steps(run_steps, n, 0, model.lbl, world, dist,
                                        torch.cuda.synchronize, dev_reduce, kernel_events=False)
             res['gpu_state'] = state.summary() or res.get('gpu_state')

@@ -364,25 +364,27 @@ __device__ inline double planck_factor(double wn)
 // division is pb::quot's three instructions; every kernel forms B this way (same bits)
 __device__ inline double planck_q(double factor, double wn, double kt, double inv_kt)
 {
-    return factor / (pb::exp_s(pb::quot(pb::kH * pb::kLS * wn, kt, inv_kt)) - 1.0);
+    return factor / (pb::exp_s(pb::quot_fast(pb::kH * pb::kLS * wn, kt, inv_kt)) - 1.0);
 }
 __device__ inline double planck(double factor, double wn, double temp)
 {
-    const double kt = pb::kKB * temp;
-    return planck_q(factor, wn, kt, 1.0 / kt);
+    double kt, inv_kt;
+    pb::sane_divisor(pb::kKB * temp, kt, inv_kt);      // (T = 0 -> B = 0 like the reference)
+    return planck_q(factor, wn, kt, inv_kt);
 }
 // s_kt[0 .. 2 nlayers): kKB * temp[k] and 1 / (kKB * temp[k]) of one temperature profile, then
 // 1 / mu[m] for the nmu quadrature angles (the angles themselves stay scalar loads)
 __device__ inline void planck_terms(double *s_kt, const double *temp, int nlayers,
                                     const double *mu = nullptr, int nmu = 0)
 {
-    for (int k = threadIdx.x; k < nlayers; k += blockDim.x) {
-        const double kt = pb::kKB * temp[k];
-        s_kt[k] = kt;
-        s_kt[nlayers + k] = 1.0 / kt;
+    // (sane_divisor: a layer at T = 0 or a ray at mu = 0 keeps pb::quot_fast finite; the results
+    // are those of the true divisions)
+    for (int k = threadIdx.x; k < nlayers; k += blockDim.x)
+        pb::sane_divisor(pb::kKB * temp[k], s_kt[k], s_kt[nlayers + k]);
+    for (int m = threadIdx.x; m < nmu; m += blockDim.x) {
+        double ms;
+        pb::sane_divisor(mu[m], ms, s_kt[2 * nlayers + m]);
     }
-    for (int m = threadIdx.x; m < nmu; m += blockDim.x)
-        s_kt[2 * nlayers + m] = 1.0 / mu[m];
     __syncthreads();
 }
 
@@ -424,7 +426,8 @@ __global__ void k_intensity(double *out, const double *tau, const int32_t *ideep
     int last = ideep[j];
     if (last > nlayers - 1)
         last = nlayers - 1;
-    const double m = mu[k], im = 1.0 / m;
+    double m, im;
+    pb::sane_divisor(mu[k], m, im);
     double blast = bbody[(int64_t)last * nwave + j];
     double result;
     if (last - rtop == 1) {
@@ -432,17 +435,17 @@ __global__ void k_intensity(double *out, const double *tau, const int32_t *ideep
     } else {
         double acc = 0.0;
         if (last > rtop) {
-            double eprev = pb::exp_s(pb::quot(-tau[(int64_t)rtop * nwave + j], m, im));
+            double eprev = pb::exp_s(pb::quot_fast(-pb::clamp_depth(tau[(int64_t)rtop * nwave + j]), m, im));
             double bprev = bbody[(int64_t)rtop * nwave + j];
             for (int i = rtop; i < last; i++) {
-                double enext = pb::exp_s(pb::quot(-tau[(int64_t)(i + 1) * nwave + j], m, im));
+                double enext = pb::exp_s(pb::quot_fast(-pb::clamp_depth(tau[(int64_t)(i + 1) * nwave + j]), m, im));
                 double bnext = bbody[(int64_t)(i + 1) * nwave + j];
                 acc += (enext - eprev) * (bnext + bprev);
                 eprev = enext;
                 bprev = bnext;
             }
         }
-        result = blast * pb::exp_s(pb::quot(-tau[(int64_t)last * nwave + j], m, im)) - 0.5 * acc;
+        result = blast * pb::exp_s(pb::quot_fast(-pb::clamp_depth(tau[(int64_t)last * nwave + j]), m, im)) - 0.5 * acc;
     }
     out[(int64_t)k * nwave + j] = result;
 }
@@ -471,22 +474,22 @@ __global__ void k_emission_flux(double *flux, double *intensity, const double *t
     const double w = wn[j];
     const double factor = planck_factor(w);
     double acc[MU], eprev[MU];
-    double t0 = tau[(int64_t)rtop * nwave + j];
+    double t0 = pb::clamp_depth(tau[(int64_t)rtop * nwave + j]);
 #pragma unroll
     for (int k = 0; k < MU; k++) {
         acc[k] = 0.0;
-        eprev[k] = k < nmu ? pb::exp_s(pb::quot(-t0, mu[k], s_imu[k])) : 0.0;
+        eprev[k] = k < nmu ? pb::exp_s(pb::quot_fast(-t0, mu[k], s_imu[k])) : 0.0;
     }
     double bprev = planck_q(factor, w, s_kt[rtop], s_kt[nlayers + rtop]);
     double tlast = t0;
     for (int i = rtop; i < last; i++) {
-        double t = tau[(int64_t)(i + 1) * nwave + j];
+        double t = pb::clamp_depth(tau[(int64_t)(i + 1) * nwave + j]);
         double bnext = planck_q(factor, w, s_kt[i + 1], s_kt[nlayers + i + 1]);
         double bsum = bnext + bprev;
 #pragma unroll
         for (int k = 0; k < MU; k++) {
             if (k < nmu) {
-                double enext = pb::exp_s(pb::quot(-t, mu[k], s_imu[k]));
+                double enext = pb::exp_s(pb::quot_fast(-t, mu[k], s_imu[k]));
                 acc[k] += (enext - eprev[k]) * bsum;
                 eprev[k] = enext;
             }
@@ -496,7 +499,7 @@ __global__ void k_emission_flux(double *flux, double *intensity, const double *t
     }
     double blast = (last > rtop) ? bprev : planck_q(factor, w, s_kt[last], s_kt[nlayers + last]);
     if (last <= rtop)
-        tlast = tau[(int64_t)last * nwave + j];
+        tlast = pb::clamp_depth(tau[(int64_t)last * nwave + j]);
     double total = 0.0;
 #pragma unroll
     for (int k = 0; k < MU; k++) {
@@ -505,7 +508,7 @@ __global__ void k_emission_flux(double *flux, double *intensity, const double *t
             if (last - rtop == 1)
                 val = blast;
             else
-                val = blast * pb::exp_s(pb::quot(-tlast, mu[k], s_imu[k])) - 0.5 * acc[k];
+                val = blast * pb::exp_s(pb::quot_fast(-tlast, mu[k], s_imu[k])) - 0.5 * acc[k];
             if (intensity)
                 intensity[(int64_t)k * nwave + j] = val;
             total += val * weights[k];
@@ -547,7 +550,7 @@ __global__ void k_emission_fused(double *flux, const double *ec, const double *i
 #pragma unroll
     for (int k = 0; k < MU; k++) {
         acc[k] = 0.0;
-        eprev[k] = k < nmu ? pb::exp_s(pb::quot(-0.0, mu[k], s_imu[k])) : 0.0;   // depth[rtop] = 0
+        eprev[k] = k < nmu ? pb::exp_s(pb::quot_fast(-0.0, mu[k], s_imu[k])) : 0.0;   // depth[rtop] = 0
     }
     double bprev = planck_q(factor, w, s_kt[rtop], s_kt[nlayers + rtop]);
     double depth = 0.0, tlast = 0.0;
@@ -570,10 +573,11 @@ __global__ void k_emission_fused(double *flux, const double *ec, const double *i
         // intensity terms of the interval (k-1, k)
         const double bnext = planck_q(factor, w, s_kt[k], s_kt[nlayers + k]);
         const double bsum = bnext + bprev;
+        const double dq = pb::clamp_depth(depth);             // (exp(-inf / mu) = 0 without a NaN)
 #pragma unroll
         for (int m = 0; m < MU; m++) {
             if (m < nmu) {
-                const double enext = pb::exp_s(pb::quot(-depth, mu[m], s_imu[m]));
+                const double enext = pb::exp_s(pb::quot_fast(-dq, mu[m], s_imu[m]));
                 acc[m] += (enext - eprev[m]) * bsum;
                 eprev[m] = enext;
             }
@@ -602,7 +606,7 @@ __global__ void k_emission_fused(double *flux, const double *ec, const double *i
             if (last - rtop == 1)
                 val = blast;
             else
-                val = blast * pb::exp_s(pb::quot(-tlast, mu[m], s_imu[m])) - 0.5 * acc[m];
+                val = blast * pb::exp_s(pb::quot_fast(-pb::clamp_depth(tlast), mu[m], s_imu[m])) - 0.5 * acc[m];
             total += val * weights[m];
         }
     }

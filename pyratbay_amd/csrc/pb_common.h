@@ -117,6 +117,38 @@ __device__ __forceinline__ double quot(double x, double d, double inv)
     return r;
 }
 
+// The same without the guard, for callers that keep the special values away from it themselves
+// (the guard's compare + branch per quotient cost 5 % of k_records and of the emission kernels):
+//   * divisors through sane_divisor(): 0 -> (2^-1000, 2^1000), +inf -> (2^1000, 2^-1000) -- the
+//     quotient is then huge / tiny but finite, and what the callers do with it (exp, then a
+//     product or a division) ends in the same 0 the true division gives;
+//   * numerators clamped to a finite value with the same result (clamp_depth: exp(-1e5 / mu) is
+//     exactly 0 for mu <= 1, like exp(-inf / mu));
+//   * or one test of the END result and a recomputation with true divisions (line_strength).
+__device__ __forceinline__ double quot_fast(double x, double d, double inv)
+{
+    const double q = x * inv;
+    return fma(fma(-q, d, x), inv, q);
+}
+__device__ __forceinline__ void sane_divisor(double d, double &ds, double &inv)
+{
+    ds = d;
+    inv = 1.0 / d;
+    if (d == 0.0) {
+        ds = 0x1p-1000;
+        inv = 0x1p+1000;
+    } else if (d > 0x1p+1000) {
+        ds = 0x1p+1000;
+        inv = 0x1p-1000;
+    }
+}
+// an optical depth as the numerator of exp(-depth / mu): NaN stays NaN, +inf and anything above 1e5
+// become 1e5 (the exponential is exactly 0 either way)
+__device__ __forceinline__ double clamp_depth(double t)
+{
+    return t > 1e5 ? 1e5 : t;
+}
+
 // exp() with its constants in SGPRs.  The arithmetic is the device library's (range reduction by
 // ln2 in two parts, degree-11 polynomial, ldexp, the same overflow/underflow selects), so the
 // result is the same bit pattern; what changes is that the polynomial coefficients sit in scalar

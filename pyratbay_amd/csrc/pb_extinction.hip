@@ -71,10 +71,17 @@ static_assert(kTile < 65536, "window coordinates are packed in 16 bits");
 __device__ inline double line_strength(double ratio, double gf, double elow, double wavn,
                                        double temp, double inv_temp, double z, double inv_z)
 {
-    return pb::quot(pb::kSigCte * ratio * gf *
-                        pb::exp_s(pb::quot(-pb::kExpCte * elow, temp, inv_temp)) *
-                        (1 - pb::exp_s(pb::quot(-pb::kExpCte * wavn, temp, inv_temp))),
-                    z, inv_z);
+    const double k = pb::quot_fast(pb::kSigCte * ratio * gf *
+                                       pb::exp_s(pb::quot_fast(-pb::kExpCte * elow, temp, inv_temp)) *
+                                       (1 - pb::exp_s(pb::quot_fast(-pb::kExpCte * wavn, temp, inv_temp))),
+                                   z, inv_z);
+    // one test of the END result instead of one per quotient: a special value in any of the three
+    // (temp or z zero / infinite, an infinite numerator) ends as NaN or 0 here -- then, and when
+    // the strength has really underflowed, the reference's own divisions decide
+    if (__builtin_expect(!(fabs(k) > 0.0), 0))
+        return pb::kSigCte * ratio * gf * pb::exp_s(-pb::kExpCte * elow / temp) *
+               (1 - pb::exp_s(-pb::kExpCte * wavn / temp)) / z;
+    return k;
 }
 
 // ---------------------------------------------------------------------------

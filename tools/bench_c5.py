@@ -196,13 +196,14 @@ def main(args):
         flux = model.eval_bands(temps, dens, pb, radius=radius, chunk=CHUNK)
         return gather_walkers(flux, BATCH, world, rank) if world > 1 else flux
 
+    from tools.gpu_state import Sampler
+    state = Sampler()                    # (before the warm-up: see gpu_state.py)
     for i in range(args.warmup):
         out = step(i)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
-    from tools.gpu_state import Sampler
-    with Sampler() as state:
+    with state:
         t0 = time.perf_counter()
         for i in range(steps):
             out = step(i)

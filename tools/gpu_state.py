@@ -86,7 +86,7 @@ class Sampler:
 
     def __init__(self, period=0.05, pci='auto'):
         self.period = period
-        self.cards = cards()
+        self.cards = [] if os.environ.get('PB_GPU_STATE') == '0' else cards()
         self.pci = current_pci() if pci == 'auto' else pci
         if self.pci:
             mine = [c for c in self.cards
@@ -100,6 +100,11 @@ class Sampler:
         self._thread = None
 
     def __enter__(self):
+        # (re-usable: make the object BEFORE the chip is warmed up -- finding the cards in sysfs
+        # takes milliseconds, and milliseconds of idle between the priming spectra and a short
+        # timed region cost 7 % of bench.py's 20-step value -- and enter it right at the region)
+        self.rows = [[] for _ in self.cards]
+        self._stop = threading.Event()
         if self.cards:
             self._thread = threading.Thread(target=self._run, daemon=True)
             self._thread.start()
