@@ -31,7 +31,7 @@ echo "bench c2 done"
 rm -rf gpurun_out/prof_bench gpurun_out/prof_c5 gpurun_out/prof_c5em
 # one spectrum at a time (PB_STREAMS=1): the kernel durations then agree with roofline.kernel_ms,
 # which bench.py measures in its un-pipelined pass
-PB_STREAMS=1 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_bench -- python bench.py --no-cpu-baseline --no-rank-projection --sustain-seconds 0 > gpurun_out/prof_bench.log 2>&1 || exit 1
+PB_STREAMS=1 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_bench -- python bench.py --no-cpu-baseline --no-rank-projection --no-legs --sustain-seconds 0 > gpurun_out/prof_bench.log 2>&1 || exit 1
 cp $(find gpurun_out/prof_bench -name '*kernel_stats.csv' | head -1) gpurun_out/${tag}_kernel_stats.csv
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_c5 -- python bench.py --workload c5 --steps 20 --no-cpu-baseline > gpurun_out/prof_c5.log 2>&1 || exit 1
 cp $(find gpurun_out/prof_c5 -name '*kernel_stats.csv' | head -1) gpurun_out/${tag}_kernel_stats_c5.csv
@@ -47,7 +47,7 @@ python bench.py --workload c3-bands --steps 5 --warmup 2 --cpu-layers 4 > gpurun
 python bench.py --workload c4 --steps 3 --warmup 1 --cpu-layers 2 > gpurun_out/${tag}_bench_c4.json 2> gpurun_out/${tag}_bench_c4.err || exit 1
 echo "other workloads done"
 { for n in 2 4 8; do python tools/bench_wshard.py $n c2 3; done; python tools/bench_wshard.py 8 c2-1e6 3; } 2>&1 | grep shard > gpurun_out/${tag}_wshard.log
-{ python tools/bench_rank_rccl.py 8 c2 3; python tools/bench_rank_rccl.py 4 c2 3; python tools/bench_rank_rccl.py 2 c2 3; python tools/bench_rank_rccl.py 8 c2-1e6 3; } 2>&1 | grep "rank " > gpurun_out/${tag}_rank_rccl.log
+{ python tools/bench_rank_rccl.py 8 c2 3 3; python tools/bench_rank_rccl.py 8 c2 3; python tools/bench_rank_rccl.py 4 c2 3 3; python tools/bench_rank_rccl.py 2 c2 3 3; python tools/bench_rank_rccl.py 8 c2-1e6 3 3; } 2>&1 | grep "rank " > gpurun_out/${tag}_rank_rccl.log
 python tools/bench_dropin.py 2>&1 | grep drop-in > gpurun_out/${tag}_dropin.log
 echo "rank shards done"
 { python tools/bench_ordered.py; for o in 0 1 0 1; do echo "PB_COLUMN_ORDER=$o:"; PB_COLUMN_ORDER=$o python bench.py --workload c5 --no-cpu-baseline | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(' c5', round(d['value']), 'evals/s', round(d['ms_per_step'], 3), 'ms per 64 walkers')"; done; for o in 0 1; do echo "PB_COLUMN_ORDER=$o:"; PB_COLUMN_ORDER=$o python bench.py --workload c5-emission --steps 40 --no-cpu-baseline | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(' c5-emission', round(d['value']), 'evals/s', round(d['ms_per_step'], 3), 'ms per 64 walkers')"; done; } 2>&1 | grep -v amdgpu.ids > gpurun_out/${tag}_ordered.log
