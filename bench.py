@@ -694,7 +694,7 @@ def main():
                                      voigt=shared.get('voigt'), lines=shared.get('lines'),
                                      **kw_pipe)
                 model = pipe.models[0]
-                gather = pipe.gathers[0][0] if per > 1 else pipe.gathers[0]
+                gather = pipe.gathers[0]
                 res['streams'] = streams
                 res['stack'] = per
             elif streams > 1:
@@ -717,7 +717,7 @@ def main():
                 # every rank computes its wavenumber shard, then the shards are re-assembled
                 # on every rank (RCCL all-gather over xGMI when world > 1)
                 if per > 1:
-                    return [g(x) for g, x in zip(pipe.gathers[0], model.run())][-1]
+                    return pipe.gathers[0](model.run())[-1]
                 return gather(model.run())
             pipelined = streams > 1
         shared.setdefault('voigt', model.voigt)

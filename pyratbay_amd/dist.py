@@ -176,6 +176,67 @@ class SpectrumGather:
         return self.full
 
 
+class StackGather:
+    """The closing collective of a StackedShard: the K shards of a stacked submission leave in ONE
+    all_gather_into_tensor (K x pad doubles per rank) instead of K, and one strided copy sorts the
+    blocks [world][K][pad] into K contiguous spectra [K][world x pad].
+
+    Why: the K all-gathers of ~100 kB each are latency-bound launches on the communicator's one
+    stream -- K + 1 collectives per stacked submission of a rank that spends ~0.44 ms on it at
+    C2 / 8 ranks; this form issues two.  Same padding rule as SpectrumGather(uniform=True): shards
+    of one size, the last one shorter (balanced shards, unpacked rank by rank, when a rank would
+    own nothing otherwise); `slots[k]` (where atmosphere k's transit call writes its shard) is part
+    of the send buffer and nothing is packed on the way in."""
+
+    def __init__(self, nwave, world, rank, stack, device, group=None):
+        self.bounds = uniform_bounds(nwave, world)
+        self.uniform = self.bounds is not None
+        if not self.uniform:                      # (a rank would own nothing: balanced shards,
+            self.bounds = shard_bounds(nwave, world)   # unpacked rank by rank)
+        self.world, self.rank, self.group, self.stack = world, rank, group, int(stack)
+        self.nwave = int(nwave)
+        self.pad = int(np.max(np.diff(self.bounds)))
+        K = self.stack
+        self.send = torch.zeros((K, self.pad), dtype=torch.float64, device=device)
+        self.recv = torch.zeros((world, K, self.pad), dtype=torch.float64, device=device)
+        self.sorted = torch.zeros((K, world * self.pad), dtype=torch.float64, device=device)
+        self.full = [self.sorted[k, :self.nwave] for k in range(K)]
+
+    @property
+    def wbegin(self):
+        return int(self.bounds[self.rank])
+
+    @property
+    def wcount(self):
+        return int(self.bounds[self.rank + 1] - self.bounds[self.rank])
+
+    @property
+    def slots(self):
+        """Where the model writes the K shards of this rank (views of the send buffer)."""
+        return [self.send[k, :self.wcount] for k in range(self.stack)]
+
+    def _exchange(self):
+        all_gather_flat(self.recv.view(-1), self.send.view(-1), self.group)
+
+    def __call__(self, local):
+        """local: K tensors [wcount] -> K full spectra [nwave] on every rank."""
+        assert len(local) == self.stack
+        if self.world == 1:
+            return list(local)
+        for k, x in enumerate(local):
+            assert x.shape[0] == self.wcount
+            if x.data_ptr() != self.send[k].data_ptr():
+                self.send[k, :self.wcount].copy_(x)
+        self._exchange()
+        if self.uniform:
+            self.sorted.view(self.stack, self.world, self.pad).copy_(self.recv.transpose(0, 1))
+        else:
+            for r in range(self.world):
+                a, b = int(self.bounds[r]), int(self.bounds[r + 1])
+                self.sorted[:, a:b].copy_(self.recv[r, :, :b - a])
+        return self.full
+
+
 def kmax_allreduce(group=None):
     """The exchange step of the two-phase shard extinction (engine.LBL.extinction_begin/_end):
     returns a function that all-reduces (MAX) the int64 view of the per-row maxima in place --
@@ -408,7 +469,7 @@ class StackedShard:
     """K atmospheres of ONE wavenumber shard per extinction call: their layers are stacked as
     K x L layers of one plan (layer state, records, gather and combine launched once for all of
     them, ONE all-reduce of the K x L x rows maxima), then K transit calls, each writing its shard
-    into a gather slot of its own.
+    into a slot of the one send buffer (StackGather).
 
     Why: a 1/8 shard of C2 is a 0.17-ms gather launch over 7 tiles x 80
     layers plus ~0.09 ms of small launches whose size does not shrink with the number of ranks;
@@ -501,7 +562,8 @@ class ShardPipeline:
     caller's stream.
 
     stack = K > 1 (transit geometry, constant-step grids): every context is a StackedShard -- K
-    atmospheres per extinction call, ONE all-reduce of their maxima, K all-gathers; submit()
+    atmospheres per extinction call, ONE all-reduce of their maxima, ONE all-gather of their K
+    shards (StackGather); submit()
     then enqueues K spectra and returns ([K full spectra], event) of the previous submission."""
 
     def __init__(self, case, world, rank, depth=2, group=None, kmax_exchange=True,
@@ -512,21 +574,21 @@ class ShardPipeline:
         self.stack = int(stack)
         if self.stack > 1:
             assert rt_path == 'transit', 'stack > 1: transit geometry'
-            self.gathers = [[SpectrumGather(nwave, world, rank, 'cuda', group, uniform=True)
-                             for _ in range(self.stack)] for _ in range(depth)]
-            g0 = self.gathers[0][0]
+            self.gathers = [StackGather(nwave, world, rank, self.stack, 'cuda', group)
+                            for _ in range(depth)]
+            g0 = self.gathers[0]
             first = StackedShard(case, self.stack, g0.wbegin, g0.wcount,
                                  itop=model_kw.get('itop', 0), voigt=voigt, lines=lines)
             self.models = [first] + [StackedShard(case, self.stack, g0.wbegin, g0.wcount,
                                                   itop=model_kw.get('itop', 0),
                                                   voigt=first.voigt, lines=first.lines)
                                      for _ in range(depth - 1)]
-            for m, gs in zip(self.models, self.gathers):
+            for m, g in zip(self.models, self.gathers):
                 m.lbl.set_concurrency(depth)
                 if kmax_exchange and world > 1:
                     m.kmax_exchange = kmax_allreduce(group)
                 if world > 1:
-                    m.spectrum_out = [g.slot for g in gs]
+                    m.spectrum_out = g.slots
             self.streams = engine.side_streams(depth)
             self.done = [None] * depth
             self.count = 0
@@ -567,10 +629,7 @@ class ShardPipeline:
         self.pending = None
         stream = self.streams[j]
         with torch.cuda.stream(stream):
-            if self.stack > 1:
-                full = [g(x) for g, x in zip(self.gathers[j], local)]
-            else:
-                full = self.gathers[j](local)
+            full = self.gathers[j](local)        # (stack > 1: K shards, one all-gather)
             event = torch.cuda.Event()
             event.record(stream)
         self.done[j] = event

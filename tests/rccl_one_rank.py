@@ -116,6 +116,34 @@ def main():
     out['shard_pipeline_vs_single'] = err
     assert err <= 1e-12, err
 
+    # (6) the stacked form as rank 1 of 3: K = 2 atmospheres per submission, ONE all-reduce of their
+    #     maxima and ONE all-gather of their two shards (dist.StackGather; on this one-rank group the
+    #     all-gather moves the rank's own K x pad block), the sorting copy at its real size
+    class OneRankStackGather(pbdist.StackGather):
+        def _exchange(self):
+            pbdist.all_gather_flat(self.recv[self.rank].view(-1), self.send.view(-1))
+
+    spipe = pbdist.ShardPipeline(case, 3, 1, depth=2, kmax_exchange=True, voigt=plain.voigt,
+                                 lines=plain.lines, stack=2)
+    spipe.gathers = [OneRankStackGather(nwave, 3, 1, 2, 'cuda') for _ in range(2)]
+    for m, g in zip(spipe.models, spipe.gathers):
+        assert g.uniform
+        m.spectrum_out = g.slots
+    stacked = []
+    for i in range(4):
+        r = spipe.submit()
+        assert (r is None) == (i == 0)
+        if r is not None:
+            stacked += [x.clone() for x in r[0]]
+    stacked += [x.clone() for x in spipe.flush()[0]]
+    torch.cuda.synchronize()
+    assert len(stacked) == 8
+    err = max(float(torch.max(torch.abs(f[a:b] / want[a:b] - 1)).item()) for f in stacked)
+    out['stacked_pipeline_vs_single'] = err
+    assert err <= 1e-12, err
+    # (the blocks of the other ranks were never received: they stay zero)
+    assert all(float(f[:a].abs().max()) == 0.0 for f in stacked)
+
     # (4) walkers gathered over the ranks (replica form of the retrieval batch)
     local = torch.rand((7, 3), dtype=torch.float64, device='cuda')
     assert torch.equal(pbdist.gather_walkers(local, 7, 1, 0), local)

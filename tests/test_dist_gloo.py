@@ -123,6 +123,49 @@ def test_uniform_shards_need_no_unpacking(tmp_path, orc, nwave, world):
             assert np.all(sizes[:-1] == sizes[0]) and 0 < sizes[-1] <= sizes[0]
 
 
+def _worker_stack(rank, world, port, nwave, stack, tmp):
+    sys.path.insert(0, ROOT)
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from pyratbay_amd import dist as pbd
+    gather = pbd.StackGather(nwave, world, rank, stack, 'cpu')
+    a, n = gather.wbegin, gather.wcount
+    want = _stack_spectra(nwave, stack)
+    outs = []
+    for it in range(2):                       # (buffers are re-used from call to call)
+        slots = gather.slots
+        for k in range(stack):
+            if (k + it) % 2:                  # written in place, as StackedShard's transit calls do
+                slots[k].copy_(torch.from_numpy(want[k, a:a + n] + it))
+            else:                             # or handed over: copied into the send buffer
+                slots[k] = torch.from_numpy(want[k, a:a + n] + it)
+        outs.append(np.stack([f.numpy().copy() for f in gather(slots)]))
+    np.savez(os.path.join(tmp, f'rank{rank}.npz'), first=outs[0], second=outs[1],
+             bounds=gather.bounds)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _stack_spectra(nwave, stack):
+    rng = np.random.default_rng(5)
+    return rng.uniform(0.0, 1.0, (stack, nwave))
+
+
+@pytest.mark.parametrize('nwave,world,stack', [(1001, 2, 3), (1003, 3, 2), (1000, 8, 3), (10, 8, 2)])
+def test_stack_gather(tmp_path, nwave, world, stack):
+    """dist.StackGather: the K shards of a stacked submission in ONE all-gather, sorted into K
+    contiguous spectra on every rank (10 samples on 8 ranks: balanced shards, unpacked per rank)."""
+    mp.spawn(_worker_stack, args=(world, _free_port(), nwave, stack, str(tmp_path)), nprocs=world,
+             join=True)
+    want = _stack_spectra(nwave, stack)
+    for rank in range(world):
+        got = np.load(tmp_path / f'rank{rank}.npz')
+        assert np.array_equal(got['first'], want)
+        assert np.array_equal(got['second'], want + 1)
+        assert got['bounds'][0] == 0 and got['bounds'][-1] == nwave
+
+
 def test_shard_bounds_properties():
     from pyratbay_amd.dist import shard_bounds
     for nwave in (1, 7, 8, 100001, 1000001):

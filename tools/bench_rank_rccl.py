@@ -42,6 +42,14 @@ class OneRankGather(pbdist.SpectrumGather):
         return self.full
 
 
+class OneRankStackGather(pbdist.StackGather):
+    """StackGather of rank r of `world` with the all-gather on a one-rank group: this rank's K x pad
+    block into a buffer of its own size; the sorting copy runs at its real size."""
+
+    def _exchange(self):
+        pbdist.all_gather_flat(self.recv[0].view(-1), self.send.view(-1))
+
+
 def measure(world, name='c2', streams=3, steps=200, voigt=None, lines=None, collectives=(True, False),
             log=None, prime_seconds=0.3, keep=False, stack=1):
     """ms per spectrum (and host submission ms) of rank world // 2 of `world`, `streams` spectra in
@@ -54,10 +62,9 @@ def measure(world, name='c2', streams=3, steps=200, voigt=None, lines=None, coll
         # K atmospheres per extinction call (dist.StackedShard): K x streams spectra in flight
         pipe = pbdist.ShardPipeline(case, world, r, depth=streams, kmax_exchange=True, voigt=voigt,
                                     lines=lines, stack=stack)
-        pipe.gathers = [[OneRankGather(nwave, world, r, 'cuda', uniform=True)
-                         for _ in range(stack)] for _ in range(streams)]
-        for m, gs in zip(pipe.models, pipe.gathers):
-            m.spectrum_out = [g.slot for g in gs]
+        pipe.gathers = [OneRankStackGather(nwave, world, r, stack, 'cuda') for _ in range(streams)]
+        for m, g in zip(pipe.models, pipe.gathers):
+            m.spectrum_out = g.slots
     else:
         pipe = pbdist.ShardPipeline(case, world, r, depth=streams, kmax_exchange=True, voigt=voigt,
                                     lines=lines,
@@ -73,11 +80,9 @@ def measure(world, name='c2', streams=3, steps=200, voigt=None, lines=None, coll
         if not coll and stack > 1:
             for m in pipe.models:
                 m.spectrum_out = [None] * stack
-            pipe.gathers = [[pbdist.SpectrumGather(nwave, 1, 0, 'cuda') for _ in range(stack)]
-                            for _ in range(streams)]
-            for gs, m in zip(pipe.gathers, pipe.models):
-                for g in gs:
-                    g.bounds = np.array([0, m.wcount])
+            pipe.gathers = [pbdist.StackGather(nwave, 1, 0, stack, 'cuda') for _ in range(streams)]
+            for g, m in zip(pipe.gathers, pipe.models):   # (world 1: returns the local shards)
+                g.bounds = np.array([0, m.wcount])
         elif not coll:
             for m in pipe.models:
                 m.spectrum_out = None
