@@ -532,6 +532,22 @@ int pb_band_integrate_batch(double *bandflux_d, const double *spectrum_d, const 
                             const double *response_d, const int64_t *response_offset_d,
                             const double *heights_d, int nbands, int nwave, int nwalkers,
                             void *stream);
+/* What the reference makes of a plane-parallel flux after the radiative transfer
+ * (pyrat/spectrum.py:394-405; eval()'s f_lambda conversion, pyrat_obj.py:323-329), per sample:
+ *   fplanet = flux_d [* f_dilution when dilute != 0]
+ *   mode 0 emission: spectrum = fplanet
+ *   mode 1 eclipse : spectrum = fplanet * (1/starflux_d * scale), scale = (rplanet/rstar)^2
+ *   mode 2 f_lambda: spectrum = 10 * fplanet * (scale * wn_d * 1e-4)^2, scale = rplanet/distance
+ * -- the NumPy expressions' products in their order (bit-equal).  fplanet_d may be NULL; spectrum_d
+ * and fplanet_d may alias flux_d. */
+int pb_emission_observables(double *spectrum_d, double *fplanet_d, const double *flux_d,
+                            const double *starflux_d, const double *wn_d, int64_t nwave, int mode,
+                            int dilute, double f_dilution, double scale, void *stream);
+/* bandflux_d[w,b] *= walker_scale_d[w] (f_dilution of walker w, pyrat_obj.py:296-297) and
+ * *= band_scale_d[b] (eclipse: rprs^2 / bandflux_star, pyrat_obj.py:662-665), in that order;
+ * either pointer may be NULL. */
+int pb_band_scale(double *bandflux_d, const double *band_scale_d, const double *walker_scale_d,
+                  int nbands, int nwalkers, void *stream);
 /* eval()'s reject path (pyrat_obj.py:302-320, 378-380): walkers with a temperature outside
  * [tmin, tmax] get bandflux = +inf. */
 int pb_reject_walkers(double *bandflux_d, const double *temps_d, double tmin, double tmax,

@@ -434,6 +434,47 @@ def emission_deck(depth, ideep, wn, temp, mu, weights, rtop, cloud_tsurf=None, c
     return np.sum(inten * np.asarray(weights)[:, None], axis=0)
 
 
+def emission_observables(flux, rt_path, starflux=None, rplanet=None, rstar=None,
+                         f_dilution=None):
+    """What spectrum() makes of a plane-parallel flux after the radiative transfer
+    (pyrat/spectrum.py:394-405) -> (spectrum, fplanet): the dilution factor on every emission-type
+    path, the planet-to-star flux ratio on the eclipse ones."""
+    fplanet = np.array(flux, float)
+    if f_dilution is not None:
+        fplanet *= f_dilution
+    spectrum = fplanet
+    if rt_path in ('eclipse', 'eclipse_two_stream'):
+        fstar_rprs = 1 / np.asarray(starflux) * (rplanet / rstar)**2
+        spectrum = fplanet * fstar_rprs
+    return spectrum, fplanet
+
+
+def f_lambda_units(spectrum, wn, rplanet, distance):
+    """eval()'s conversion of an emission spectrum from erg s-1 cm-2 cm at the planet to
+    W m-2 um-1 at the observer (pyrat_obj.py:323-329; pc.um = 1e-4)."""
+    return 10.0 * np.asarray(spectrum) * (rplanet / distance * np.asarray(wn) * 1.0e-4)**2
+
+
+def band_integrate(spectrum, wn, bands):
+    """Pyrat.band_integrate without the eclipse factor (pyrat_obj.py:649-660): per band
+    PassBand.integrate (spec_tools.py:193-233).  bands: (idx, response, height, photon_counting)."""
+    out = np.zeros(len(bands))
+    for b, (idx, response, height, counting) in enumerate(bands):
+        w = wn[idx]
+        if counting:
+            wl = 1.0 / (w * 1.0e-4)
+            out[b] = np.trapezoid(wl * spectrum[idx] * response, w) * height
+        else:
+            out[b] = np.trapezoid(spectrum[idx] * response, w) * height
+    return out
+
+
+def eclipse_bandflux(bandflux, rplanet, rstar, bandflux_star):
+    """The eclipse branch of Pyrat.band_integrate (pyrat_obj.py:662-665)."""
+    rprs = rplanet / rstar
+    return np.asarray(bandflux) * (rprs**2.0 / np.asarray(bandflux_star))
+
+
 # ---------------------------------------------------------------------------------------------
 # Loader of sampled cross sections (numpy restatement; test infrastructure)
 # ---------------------------------------------------------------------------------------------

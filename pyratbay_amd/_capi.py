@@ -88,6 +88,8 @@ _PROTOS = {
     'pb_emission_flux_batch': [vp, vp, vp, vp, vp, vp, vp, i32, f64, i32, i32, i32, i32, i32, vp],
     'pb_emission_flux_ordered': [vp, vp, vp, vp, vp, vp, vp, vp, i32, f64, i32, i32, i32, i32, i32, vp],
     'pb_band_integrate_batch': [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp],
+    'pb_emission_observables': [vp, vp, vp, vp, vp, i64, i32, i32, f64, f64, vp],
+    'pb_band_scale': [vp, vp, vp, i32, i32, vp],
     'pb_reject_walkers': [vp, vp, f64, f64, i32, i32, i32, vp],
     'pb_optdepth': [vp, vp, i64, vp, i32, f64, vp, i32, i32, vp],
     'pb_optical_depth_transit': [vp, vp, vp, vp, i32, i32, f64, i32, i32, vp],

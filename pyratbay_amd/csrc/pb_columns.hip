@@ -253,6 +253,57 @@ __global__ __launch_bounds__(kBlock) void k_transit_finish(
 }
 
 // ---------------------------------------------------------------------------
+// What the reference makes of a plane-parallel flux AFTER the radiative transfer, per sample
+// (pyrat/spectrum.py:394-405 and eval()'s unit conversion, pyrat_obj.py:323-329):
+//   fplanet  = flux [* f_dilution]
+//   emission : spectrum = fplanet
+//   eclipse  : spectrum = fplanet * (1/starflux * rprs2),     rprs2 = (rplanet/rstar)^2
+//   f_lambda : spectrum = 10.0 * fplanet * (rd * wn * 1e-4)^2, rd = rplanet/distance
+// Same products in the same order as the NumPy expressions (bit-equal); `scale` is rprs2 or rd.
+// spectrum and fplanet may alias flux (the reference's `spec.fplanet = spec.spectrum`).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_emission_observables(
+    double *spectrum, double *fplanet, const double *flux, const double *starflux,
+    const double *wn, int64_t n, int mode, int dilute, double f_dilution, double scale)
+{
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n)
+        return;
+    double f = flux[i];
+    if (dilute)
+        f *= f_dilution;
+    double s = f;
+    if (mode == 1) {
+        const double fstar_rprs = 1.0 / starflux[i] * scale;
+        s = f * fstar_rprs;
+    } else if (mode == 2) {
+        const double t = scale * wn[i] * 1.0e-4;
+        s = 10.0 * f * (t * t);
+    }
+    if (fplanet)
+        fplanet[i] = f;
+    spectrum[i] = s;
+}
+
+// band fluxes of a batch times a per-walker factor (f_dilution, pyrat_obj.py:296-297: applied to
+// the band integral here, to the spectrum in the reference -- the same up to one rounding) and a
+// per-band factor (eclipse: rprs^2 / bandflux_star, pyrat_obj.py:662-665), either may be absent
+__global__ __launch_bounds__(kBlock) void k_band_scale(double *bandflux, const double *band_scale,
+                                                       const double *walker_scale, int nbands,
+                                                       int64_t n)
+{
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n)
+        return;
+    double v = bandflux[i];
+    if (walker_scale)
+        v *= walker_scale[i / nbands];
+    if (band_scale)
+        v *= band_scale[i % nbands];
+    bandflux[i] = v;
+}
+
+// ---------------------------------------------------------------------------
 // _trapezoid.plane_parallel_optical_depth (src_c/_trapezoid.c:175-213)
 // ---------------------------------------------------------------------------
 __global__ void k_plane_depth(double *depth, int32_t *ideep, const double *ec,
@@ -1067,6 +1118,39 @@ int pb_blackbody_wn(double *B_d, const double *wn_d, int nwave, double temp, voi
     PB_REQUIRE(B_d && wn_d, "pb_blackbody_wn: null pointer");
     k_blackbody1d<<<pb::div_up(nwave, kBlock), kBlock, 0, pb::as_stream(stream)>>>(
         B_d, wn_d, nwave, temp);
+    PB_LAUNCH_CHECK();
+    return PB_OK;
+}
+
+int pb_emission_observables(double *spectrum_d, double *fplanet_d, const double *flux_d,
+                            const double *starflux_d, const double *wn_d, int64_t nwave, int mode,
+                            int dilute, double f_dilution, double scale, void *stream)
+{
+    PB_REQUIRE(nwave >= 0, "pb_emission_observables: bad shape");
+    PB_REQUIRE(mode >= 0 && mode <= 2, "pb_emission_observables: mode %d (0 emission, 1 eclipse, "
+                                      "2 f_lambda)", mode);
+    if (nwave == 0)
+        return PB_OK;
+    PB_REQUIRE(spectrum_d && flux_d, "pb_emission_observables: null pointer");
+    PB_REQUIRE(mode != 1 || starflux_d, "pb_emission_observables: eclipse needs the stellar flux");
+    PB_REQUIRE(mode != 2 || wn_d, "pb_emission_observables: f_lambda needs the wavenumbers");
+    k_emission_observables<<<(unsigned)pb::div_up(nwave, (int64_t)kBlock), kBlock, 0,
+                             pb::as_stream(stream)>>>(spectrum_d, fplanet_d, flux_d, starflux_d,
+                                                      wn_d, nwave, mode, dilute, f_dilution, scale);
+    PB_LAUNCH_CHECK();
+    return PB_OK;
+}
+
+int pb_band_scale(double *bandflux_d, const double *band_scale_d, const double *walker_scale_d,
+                  int nbands, int nwalkers, void *stream)
+{
+    PB_REQUIRE(nbands >= 0 && nwalkers >= 0, "pb_band_scale: bad sizes");
+    const int64_t n = (int64_t)nbands * nwalkers;
+    if (n == 0 || (!band_scale_d && !walker_scale_d))
+        return PB_OK;
+    PB_REQUIRE(bandflux_d, "pb_band_scale: null pointer");
+    k_band_scale<<<(unsigned)pb::div_up(n, (int64_t)kBlock), kBlock, 0, pb::as_stream(stream)>>>(
+        bandflux_d, band_scale_d, walker_scale_d, nbands, n);
     PB_LAUNCH_CHECK();
     return PB_OK;
 }

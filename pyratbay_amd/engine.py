@@ -758,6 +758,53 @@ def emission_flux(depth, ideep, wn, temp, mu, weights, rtop, want_intensity=Fals
     return (flux, inten) if want_intensity else flux
 
 
+# the reference's rt_path values by family (constants/code_constants.py:83-102) -> (geometry of the
+# radiative transfer here, what is made of the flux afterwards)
+RT_PATHS = {
+    'transit': ('transit', None),
+    'emission': ('emission', 'emission'),
+    'eclipse': ('emission', 'eclipse'),
+    'f_lambda': ('emission', 'f_lambda'),
+    'two_stream': ('two_stream', 'emission'),
+    'emission_two_stream': ('two_stream', 'emission'),
+    'eclipse_two_stream': ('two_stream', 'eclipse'),
+}
+
+
+def emission_observables(flux, kind='emission', starflux=None, rplanet=None, rstar=None,
+                         f_dilution=None, wn=None, distance=None, in_place=False):
+    """What the reference makes of a plane-parallel flux after the radiative transfer
+    (pyrat/spectrum.py:394-405, eval()'s f_lambda conversion pyrat_obj.py:323-329), one launch:
+    flux[W] -> (spectrum[W], fplanet[W]).
+      fplanet = flux [* f_dilution]
+      kind 'emission': spectrum = fplanet (the same tensor, as in the reference)
+      kind 'eclipse' : spectrum = fplanet * (1/starflux * (rplanet/rstar)**2)
+      kind 'f_lambda': spectrum = 10 * fplanet * (rplanet/distance * wn * 1e-4)**2
+    in_place: fplanet is written over `flux`."""
+    mode = {'emission': 0, 'eclipse': 1, 'f_lambda': 2}[kind]
+    n = flux.shape[0]
+    scale = 0.0
+    if mode == 1:
+        if starflux is None or rplanet is None or rstar is None:
+            raise _capi.PbError('eclipse: starflux[W], rplanet and rstar are needed '
+                                '(pyrat/argum.py:37-44)')
+        assert starflux.shape == flux.shape
+        scale = (float(rplanet) / float(rstar))**2
+    if mode == 2:
+        if wn is None or rplanet is None or distance is None:
+            raise _capi.PbError('f_lambda: wn[W], rplanet and distance are needed')
+        assert wn.shape == flux.shape
+        scale = float(rplanet) / float(distance)
+    if mode == 0 and f_dilution is None:
+        return flux, flux                                   # (`spec.fplanet = spec.spectrum`)
+    fplanet = flux if in_place else torch.empty_like(flux)
+    spectrum = fplanet if mode == 0 else torch.empty_like(flux)
+    call('pb_emission_observables', _ptr(spectrum), None if mode == 0 else _ptr(fplanet),
+         _ptr(flux), _ptr(starflux), _ptr(wn), n, mode, 0 if f_dilution is None else 1,
+         0.0 if f_dilution is None else float(f_dilution), scale, _stream())
+    return spectrum, fplanet
+
+
 def loglike(bandflux, data, uncert):
     """tools/retrieval_tools.py:98-104 for a batch of walkers: bandflux[nw, nbands] (or
     [nbands]) -> loglike[nw]; a non-finite value becomes -1e98, the reference's reject value."""
@@ -830,6 +877,7 @@ class PassBands:
         self.response = dev(np.concatenate([np.asarray(b[1], float) for b in bands]))
         self.heights = dev(np.array([b[2] for b in bands], float))
         self.partial = torch.zeros(self.nbands, dtype=torch.float64, device='cuda')
+        self.scale = None               # per-band factor after the heights (set_eclipse)
 
     def partial_integrate(self, spectrum_full, wbegin=0, wcount=None):
         """Un-scaled partial sums over the pairs whose left sample is in the shard."""
@@ -840,14 +888,37 @@ class PassBands:
              self.nbands, int(wbegin), int(wcount), _stream())
         return self.partial
 
-    def integrate_batch(self, spectra, out=None):
-        """Band fluxes (heights applied) of full-grid spectra[nw, W] -> [nw, nbands]."""
+    def set_eclipse(self, rplanet, rstar, bandflux_star):
+        """Eclipse geometry: integrate_batch() then returns band(fplanet) * rprs**2 / bandflux_star
+        (Pyrat.band_integrate, pyrat_obj.py:662-665).  bandflux_star[nbands] = the band integrals
+        of the stellar flux (pyrat/argum.py:86-90: `star_bandflux()` computes them here)."""
+        rprs = float(rplanet) / float(rstar)
+        self.scale = dev(rprs**2.0 / np.asarray(bandflux_star, float))
+        return self
+
+    def star_bandflux(self, starflux):
+        """bandflux_star of pyrat/argum.py:86-90: the bands' integrals of starflux[W] -> [nbands]
+        (host array)."""
+        scale, self.scale = self.scale, None
+        try:
+            out = self.integrate_batch(dev(starflux).view(1, -1))[0]
+        finally:
+            self.scale = scale
+        return out.cpu().numpy()
+
+    def integrate_batch(self, spectra, out=None, f_dilution=None):
+        """Band fluxes (heights applied; then the walkers' dilution factors f_dilution[nw], if
+        given, and the eclipse factor, if set) of full-grid spectra[nw, W] -> [nw, nbands]."""
         nw, nwave = spectra.shape
         if out is None:
             out = torch.empty((nw, self.nbands), dtype=torch.float64, device=spectra.device)
         call('pb_band_integrate_batch', _ptr(out), _ptr(spectra), _ptr(self.wn),
              _ptr(self.start), _ptr(self.count), _ptr(self.response), _ptr(self.offset),
              _ptr(self.heights), self.nbands, nwave, nw, _stream())
+        if self.scale is not None or f_dilution is not None:
+            assert f_dilution is None or f_dilution.shape == (nw,)
+            call('pb_band_scale', _ptr(out), _ptr(self.scale), _ptr(f_dilution), self.nbands, nw,
+                 _stream())
         return out
 
 
@@ -924,8 +995,18 @@ class LBLSpectrum:
                  quadrature_mu=None, quadrature_weights=None, keep_flat=False,
                  voigt=None, lines=None, tint=0.0, flux_top=None, continuum=None,
                  continuum_density=None, timestamps=True, materialize_depth=True,
-                 predict_runs=False):
+                 predict_runs=False, starflux=None, rplanet=None, f_dilution=None,
+                 distance=None):
         require_gpu()
+        # rt_path: any of the reference's (constants/code_constants.py:83-102) or 'two_stream'
+        # (= emission_two_stream).  self.rt_path is the GEOMETRY of the radiative transfer
+        # ('transit', 'emission', 'two_stream'); self.observable what is made of an emission-type
+        # flux afterwards ('emission', 'eclipse', 'f_lambda'; pyrat/spectrum.py:394-405) from
+        # starflux[nwave], rplanet (with atm['rstar']), f_dilution, distance.
+        if rt_path not in RT_PATHS:
+            raise _capi.PbError(f'rt_path {rt_path!r}: select from {sorted(RT_PATHS)}')
+        self.rt_path_name = rt_path
+        rt_path, self.observable = RT_PATHS[rt_path]
         # per-stage HIP-event timers behind the `timestamps` property (the reference's
         # pyrat.timestamps keys); timestamps=False: run() records no events
         self._timer = StageTimer() if timestamps else None
@@ -1001,6 +1082,18 @@ class LBLSpectrum:
         self.ec = torch.empty((self.nlayers, 1, self.wcount), dtype=torch.float64,
                               device='cuda')
         self.depth = self.ideep = self.spectrum = None
+        # emission-type paths: the planet's flux (after f_dilution) beside `spectrum`, as the
+        # reference's spec.fplanet; eclipse: spectrum = fplanet / starflux * (rplanet/rstar)^2
+        self.fplanet = None
+        self.f_dilution = f_dilution
+        self.rplanet = rplanet if rplanet is not None else atm.get('rplanet')
+        self.distance = distance
+        self.starflux = None
+        if self.observable == 'eclipse':
+            if starflux is None or self.rplanet is None:
+                raise _capi.PbError(f'rt_path {self.rt_path_name!r} needs starflux[nwave] and '
+                                    'rplanet (pyrat/argum.py:37-44)')
+            self.starflux = dev(np.asarray(starflux, float)[wbegin:wbegin + self.wcount])
         # the TLI file's partition-function tables (from_tli): set_atmosphere() without `isoz`
         # evaluates them at the new temperatures on the device
         self.partition = None
@@ -1175,7 +1268,22 @@ class LBLSpectrum:
         else:
             self.spectrum = emission_flux(self.depth, self.ideep, self.wn, self.temp,
                                           self.mu, self.weights, self.itop)
+        if self.rt_path != 'transit':
+            # f_dilution, eclipse ratio (pyrat/spectrum.py:394-405); 'f_lambda' stays in
+            # erg s-1 cm-2 cm here as in the reference's run(): observed() converts
+            kind = 'eclipse' if self.observable == 'eclipse' else 'emission'
+            self.spectrum, self.fplanet = emission_observables(
+                self.spectrum, kind, self.starflux, self.rplanet, self.rstar, self.f_dilution,
+                in_place=self.rt_path != 'two_stream')    # (flux_up[0] stays what two_stream made)
         return self.spectrum
+
+    def observed(self):
+        """The last spectrum as eval() returns it (pyrat_obj.py:323-329): rt_path 'f_lambda'
+        converts the planet's flux to W m-2 um-1 at `distance`; every other path: `spectrum`."""
+        if self.observable != 'f_lambda':
+            return self.spectrum
+        return emission_observables(self.fplanet, 'f_lambda', rplanet=self.rplanet, wn=self.wn,
+                                    distance=self.distance)[0]
 
     def capture(self):
         """Capture one run() into a HIP graph (torch.cuda.CUDAGraph on a side stream) and
@@ -1505,7 +1613,8 @@ class TableSpectrum:
             raise _capi.PbError('this model was built with timestamps=False')
         return self._timer.read()
 
-    def eval_bands(self, temps, dens, bands, radius=None, chunk=64, streams=None):
+    def eval_bands(self, temps, dens, bands, radius=None, chunk=64, streams=None,
+                   f_dilution=None):
         """Batched-walker evaluation (the inner loop of a retrieval, pyrat_obj.py:225-385
         without the parameter mapping): temps[nw, L], dens[nw, L, nspec] device tensors,
         optional per-walker radius[nw, L] (the hydrostatic profile changes with every model),
@@ -1514,9 +1623,13 @@ class TableSpectrum:
         band integration -- with no per-walker Python and no host synchronisation (except the
         one-time column ordering of the first call with column_order='auto': class docstring).  Walkers
         whose temperatures leave the table's range get +inf, like eval()'s reject path
-        (pyrat_obj.py:302-320, 378-380)."""
+        (pyrat_obj.py:302-320, 378-380).  Emission geometry: f_dilution[nw] = the walkers'
+        dilution factors (pyrat_obj.py:296-297), and bands.set_eclipse(...) for the planet-to-star
+        flux ratios of an eclipse retrieval (pyrat_obj.py:662-665)."""
         assert self.rt_path in ('transit', 'emission') and self.continuum is None, \
             'eval_bands: transit or emission geometry on sampled cross sections'
+        assert f_dilution is None or self.rt_path == 'emission', 'f_dilution: emission geometry'
+        self._f_dilution = f_dilution
         nw = temps.shape[0]
         out = torch.empty((nw, bands.nbands), dtype=torch.float64, device='cuda')
         if radius is None:
@@ -1647,7 +1760,9 @@ class TableSpectrum:
                                               temps[w0:w1], self.mu, self.weights, self.itop,
                                               self.nlayers, self.maxdepth,
                                               self.column_order if ordered else None)
-            bands.integrate_batch(spectra, out[w0:w1])
+            fd = getattr(self, '_f_dilution', None)
+            bands.integrate_batch(spectra, out[w0:w1],
+                                  None if fd is None else fd[w0:w1].contiguous())
             return
         if shared_radius:
             rad = radius.expand(n, -1).contiguous()
