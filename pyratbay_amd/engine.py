@@ -1629,7 +1629,7 @@ class TableSpectrum:
         assert self.rt_path in ('transit', 'emission') and self.continuum is None, \
             'eval_bands: transit or emission geometry on sampled cross sections'
         assert f_dilution is None or self.rt_path == 'emission', 'f_dilution: emission geometry'
-        self._f_dilution = f_dilution
+        assert f_dilution is None or f_dilution.shape == (temps.shape[0],)
         nw = temps.shape[0]
         out = torch.empty((nw, bands.nbands), dtype=torch.float64, device='cuda')
         if radius is None:
@@ -1672,10 +1672,10 @@ class TableSpectrum:
             if streams > 1:
                 with torch.cuda.stream(self._eval_streams[ci % streams]):
                     self._eval_chunk(temps, dens, bands, radius, shared_radius, path1, out, w0,
-                                     min(w0 + chunk, nw))
+                                     min(w0 + chunk, nw), f_dilution)
             else:
                 self._eval_chunk(temps, dens, bands, radius, shared_radius, path1, out, w0,
-                                 min(w0 + chunk, nw))
+                                 min(w0 + chunk, nw), f_dilution)
         if streams > 1:
             for st in self._eval_streams[:streams]:
                 caller.wait_stream(st)
@@ -1704,7 +1704,8 @@ class TableSpectrum:
         return bool(want) and table_transit_supported(self.nspec, self.ntemp, self.nlayers,
                                                       self.itop, self.nlayers, self.nwave)
 
-    def _eval_chunk(self, temps, dens, bands, radius, shared_radius, path1, out, w0, w1):
+    def _eval_chunk(self, temps, dens, bands, radius, shared_radius, path1, out, w0, w1,
+                    f_dilution=None):
         """One chunk of eval_bands: walkers [w0, w1) through every stage, one launch each."""
         n = w1 - w0
         if self.rt_path == 'transit' and self._one_pass():
@@ -1760,9 +1761,8 @@ class TableSpectrum:
                                               temps[w0:w1], self.mu, self.weights, self.itop,
                                               self.nlayers, self.maxdepth,
                                               self.column_order if ordered else None)
-            fd = getattr(self, '_f_dilution', None)
             bands.integrate_batch(spectra, out[w0:w1],
-                                  None if fd is None else fd[w0:w1].contiguous())
+                                  None if f_dilution is None else f_dilution[w0:w1].contiguous())
             return
         if shared_radius:
             rad = radius.expand(n, -1).contiguous()
