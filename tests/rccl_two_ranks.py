@@ -3,7 +3,8 @@
 phase shards, the all-reduce(MAX) of the maxima on the aliasing tensor, equal-size shards gathered
 by one all-gather, three spectra in flight) against the spectrum computed whole on this rank's GPU,
 and the two-phase shard extinction against the one-call form bit for bit at PB_STAGE_SPLIT=1;
-the layer decomposition (all-to-all + all-gather, pipelined) against the same spectrum."""
+the layer decomposition (all-to-all + all-gather, pipelined) and the stacked shards (two
+atmospheres per submission, one all-gather of both) against the same spectrum."""
 import json
 import os
 import sys
@@ -58,7 +59,23 @@ def main():
     torch.cuda.synchronize()
     out['layers_vs_single'] = max(float(torch.max(torch.abs(o / want - 1)).item()) for o in outs)
 
-    worst = torch.tensor([out['wavenumber_vs_single'], out['layers_vs_single'],
+    # the stacked form bench.py --gpus N runs: 2 atmospheres per submission, one all-reduce of their
+    # maxima, ONE all-gather of their shards (dist.StackGather), two submissions in flight
+    spipe = pbdist.ShardPipeline(case, world, rank, depth=2, kmax_exchange=True,
+                                 voigt=whole.voigt, lines=whole.lines, stack=2)
+    stacked = []
+    for i in range(4):
+        r = spipe.submit()
+        if r is not None:
+            stacked += [x.clone() for x in r[0]]
+    stacked += [x.clone() for x in spipe.flush()[0]]
+    torch.cuda.synchronize()
+    assert len(stacked) == 8
+    out['stacked_vs_single'] = max(float(torch.max(torch.abs(f / want - 1)).item())
+                                   for f in stacked)
+
+    worst = torch.tensor([out['wavenumber_vs_single'],
+                          max(out['layers_vs_single'], out['stacked_vs_single']),
                           0.0 if out['two_phase_equals_one_call'] else 1.0],
                          dtype=torch.float64, device='cuda')
     dist.all_reduce(worst, op=dist.ReduceOp.MAX)
