@@ -1277,6 +1277,36 @@ class LBLSpectrum:
                 in_place=self.rt_path != 'two_stream')    # (flux_up[0] stays what two_stream made)
         return self.spectrum
 
+    def get_ec(self, layer):
+        """Pyrat.get_ec(layer) for the line-by-line model (pyrat_obj.py:700-719 ->
+        line_by_line.py:224-230): the cross sections of ONE layer per species (`add = 0`,
+        extinction.py:155-158) times that species' number density -> (ec[nspec, wcount] in cm-1 on
+        the device, labels).  A species is a row of `isoiext`; its label is atm['species'] of the
+        molecule its isotopes belong to (the row index when the case names none).  (The reference
+        multiplies every row by `density[layer]` of ALL the model's species at once, which only
+        broadcasts for a single-species model; here each row takes its own species' density.)"""
+        atm, iso = self.case['atm'], self.case['iso']
+        layer = int(layer)
+        if not 0 <= layer < self.nlayers:
+            raise _capi.PbError(f'get_ec: layer {layer} outside 0 ... {self.nlayers - 1}')
+        sl = slice(layer, layer + 1)
+        ec = self.lbl.extinction(self.temp[sl], self.dens[sl].contiguous(),
+                                 self.isoz[:, sl].contiguous(), add=False, wbegin=self.wbegin,
+                                 wcount=self.wcount)[0]
+        isoiext = np.asarray(iso['isoiext'])
+        isoimol = np.asarray(iso['isoimol'])
+        imol = [int(isoimol[np.flatnonzero(isoiext == r)[0]]) if np.any(isoiext == r) else -1
+                for r in range(ec.shape[0])]
+        dens = self.dens[layer]
+        scale = torch.stack([dens[m] if m >= 0 else torch.zeros_like(dens[0]) for m in imol])
+        names = atm.get('species')
+        labels = [str(names[m]) if names is not None and m >= 0 else str(r)
+                  for r, m in enumerate(imol)]
+        # ec[r, :] *= scale[r] (pb_band_scale with the rows as its 'walkers')
+        call('pb_band_scale', _ptr(ec), None, _ptr(scale.contiguous()), ec.shape[1], ec.shape[0],
+             _stream())
+        return ec, labels
+
     def observed(self):
         """The last spectrum as eval() returns it (pyrat_obj.py:323-329): rt_path 'f_lambda'
         converts the planet's flux to W m-2 um-1 at `distance`; every other path: `spectrum`."""

@@ -115,3 +115,26 @@ def test_partition_table_for_a_batch_of_walkers(golden):
     assert outside.any()
     assert np.array_equal(np.isnan(z[:, 5, 7]), outside) and np.isnan(z).sum() == outside.sum()
     torch.cuda.synchronize()
+
+
+def test_get_ec_of_single_layers(golden):
+    """Pyrat.get_ec(layer) of the real package on the G6 transit run (fixture G20,
+    make_golden_get_ec.py): the per-species extinction of single layers (add = 0 cross sections x
+    the species' density) from the TLI file + atmosphere alone."""
+    from pyratbay_amd import engine
+    g = golden('g6_e2e_transit')
+    g20 = golden('g20_get_ec')
+    grid, atm, voigt = _config(g)
+    model = engine.LBLSpectrum.from_tli(TLI, atm, grid, ethresh=float(g['ethresh']),
+                                        maxdepth=float(g['maxdepth']), rt_path='transit',
+                                        itop=int(g['rtop']), **voigt)
+    for layer in g20['layers']:
+        ec, labels = model.get_ec(int(layer))
+        assert labels == [str(x) for x in g20[f'labels_{layer}']] == ['H2O']
+        want = g20[f'ec_{layer}']
+        got = ec.cpu().numpy()
+        assert got.shape == want.shape
+        assert np.array_equal(got == 0, want == 0)
+        np.testing.assert_allclose(got, want, rtol=1e-12)
+    with pytest.raises(Exception, match='layer'):
+        model.get_ec(len(g['temp']))
