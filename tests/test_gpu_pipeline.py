@@ -540,6 +540,33 @@ def test_shard_pipeline_stacked_atmospheres(eng, case, monkeypatch, stack):
         del pipe
 
 
+@pytest.mark.parametrize('nlayers,stack', [(120, 4), (200, 3), (80, 8)])
+def test_stacked_shard_many_layers(eng, nlayers, stack):
+    """dist.StackedShard beyond the bench's shape: C4's 120 layers x 4 atmospheres, 600 and 640
+    stacked layers in one extinction call (layer indices above 255 in the unit table, the per-row
+    maxima of every stacked layer) -- each atmosphere's spectrum equals the serial run's."""
+    import torch
+    from pyratbay_amd import synth
+    from pyratbay_amd.dist import StackedShard
+    case = synth.lbl_case(2001, nlayers, 8000, wnosamp=24, nlor=20, ndop=10, extent=80.0,
+                          cutoff=4.0, niso=2, seed=3)
+    serial = eng.LBLSpectrum(case, rt_path='transit')
+    atm, iso = case['atm'], case['iso']
+    shard = StackedShard(case, stack, voigt=serial.voigt, lines=serial.lines)
+    want = []
+    for k in range(stack):
+        temp = atm['temp'] * (1 + 0.03 * k)
+        dens = atm['dens'] * (atm['temp'] / temp)[:, None]
+        serial.set_atmosphere(temp, dens, iso['isoz'])
+        want.append(serial.run().clone())
+        shard.set_atmosphere(k, temp, dens, iso['isoz'])
+    got = shard.run()
+    torch.cuda.synchronize()
+    assert not torch.equal(want[0], want[-1])
+    for g, w in zip(got, want):
+        np.testing.assert_allclose(g.cpu().numpy(), w.cpu().numpy(), rtol=1e-12)
+
+
 @pytest.mark.gpu_experiments
 def test_resolution_mode_predicted_runs(eng, monkeypatch):
     """`resolution` mode with the run plan taken from the last read-back of the layers' factors
