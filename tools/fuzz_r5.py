@@ -11,6 +11,10 @@
       per call on a random shard against LBLSpectrum.run() of each (1e-12), one rank;
   (4) line lists whose isotopes interleave (accepted, equal to the oracle's sequential pass) and
       lists that step back within an isotope (refused).
+  (5) what follows the radiative transfer on the emission-type paths (engine.emission_observables,
+      PassBands.set_eclipse / star_bandflux / per-walker dilution): random fluxes of 1 ... 5000
+      samples with zeros, infinities and NaNs planted in flux and stellar flux, against the
+      oracle's NumPy restatement BIT FOR BIT (band fluxes 1e-13).
 usage: python tools/fuzz_r5.py [count] [seed0]"""
 import os
 import sys
@@ -234,19 +238,75 @@ def order_case(eng, orc, rng, seed):
             raise AssertionError('a list that steps back within an isotope was accepted')
 
 
+def same_bits(a, b):
+    return a.shape == b.shape and bool(np.all((a == b) | (np.isnan(a) & np.isnan(b)))) and \
+        bool(np.all(np.signbit(a) == np.signbit(b)))
+
+
+def observables_case(eng, orc, rng):
+    W = int(rng.choice([1, 2, 63, 64, 65, 257, 1000, 5000]))
+    wn = np.sort(rng.uniform(500.0, 30000.0, W))
+    flux = 10.0**rng.uniform(-3, 7, W)
+    star = 10.0**rng.uniform(4, 8, W)
+    for arr in (flux, star):
+        for val in (0.0, -0.0, np.inf, np.nan, 5e-324, 1e308):
+            if rng.random() < 0.3:
+                arr[rng.integers(0, W)] = val
+    rplanet, rstar, distance = 10.0**rng.uniform(8, 10), 10.0**rng.uniform(10, 11), 10.0**rng.uniform(18, 21)
+    dil = None if rng.random() < 0.4 else float(rng.uniform(0.0, 1.0))
+    dflux, dstar, dwn = eng.dev(flux), eng.dev(star), eng.dev(wn)
+    with np.errstate(all='ignore'):
+        for kind in ('emission', 'eclipse'):
+            got, fp = eng.emission_observables(dflux, kind, dstar, rplanet, rstar, dil)
+            want, wfp = orc.emission_observables(flux, kind, star, rplanet, rstar, dil)
+            assert same_bits(host(got), want) and same_bits(host(fp), wfp), kind
+        got, fp = eng.emission_observables(dflux, 'f_lambda', rplanet=rplanet, f_dilution=dil,
+                                           wn=dwn, distance=distance)
+        _, wfp = orc.emission_observables(flux, 'emission', f_dilution=dil)
+        assert same_bits(host(got), orc.f_lambda_units(wfp, wn, rplanet, distance))
+        assert same_bits(host(fp), wfp)
+    assert same_bits(host(dflux), flux)                       # never in place unless asked
+    # bands: eclipse factor and per-walker dilution on finite spectra
+    if W >= 8:
+        nb = int(rng.integers(1, 6))
+        bands = []
+        for _ in range(nb):
+            lo = int(rng.integers(0, W - 2))
+            hi = int(rng.integers(lo + 2, W + 1))
+            bands.append((lo, rng.uniform(0.0, 1.0, hi - lo), float(rng.uniform(0.1, 3.0))))
+        pb = eng.PassBands(wn, bands)
+        star_f = 10.0**rng.uniform(4, 8, W)
+        sb = pb.star_bandflux(star_f)
+        want_sb = np.array([np.trapezoid(star_f[s:s + len(r)] * r, wn[s:s + len(r)]) * h
+                            for s, r, h in bands])
+        np.testing.assert_allclose(sb, want_sb, rtol=1e-13)
+        nw = int(rng.integers(1, 5))
+        spectra = 10.0**rng.uniform(-3, 7, (nw, W))
+        fd = rng.uniform(0.1, 1.0, nw)
+        pb.set_eclipse(rplanet, rstar, sb)
+        got = host(pb.integrate_batch(eng.dev(spectra), f_dilution=eng.dev(fd)))
+        plain = np.array([[np.trapezoid(sp[s:s + len(r)] * r, wn[s:s + len(r)]) * h
+                           for s, r, h in bands] for sp in spectra])
+        want = orc.eclipse_bandflux(plain * fd[:, None], rplanet, rstar, sb)
+        np.testing.assert_allclose(got, want, rtol=1e-13)
+
+
 def main():
     count = int(sys.argv[1]) if len(sys.argv) > 1 else 300
     seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 51000
     from pyratbay_amd import engine as eng
     from oracle import oracle as orc
     eng.require_gpu()
-    fails, repaired, n = 0, 0, [0, 0, 0, 0]
+    fails, repaired, n = 0, 0, [0, 0, 0, 0, 0]
     for i in range(count):
         seed = seed0 + i
         rng = np.random.default_rng(seed)
         try:
             kind = i % 8
-            if kind < 4:
+            if i % 16 == 3:
+                observables_case(eng, orc, rng)
+                n[4] += 1
+            elif kind < 4:
                 repaired += limited_case(eng, rng)
                 n[0] += 1
             elif kind < 6:
@@ -264,7 +324,7 @@ def main():
             traceback.print_exc()
     print(f'fuzz_r5: {count} cases from seed {seed0}: {fails} failures; tile-limited batches '
           f'{n[0]} ({repaired} with a repair pass), eval_bands with random margins {n[1]}, stacked '
-          f'shards {n[2]}, interleaved / stepping-back line lists {n[3]}')
+          f'shards {n[2]}, interleaved / stepping-back line lists {n[3]}, observables {n[4]}')
     print('failures: []' if not fails else f'failures: {fails}')
     return 1 if fails else 0
 
